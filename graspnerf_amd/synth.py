@@ -1,0 +1,66 @@
+"""Synthetic scene generator for benchmarks, tests and golden fixtures.
+
+Everything is drawn from `numpy.random.default_rng(1000 + scene_id)` (PCG64, platform
+stable) in a fixed order, so the GPU box regenerates bit-identical inputs from a seed and the
+fixtures only need to store outputs.  Cameras sit on a ring looking at the workspace centre
+(OpenCV axes, world->camera poses), intrinsics follow the reference planner
+(ref: src/nr/main.py:105-112), depth range [0.2, 0.8] (main.py:181-183), workspace bbox
+[[-0.15,-0.15,-0.05],[0.15,0.15,0.25]] (ref: src/nr/dataset/database.py:122-123).
+"""
+import numpy as np
+
+CONFIGS = {
+    # BASELINE.json configs[0]: 1 scene, 3 views, 16^3, small images (CPU plumbing case)
+    'cfg1': dict(V=3, H=96, W=128, res=16, rn=64,
+                 K=[[100.0, 0, 63.5], [0, 100.0, 47.5], [0, 0, 1]]),
+    # BASELINE.json configs[1..3]: 6 views, 288x512, 40^3, 512 rays
+    'cfg2': dict(V=6, H=288, W=512, res=40, rn=512,
+                 K=[[357.048, 0, 255.8], [0, 357.048, 143.8], [0, 0, 1]]),
+}
+
+
+def ring_cameras(V, radius=0.5, theta=np.pi / 3, target=(0.0, 0.0, 0.1)):
+    """[V,3,4] world->camera, OpenCV convention (z forward, x right, y down)."""
+    poses = []
+    tgt = np.asarray(target, np.float64)
+    for i in range(V):
+        phi = 2 * np.pi * i / V
+        eye = np.array([radius * np.sin(theta) * np.cos(phi),
+                        radius * np.sin(theta) * np.sin(phi),
+                        radius * np.cos(theta) + tgt[2]])
+        zf = tgt - eye
+        zf /= np.linalg.norm(zf)
+        xr = np.cross(zf, np.array([0.0, 0.0, 1.0]))
+        xr /= np.linalg.norm(xr)
+        yd = np.cross(zf, xr)
+        R = np.stack([xr, yd, zf], 0)
+        poses.append(np.concatenate([R, (-R @ eye)[:, None]], 1))
+    return np.asarray(poses, np.float32)
+
+
+def make_scene(scene_id=0, cfg='cfg2', with_query_image=True):
+    """-> (ref dict, que dict) of float32 numpy arrays.
+    ref: imgs[V,3,H,W] in [0,1], img_feats/ray_feats[V,32,H/4,W/4], poses[V,3,4], Ks[V,3,3],
+         depth_range[V,2], bbox3d[2,3]
+    que: coords[rn,2] (x,y) float, pose[3,4], K[3,3], depth_range[2], imgs[1,3,H,W] (= view 0)."""
+    c = CONFIGS[cfg] if isinstance(cfg, str) else cfg
+    V, H, W, rn = c['V'], c['H'], c['W'], c['rn']
+    fh, fw = H // 4, W // 4
+    rng = np.random.default_rng(1000 + scene_id)
+    imgs = rng.random((V, 3, H, W)).astype(np.float32)
+    img_feats = (0.5 * rng.standard_normal((V, 32, fh, fw))).astype(np.float32)
+    ray_feats = (0.5 * rng.standard_normal((V, 32, fh, fw))).astype(np.float32)
+    cx = rng.integers(0, W, rn)
+    cy = rng.integers(0, H, rn)
+    coords = np.stack([cx, cy], -1).astype(np.float32)
+    poses = ring_cameras(V)
+    K = np.asarray(c['K'], np.float32)
+    ref = dict(imgs=imgs, img_feats=img_feats, ray_feats=ray_feats, poses=poses,
+               Ks=np.repeat(K[None], V, 0).copy(),
+               depth_range=np.repeat(np.asarray([[0.2, 0.8]], np.float32), V, 0).copy(),
+               bbox3d=np.asarray([[-0.15, -0.15, -0.05], [0.15, 0.15, 0.25]], np.float32))
+    que = dict(coords=coords, pose=poses[0].copy(), K=K.copy(),
+               depth_range=np.asarray([0.2, 0.8], np.float32))
+    if with_query_image:
+        que['imgs'] = imgs[:1].copy()
+    return ref, que

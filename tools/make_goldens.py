@@ -1,0 +1,170 @@
+"""Generate golden vectors by importing and running the REFERENCE (/root/reference) on CPU.
+
+Runs only in the build container (the reference cannot travel to the GPU box).  Emits
+  tests/golden/weights_seed0.npz   hot-path parameters (reference state-dict keys)
+  tests/golden/golden_cfg1.npz     V=3, 16^3, 96x128: reference outputs (+ sha256 of inputs)
+  tests/golden/golden_cfg2.npz     V=6, 40^3, 288x512, 512 rays: reference outputs
+Inputs are NOT stored: tests regenerate them from graspnerf_amd.synth.make_scene(seed) and
+check the recorded SHA-256.
+
+Weights: `torch.manual_seed(0)` construction of the reference NeuralRayRenderer, then every
+hot-path bias / LayerNorm parameter gets + 0.1*N(0,1) (the reference zero-initialises most
+biases, ibrnet.py:104-109, which would leave bias handling untested).
+
+Usage:  python tools/make_goldens.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from ref_import import import_reference, REF  # noqa: E402
+from graspnerf_amd.synth import make_scene, CONFIGS  # noqa: E402
+
+HOT = ('dist_decoder.', 'fine_dist_decoder.', 'agg_net.', 'fine_agg_net.')
+
+
+def sha(arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def build_net(renderer, res, dn):
+    cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
+    cfg['volume_resolution'] = res
+    cfg['depth_sample_num'] = dn
+    cfg['fine_depth_sample_num'] = dn
+    cfg['agg_net_cfg']['sample_num'] = dn
+    cfg['fine_agg_net_cfg']['sample_num'] = dn
+    torch.manual_seed(0)
+    net = renderer.NeuralRayRenderer(cfg)
+    net.eval()
+    return net, cfg
+
+
+def perturb_and_export(net):
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if not k.startswith(HOT):
+                continue
+            if k.endswith('.bias') or 'layer_norm' in k:
+                v.add_(0.1 * torch.randn(v.shape, generator=g))
+            out[k] = v.detach().clone().numpy()
+    return out
+
+
+def load_weights(net, weights):
+    sd = net.state_dict()
+    for k, v in weights.items():
+        sd[k].copy_(torch.from_numpy(v))
+
+
+def run_reference(renderer, net, cfg, ref, que, res):
+    """-> dict of numpy outputs of the reference sample_volume + render (eval mode)."""
+    import network.render_ops as rops
+    import utils.field_utils as fu
+    # 16^3 support: the grid is a module constant (field_utils.py:12,27)
+    if res != 40:
+        fu.RESOLUTION = res
+        fu.VOXEL_SIZE = fu.VOLUME_SIZE / res
+        fu.HALF_VOXEL_SIZE = fu.VOXEL_SIZE / 2
+        renderer.TSDF_SAMPLE_POINTS = fu.generate_grid_points()
+    else:
+        fu.RESOLUTION = 40
+        fu.VOXEL_SIZE = fu.VOLUME_SIZE / 40
+        fu.HALF_VOXEL_SIZE = fu.VOXEL_SIZE / 2
+        renderer.TSDF_SAMPLE_POINTS = fu.generate_grid_points()
+    t = lambda a: torch.from_numpy(a.copy())
+    ref_info = {k: t(v) for k, v in ref.items()}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None],
+                'Ks': t(que['K'])[None], 'depth_range': t(que['depth_range'])[None],
+                'imgs': t(que['imgs'])}
+    out = {}
+    with torch.no_grad():
+        vol = net.sample_volume(ref_info)
+    out['volume'] = vol.numpy()
+    # volume-path masks (bit-exact check): re-run the reference projection on the same points
+    pts = (torch.from_numpy(renderer.TSDF_SAMPLE_POINTS) + ref_info['bbox3d'][0]).reshape(1, res * res, res, 3)
+    pts = torch.flip(pts, (2,))
+    prj = rops.project_points_dict(ref_info, pts)
+    out['volume_mask_bits'] = np.packbits(prj['mask'].numpy().astype(bool).reshape(-1))
+    uv = prj['pts'].numpy().reshape(ref['poses'].shape[0], -1, 2)
+    h, w = ref['imgs'].shape[-2:]
+    marg = np.minimum.reduce([np.abs(uv[..., 0] + 0.5), np.abs(uv[..., 0] - (w - 0.5)),
+                              np.abs(uv[..., 1] + 0.5), np.abs(uv[..., 1] - (h - 0.5))])
+    out['volume_mask_min_margin_px'] = np.float32(marg.min())
+
+    # render (coarse + fine), capturing searchsorted indices and the fine depths
+    captured = {}
+    orig_ss = torch.searchsorted
+    orig_sort = torch.sort
+
+    def ss(cdf, u, **kw):
+        r = orig_ss(cdf, u, **kw)
+        captured['inds'] = r.clone()
+        captured['cdf'] = cdf.clone()
+        captured['u'] = u.clone()
+        return r
+
+    def srt(x, *a, **kw):
+        r = orig_sort(x, *a, **kw)
+        captured['fine_depth_sorted'] = r[0].clone()
+        return r
+    torch.searchsorted = ss
+    torch.sort = srt
+    try:
+        with torch.no_grad():
+            rend = net.render(que_info, ref_info, False)
+    finally:
+        torch.searchsorted = orig_ss
+        torch.sort = orig_sort
+    for k, v in rend.items():
+        out['render.' + k] = v.numpy()
+    out['fine_inds'] = captured['inds'].numpy()[0].astype(np.int64)
+    out['fine_depth_sorted'] = captured['fine_depth_sorted'].numpy()[0]
+    cdf, u = captured['cdf'].numpy()[0], captured['u'].numpy()[0]
+    out['fine_inds_min_margin'] = np.float32(np.abs(u[:, :, None] - cdf[:, None, :]).min())
+    return out
+
+
+def main():
+    renderer = import_reference()
+    os.makedirs(ROOT + '/tests/golden', exist_ok=True)
+    net40, cfg40 = build_net(renderer, 40, 40)
+    weights = perturb_and_export(net40)
+    np.savez_compressed(ROOT + '/tests/golden/weights_seed0.npz', **weights)
+    print('weights:', sum(v.size for v in weights.values()), 'floats')
+
+    for name, res, dn, net_cfg in (('cfg2', 40, 40, (net40, cfg40)), ('cfg1', 16, 16, None)):
+        if net_cfg is None:
+            net, cfg = build_net(renderer, res, dn)
+            load_weights(net, weights)
+        else:
+            net, cfg = net_cfg
+        ref, que = make_scene(0, name)
+        out = run_reference(renderer, net, cfg, ref, que, res)
+        out['input_sha256'] = np.frombuffer(sha([ref[k] for k in sorted(ref)] +
+                                                 [que[k] for k in sorted(que)]).encode(), np.uint8)
+        out['dn'] = np.int64(dn)
+        np.savez_compressed(ROOT + f'/tests/golden/golden_{name}.npz', **out)
+        print(name, 'volume range', out['volume'].min(), out['volume'].max(),
+              'mask margin', out['volume_mask_min_margin_px'], 'inds margin', out['fine_inds_min_margin'])
+        for k, v in out.items():
+            print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
+
+
+if __name__ == '__main__':
+    main()
