@@ -1,0 +1,92 @@
+"""ctypes binding of libgnr.so (include/gnr.h).  The product path has NO CPU fallback: if the
+library is missing or fails to load, importing the hot path raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libgnr.so')
+
+GNR_OK = 0
+ERRORS = {-1: 'GNR_ERR_ARG', -2: 'GNR_ERR_SHAPE', -3: 'GNR_ERR_HIP', -4: 'GNR_ERR_WORKSPACE'}
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class GnrScene(C.Structure):
+    _fields_ = [('B', C.c_int), ('V', C.c_int), ('H', C.c_int), ('W', C.c_int), ('fh', C.c_int), ('fw', C.c_int),
+                ('imgs', C.c_void_p), ('img_feats', C.c_void_p), ('ray_feats', C.c_void_p),
+                ('poses', C.c_void_p), ('Ks', C.c_void_p), ('depth_range', C.c_void_p)]
+
+
+class GnrRays(C.Structure):
+    _fields_ = [('rn', C.c_int), ('dn', C.c_int), ('fdn', C.c_int),
+                ('ray_mask_view_num', C.c_int), ('ray_mask_point_num', C.c_int),
+                ('coords', C.c_void_p), ('que_pose', C.c_void_p), ('que_K', C.c_void_p),
+                ('que_depth_range', C.c_void_p), ('que_imgs', C.c_void_p)]
+
+
+RENDER_OUT_FIELDS = ['depth', 'sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr',
+                     'pixel_colors_gt', 'render_depth', 'ray_mask', 'sdf_gradient_error', 'sdf_gradient', 'view_mask']
+
+
+class GnrRenderOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in RENDER_OUT_FIELDS]
+
+
+class GnrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libgnr.so once.  Raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnrError(f'{LIB_PATH} not found: build it with graspnerf_amd/csrc/build.sh '
+                       f'(or __graft_entry__.build()); there is no CPU fallback for the hot path')
+    L = C.CDLL(LIB_PATH)
+    L.gnr_canonical_weights_floats.restype = C.c_int
+    L.gnr_packed_weights_floats.restype = C.c_int
+    L.gnr_pack_weights.argtypes = [c_float_p, c_float_p]
+    L.gnr_pack_weights.restype = C.c_int
+    L.gnr_layout_offset.argtypes = [C.c_char_p]
+    L.gnr_layout_offset.restype = C.c_int
+    L.gnr_workspace_bytes.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_int, C.c_int]
+    L.gnr_workspace_bytes.restype = C.c_size_t
+    L.gnr_prepare.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_prepare.restype = C.c_int
+    L.gnr_sample_volume_fwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_sample_volume_fwd.restype = C.c_int
+    L.gnr_debug_volume_chain.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_debug_volume_chain.restype = C.c_int
+    L.gnr_render_by_depth_fwd.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_int, C.c_void_p,
+                                          C.POINTER(GnrRenderOut), C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_render_by_depth_fwd.restype = C.c_int
+    L.gnr_render_rays_fwd.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_void_p,
+                                      C.POINTER(GnrRenderOut), C.POINTER(GnrRenderOut), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_render_rays_fwd.restype = C.c_int
+    L.gnr_time_chain_kernel.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                        c_float_p, C.c_void_p]
+    L.gnr_time_chain_kernel.restype = C.c_int
+    L.gnr_last_error.restype = C.c_char_p
+    L.gnr_dominant_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_layout_offset', 'gnr_workspace_bytes',
+            'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
+            'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel']
+
+
+def check(rc, what):
+    if rc != GNR_OK:
+        msg = lib().gnr_last_error().decode(errors='replace')
+        raise GnrError(f'{what} failed: {ERRORS.get(rc, rc)} ({msg})')

@@ -1,0 +1,1056 @@
+// gfx950 (MI355X / CDNA4) kernels of the GraspNeRF volumetric hot path.
+//
+//   k_repack_feats   NCHW img_feats + ray_feats -> [B*V][fh][fw][64] channel-last (one 256-B
+//                    line per bilinear tap)
+//   k_view_setup     per view: H = K[R|t], camera centre, inverse-depth range
+//   k_points_volume  per voxel centre descriptor, column order, top->down  (renderer.py:167-170)
+//   k_coarse_depth / k_points_rays   ray samples (render_ops.py:4-52,146-170)
+//   k_chain<V,RENDER> THE hot kernel: per-(point,view) projection + gather + mixture decoder +
+//                    prob-embed + IBRNet aggregation + geometry MLP, all layers as chained
+//                    v_mfma_f32_16x16x4_f32 with activations resident in registers
+//                    (dist_decoder.py:99-142, aggregate_net.py:35-70, ibrnet.py:456-489,506-512)
+//   k_ray<RENDER>    per ray / voxel column: 40-token self-attention + SDF head, and for rays the
+//                    in-forward VJP, NeuS alpha, compositing, ray mask and inverse-CDF resampling
+//                    (ibrnet.py:490-504, aggregate_net.py:105-121, render_ops.py:72-80,172-229)
+//
+// Layout conventions are documented in gnr_layout.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gnr_layout.h"
+
+namespace gnr {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define DEV __device__ __forceinline__
+
+DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+DEV float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+DEV float sigmoid1(float x) { return 1.f / (1.f + __expf(-x)); }
+DEV float softplus1(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+DEV float tanh1(float x) {            // 1 - 2/(e^{2x}+1); saturates cleanly to +-1
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f / (e + 1.f);
+}
+// sum over the 4 lane groups (lanes l, l^16, l^32, l^48); identical bits on all four
+DEV float gsum(float x) {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------
+// chained-MFMA layer:  acc[nb] += W_frag(j, nb) * in[j]   for k-steps j in [J0, J0+J)
+// ---------------------------------------------------------------------------------------
+template <int J, int NB, int J0 = 0>
+DEV void mm(const float* __restrict__ w, int lane, const float (&in)[J], f4 (&acc)[NB]) {
+    // The weight image in LDS is loop-invariant; without this the compiler hoists every fragment
+    // load out of the view/tile loops (LICM) and spills hundreds of registers.
+    asm volatile("" ::: "memory");
+    if constexpr (NB == 4 || NB == 3) {
+        const f4* w4 = reinterpret_cast<const f4*>(w) + J0 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f4 a = w4[j * 64];
+            acc[0] = mfma16(a.x, in[j], acc[0]);
+            acc[1] = mfma16(a.y, in[j], acc[1]);
+            acc[2] = mfma16(a.z, in[j], acc[2]);
+            if constexpr (NB == 4) acc[3] = mfma16(a.w, in[j], acc[3]);
+        }
+    } else if constexpr (NB == 2) {
+        const f2* w2 = reinterpret_cast<const f2*>(w) + J0 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f2 a = w2[j * 64];
+            acc[0] = mfma16(a.x, in[j], acc[0]);
+            acc[1] = mfma16(a.y, in[j], acc[1]);
+        }
+    } else {
+        static_assert(NB == 1 && J0 % 4 == 0, "NB==1 parts must start on a 4-slot boundary");
+        const f4* w4 = reinterpret_cast<const f4*>(w) + (J0 / 4) * 64 + lane;
+        // two interleaved accumulators hide the 40-cycle dependent-MFMA latency
+        f4 alt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j4 = 0; j4 < cdiv(J, 4); ++j4) {
+            const f4 a = w4[j4 * 64];
+            if (4 * j4 + 0 < J) acc[0] = mfma16(a.x, in[4 * j4 + 0], acc[0]);
+            if (4 * j4 + 1 < J) alt = mfma16(a.y, in[4 * j4 + 1], alt);
+            if (4 * j4 + 2 < J) acc[0] = mfma16(a.z, in[4 * j4 + 2], acc[0]);
+            if (4 * j4 + 3 < J) alt = mfma16(a.w, in[4 * j4 + 3], alt);
+        }
+        acc[0] += alt;
+    }
+}
+
+template <int NB>
+DEV void load_bias(const float* __restrict__ b, int g, f4 (&acc)[NB]) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = reinterpret_cast<const f4*>(b)[nb * 4 + g];
+}
+
+template <int NB>
+DEV void elu_to(const f4 (&acc)[NB], float (&out)[NB * 4]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        out[nb * 4 + 0] = elu1(acc[nb].x);
+        out[nb * 4 + 1] = elu1(acc[nb].y);
+        out[nb * 4 + 2] = elu1(acc[nb].z);
+        out[nb * 4 + 3] = elu1(acc[nb].w);
+    }
+}
+
+// partial dot of a natural-layout 8-slot vector with a per-group table row T[g][8]
+DEV float dot8(const float* __restrict__ T, int g, const float (&h)[8]) {
+    const f4 a = reinterpret_cast<const f4*>(T)[g * 2], b = reinterpret_cast<const f4*>(T)[g * 2 + 1];
+    return a.x * h[0] + a.y * h[1] + a.z * h[2] + a.w * h[3] + b.x * h[4] + b.y * h[5] + b.z * h[6] + b.w * h[7];
+}
+DEV float dot4(const float* __restrict__ T, int g, const float (&h)[4]) {
+    const f4 a = reinterpret_cast<const f4*>(T)[g];
+    return a.x * h[0] + a.y * h[1] + a.z * h[2] + a.w * h[3];
+}
+
+// ---------------------------------------------------------------------------------------
+// setup kernels
+// ---------------------------------------------------------------------------------------
+// [BV][32][npix] x2 (NCHW) -> [BV][npix][64]; block = 256 threads handles 64 pixels
+__global__ __launch_bounds__(256) void k_repack_feats(const float* __restrict__ ray_feats,
+                                                      const float* __restrict__ img_feats,
+                                                      float* __restrict__ out, int npix) {
+    __shared__ float tile[64][65];
+    const int bv = blockIdx.y, p0 = blockIdx.x * 64, t = threadIdx.x;
+    const int tx = t & 63, ty = t >> 6;
+    const size_t in_base = (size_t)bv * 32 * npix;
+#pragma unroll
+    for (int c0 = 0; c0 < 64; c0 += 4) {
+        const int c = c0 + ty, p = p0 + tx;
+        float v = 0.f;
+        if (p < npix) v = (c < 32) ? ray_feats[in_base + (size_t)c * npix + p] : img_feats[in_base + (size_t)(c - 32) * npix + p];
+        tile[c][tx] = v;
+    }
+    __syncthreads();
+    float* o = out + ((size_t)bv * npix + p0) * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + t;           // float4 index within the 64x64 tile
+        const int p = idx >> 4, c4 = (idx & 15) * 4;
+        if (p0 + p < npix) {
+            f4 v = {tile[c4][p], tile[c4 + 1][p], tile[c4 + 2][p], tile[c4 + 3][p]};
+            reinterpret_cast<f4*>(o)[idx] = v;
+        }
+    }
+}
+
+// ref: render_ops.py:94 (K @ Rt), :112 (camera centre), dist_decoder.py:17-20
+__global__ void k_view_setup(const float* __restrict__ poses, const float* __restrict__ Ks,
+                             const float* __restrict__ dr, float* __restrict__ viewp, int nviews) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nviews) return;
+    const float* P = poses + i * 12;
+    const float* K = Ks + i * 9;
+    float* o = viewp + i * VIEWP_FLOATS;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c)
+            o[r * 4 + c] = __fmaf_rn(K[r * 3 + 2], P[8 + c], __fmaf_rn(K[r * 3 + 1], P[4 + c], __fmul_rn(K[r * 3], P[c])));
+    for (int c = 0; c < 3; ++c)
+        o[12 + c] = -__fmaf_rn(P[8 + c], P[11], __fmaf_rn(P[4 + c], P[7], __fmul_rn(P[c], P[3])));
+    const float nr = -1.f / dr[i * 2], fr = -1.f / dr[i * 2 + 1];
+    o[15] = nr;
+    o[16] = fr - nr;
+    for (int c = 17; c < VIEWP_FLOATS; ++c) o[c] = 0.f;
+}
+
+// ref: field_utils.py:17-27 (float64 arithmetic then cast), renderer.py:167-170,179
+__global__ void k_points_volume(const float* __restrict__ bbox_min, float* __restrict__ desc, int R, int B) {
+    const int P = R * R * R;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * P) return;
+    const int b = i / P, n = i % P;
+    const int col = n / R, s = n % R;
+    const int ix = col / R, iy = col % R, iz = R - 1 - s;
+    const double vs = 0.3 / (double)R, hv = vs / 2;
+    float* d = desc + (size_t)i * DESC_FLOATS;
+    d[0] = (float)(ix * vs + hv) + bbox_min[b * 3 + 0];
+    d[1] = (float)(iy * vs + hv) + bbox_min[b * 3 + 1];
+    d[2] = (float)(iz * vs + hv) + bbox_min[b * 3 + 2];
+    d[3] = 0.f; d[4] = 0.f; d[5] = 1.f;                 // que_dir = (0,0,1)
+    d[6] = 0.005f; d[7] = 0.005f;                       // fixed interval 0.01 (dist_decoder.py:47-49)
+}
+
+// ref: render_ops.py:146-170 (random_sample False)
+__global__ void k_coarse_depth(const float* __restrict__ que_dr, float* __restrict__ depth, int rn, int dn, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * rn * dn) return;
+    const int b = i / (rn * dn), k = i % dn;
+    const float near = que_dr[b * 2], far = que_dr[b * 2 + 1];
+    const float diff = __fsub_rn(__fdiv_rn(1.f, far), __fdiv_rn(1.f, near));
+    const float interval = __fdiv_rn(diff, (float)(dn - 1));
+    float tick = __fmul_rn(interval, (float)k);
+    if (k == 0) tick = 0.f;
+    if (k == dn - 1) tick = diff;
+    depth[i] = __fdiv_rn(1.f, __fadd_rn(__fdiv_rn(1.f, near), tick));
+}
+
+DEV void inv3x3(const float* K, float* o) {
+    const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const float A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
+    const float det = a * A + b * Bc + c * C;
+    const float id = 1.f / det;
+    o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+    o[3] = Bc * id; o[4] = (a * i - c * g) * id; o[5] = -(a * f - c * d) * id;
+    o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+}
+
+// ref: render_ops.py:4-39 (rays, unnormalised directions), :41-52 + dist_decoder.py:34-38 (intervals)
+__global__ void k_points_rays(const float* __restrict__ coords, const float* __restrict__ que_pose,
+                              const float* __restrict__ que_K, const float* __restrict__ que_dr,
+                              const float* __restrict__ depth, float* __restrict__ desc, int rn, int dn, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * rn * dn) return;
+    const int b = i / (rn * dn), ray = (i / dn) % rn, k = i % dn;
+    const float* P = que_pose + b * 12;
+    float Ki[9];
+    inv3x3(que_K + b * 9, Ki);
+    const float u = coords[((size_t)b * rn + ray) * 2], v = coords[((size_t)b * rn + ray) * 2 + 1];
+    float cam[3], tr[3], dir[3];
+    for (int r = 0; r < 3; ++r) cam[r] = Ki[r * 3] * u + Ki[r * 3 + 1] * v + Ki[r * 3 + 2];
+    for (int c = 0; c < 3; ++c) tr[c] = -(P[c] * P[3] + P[4 + c] * P[7] + P[8 + c] * P[11]);
+    for (int c = 0; c < 3; ++c) {
+        const float rc = P[c] * cam[0] + P[4 + c] * cam[1] + P[8 + c] * cam[2];
+        dir[c] = __fsub_rn(__fadd_rn(rc, tr[c]), tr[c]);          // render_ops.py:22-23
+    }
+    const float* z = depth + ((size_t)b * rn + ray) * dn;
+    const float zk = z[k];
+    const float nrm = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const float near = -1.f / que_dr[b * 2], far = -1.f / que_dr[b * 2 + 1];
+    auto inv = [&](int j) { return __fdiv_rn(__fsub_rn(__fdiv_rn(-1.f, z[j]), near), __fsub_rn(far, near)); };
+    auto half = [&](int j) { return (j == dn - 1) ? 0.5e6f : __fmul_rn(__fsub_rn(inv(j + 1), inv(j)), 0.5f); };
+    float* d = desc + (size_t)i * DESC_FLOATS;
+    for (int c = 0; c < 3; ++c) {
+        d[c] = tr[c] + dir[c] * zk;
+        d[3 + c] = -dir[c] / nrm;
+    }
+    d[6] = half(k == 0 ? 0 : k - 1);
+    d[7] = half(k);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_chain
+// ---------------------------------------------------------------------------------------
+struct ChainArgs {
+    const float* wpk;      // packed level blob (CHAIN section first)
+    const float* feat64;   // [B*V][fh][fw][64]
+    const float* imgs;     // [B*V][3][H][W]
+    const float* viewp;    // [B*V][VIEWP_FLOATS]
+    const float* desc;     // [B*P][DESC_FLOATS]
+    float* rec;            // [B*P][REC_*]
+    float* colors;         // [B*P][3]      (RENDER)
+    unsigned char* vmask;  // [B*P] or null
+    float* dbg;            // [B*P][32] or null
+    int B, P, H, W, fh, fw;
+};
+
+struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
+    float u, v, z, m;
+    float dd[4];
+};
+
+template <bool FULL>
+DEV void project_view(const float* __restrict__ vp, const float (&p)[3], const float (&qd)[3], int H, int W, ViewGeom& o) {
+    // ref: render_ops.py:98-104 (projection, depth guard), :126-128 (in-image test), :112-114 (direction)
+    const float pcx = __fmaf_rn(vp[2], p[2], __fmaf_rn(vp[1], p[1], __fmul_rn(vp[0], p[0]))) + vp[3];
+    const float pcy = __fmaf_rn(vp[6], p[2], __fmaf_rn(vp[5], p[1], __fmul_rn(vp[4], p[0]))) + vp[7];
+    float z = __fmaf_rn(vp[10], p[2], __fmaf_rn(vp[9], p[1], __fmul_rn(vp[8], p[0]))) + vp[11];
+    const bool inval = fabsf(z) < 1e-4f;
+    if (inval) z = 1e-3f;
+    o.z = z;
+    o.u = __fdiv_rn(pcx, z);
+    o.v = __fdiv_rn(pcy, z);
+    const bool outside = (o.u < -0.5f) | (o.u >= (float)W - 0.5f) | (o.v < -0.5f) | (o.v >= (float)H - 0.5f);
+    o.m = (!inval && !outside) ? 1.f : 0.f;
+    if constexpr (FULL) {
+        float d[3] = {p[0] - vp[12], p[1] - vp[13], p[2] - vp[14]};
+        const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-5f);
+        const float inr = -1.f / nrm;
+        d[0] *= inr; d[1] *= inr; d[2] *= inr;
+        o.dd[0] = d[0] - qd[0]; o.dd[1] = d[1] - qd[1]; o.dd[2] = d[2] - qd[2];     // aggregate_net.py:13
+        o.dd[3] = d[0] * qd[0] + d[1] * qd[1] + d[2] * qd[2];                       // :14
+    }
+}
+
+struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+// bilinear, border padding.  ref: ops.py:29-33 + grid_sample; see oracle bilinear_border
+DEV Taps make_taps(float u, float v, int H, int W, int fh, int fw, bool same_res) {
+    const float xn = u / (float)(W - 1) * 2.f - 1.f, yn = v / (float)(H - 1) * 2.f - 1.f;
+    float px, py;
+    if (same_res) { px = (xn + 1.f) * 0.5f * (float)(fw - 1); py = (yn + 1.f) * 0.5f * (float)(fh - 1); }
+    else { px = ((xn + 1.f) * (float)fw - 1.f) * 0.5f; py = ((yn + 1.f) * (float)fh - 1.f) * 0.5f; }
+    px = fminf(fmaxf(px, 0.f), (float)(fw - 1));
+    py = fminf(fmaxf(py, 0.f), (float)(fh - 1));
+    const float x0 = floorf(px), y0 = floorf(py);
+    const float wx1 = px - x0, wy1 = py - y0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const int x0i = (int)x0, y0i = (int)y0;
+    const int x1i = min(x0i + 1, fw - 1), y1i = min(y0i + 1, fh - 1);
+    Taps t;
+    t.o00 = y0i * fw + x0i; t.o01 = y0i * fw + x1i; t.o10 = y1i * fw + x0i; t.o11 = y1i * fw + x1i;
+    t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+    return t;
+}
+
+constexpr int SW = 20;     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c rgb
+
+template <int V, bool RENDER>
+__global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // ---- stage the CHAIN section of the packed weights into LDS (once per workgroup)
+    {
+        const f4* src = reinterpret_cast<const f4*>(a.wpk);
+        f4* dst = reinterpret_cast<f4*>(lds);
+        for (int i = threadIdx.x; i < pk::CHAIN_END / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    const int tps = (a.P + 15) >> 4;                       // tiles per scene
+    const int ntiles = a.B * tps;
+    constexpr int REC = RENDER ? REC_RAY : REC_VOL;
+
+    for (int tile = blockIdx.x * waves_per_block + wave; tile < ntiles; tile += gridDim.x * waves_per_block) {
+        const int b = tile / tps;
+        const int n_raw = (tile - b * tps) * 16 + r;
+        const bool row_ok = n_raw < a.P;
+        const int n = row_ok ? n_raw : a.P - 1;
+        const size_t pt = (size_t)b * a.P + n;
+        float p[3], qd[3], lo, hi;
+        {
+            const f4 d0 = reinterpret_cast<const f4*>(a.desc)[pt * 2], d1 = reinterpret_cast<const f4*>(a.desc)[pt * 2 + 1];
+            p[0] = d0.x; p[1] = d0.y; p[2] = d0.z; qd[0] = d0.w; qd[1] = d1.x; qd[2] = d1.y; lo = d1.z; hi = d1.w;
+        }
+        float S[V][SW];
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+#pragma unroll
+            for (int q = 0; q < SW; ++q) S[k][q] = 0.f;
+        float msum = 0.f;
+        unsigned vbits = 0;
+
+        // ================= phase 1: per view, everything up to the first cross-view reduction
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+#pragma unroll
+            for (int k = 0; k < V - 1; ++k)
+#pragma unroll
+                for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
+            const int bv = b * V + v;
+            const float* vp = a.viewp + bv * VIEWP_FLOATS;
+            ViewGeom vg;
+            project_view<true>(vp, p, qd, a.H, a.W, vg);
+            const float m = vg.m;
+            msum += m;
+            vbits |= (m != 0.f ? 1u : 0u) << v;
+
+            // ---- gather: ray channels 8g..8g+7, image-feature channels 8g..8g+7, rgb channel g
+            float FR[8], XI[9];
+            {
+                const Taps t = make_taps(vg.u, vg.v, a.H, a.W, a.fh, a.fw, false);
+                const float* fb = a.feat64 + (size_t)bv * a.fh * a.fw * 64 + 8 * g;
+                const f4* q00 = reinterpret_cast<const f4*>(fb + (size_t)t.o00 * 64);
+                const f4* q01 = reinterpret_cast<const f4*>(fb + (size_t)t.o01 * 64);
+                const f4* q10 = reinterpret_cast<const f4*>(fb + (size_t)t.o10 * 64);
+                const f4* q11 = reinterpret_cast<const f4*>(fb + (size_t)t.o11 * 64);
+                const float w00 = t.w00 * m, w01 = t.w01 * m, w10 = t.w10 * m, w11 = t.w11 * m;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f4 a0 = q00[h], a1 = q01[h], a2 = q10[h], a3 = q11[h];
+                    const f4 c0 = q00[8 + h], c1 = q01[8 + h], c2 = q10[8 + h], c3 = q11[8 + h];
+                    const f4 fr = a0 * w00 + a1 * w01 + a2 * w10 + a3 * w11;
+                    const f4 fi = c0 * w00 + c1 * w01 + c2 * w10 + c3 * w11;
+                    FR[4 * h] = fr.x; FR[4 * h + 1] = fr.y; FR[4 * h + 2] = fr.z; FR[4 * h + 3] = fr.w;
+                    XI[4 * h] = fi.x; XI[4 * h + 1] = fi.y; XI[4 * h + 2] = fi.z; XI[4 * h + 3] = fi.w;
+                }
+                const Taps ti = make_taps(vg.u, vg.v, a.H, a.W, a.H, a.W, true);
+                const float* ib = a.imgs + ((size_t)bv * 3 + min(g, 2)) * a.H * a.W;
+                const float rgb = (ib[ti.o00] * ti.w00 + ib[ti.o01] * ti.w01 + ib[ti.o10] * ti.w10 + ib[ti.o11] * ti.w11) * m;
+                XI[8] = g < 3 ? rgb : 0.f;
+            }
+            S[V - 1][19] = XI[8];                              // raw rgb for the colour blend
+
+            // ---- mixture-of-logistics decoder (dist_decoder.py:99-142)
+            float o5[5];
+#pragma unroll
+            for (int br = 0; br < 3; ++br) {
+                f4 acc[2];
+                float h1[8], h2[8];
+                load_bias<2>(lds + pk::B_DEC1 + br * 32, g, acc);
+                mm<8, 2>(lds + pk::DEC1 + br * frag_floats(8, 2), lane, FR, acc);
+                elu_to<2>(acc, h1);
+                load_bias<2>(lds + pk::B_DEC2 + br * 32, g, acc);
+                mm<8, 2>(lds + pk::DEC2 + br * frag_floats(8, 2), lane, h1, acc);
+                elu_to<2>(acc, h2);
+                if (br < 2) {
+                    o5[2 * br] = gsum(dot8(lds + pk::T_DEC3 + (2 * br) * 32, g, h2)) + lds[pk::T_DEC3_B + 2 * br];
+                    o5[2 * br + 1] = gsum(dot8(lds + pk::T_DEC3 + (2 * br + 1) * 32, g, h2)) + lds[pk::T_DEC3_B + 2 * br + 1];
+                } else {
+                    o5[4] = gsum(dot8(lds + pk::T_DEC3 + 4 * 32, g, h2)) + lds[pk::T_DEC3_B + 4];
+                }
+            }
+            float hit, vis;
+            {
+                const float mean0 = softplus1(o5[0]), mean1 = softplus1(o5[1]);
+                const float var0 = softplus1(o5[2]) + 0.05f, var1 = softplus1(o5[3]) + 0.05f;
+                const float aw = sigmoid1(o5[4]);
+                const float dinv = -1.f / fmaxf(vg.z, 1e-5f);                 // dist_decoder.py:21-23
+                const float dhat = (dinv - vp[15]) / vp[16];
+                const float nearv = dhat - lo, farv = dhat + hi;
+                const float c00 = 0.5f + 0.5f * tanh1((nearv - mean0) * var0), c01 = 0.5f + 0.5f * tanh1((nearv - mean1) * var1);
+                const float c10 = 0.5f + 0.5f * tanh1((farv - mean0) * var0), c11 = 0.5f + 0.5f * tanh1((farv - mean1) * var1);
+                vis = ((1.f - c00) * aw + (1.f - c01) * (1.f - aw)) * m;
+                hit = ((c10 - c00) * aw + (c11 - c01) * (1.f - aw)) * m;
+            }
+            // ---- prob embedding 34 -> 32 -> 32 (aggregate_net.py:46-54)
+            {
+                f4 acc[2];
+                float e1[8];
+                load_bias<2>(lds + pk::B_PE1, g, acc);
+                mm<8, 2>(lds + pk::PE1, lane, FR, acc);
+                const float extra[1] = {g == 0 ? (hit - 0.5f) * 2.f : (g == 1 ? (vis - 0.5f) * 2.f : 0.f)};
+                mm<1, 2, 8>(lds + pk::PE1, lane, extra, acc);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    e1[nb * 4 + 0] = fmaxf(acc[nb].x, 0.f); e1[nb * 4 + 1] = fmaxf(acc[nb].y, 0.f);
+                    e1[nb * 4 + 2] = fmaxf(acc[nb].z, 0.f); e1[nb * 4 + 3] = fmaxf(acc[nb].w, 0.f);
+                }
+                load_bias<2>(lds + pk::B_PE2, g, acc);
+                mm<8, 2>(lds + pk::PE2, lane, e1, acc);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    S[V - 1][9 + nb * 4 + 0] = acc[nb].x; S[V - 1][9 + nb * 4 + 1] = acc[nb].y;
+                    S[V - 1][9 + nb * 4 + 2] = acc[nb].z; S[V - 1][9 + nb * 4 + 3] = acc[nb].w;
+                }
+            }
+            // ---- x = [rgb, img_feats] + ray_dir_fc(dir_diff)  (ibrnet.py:457-459)
+            {
+                f4 acc1[1], acc3[3];
+                float d1[4], df[12];
+                load_bias<1>(lds + pk::B_RDF1, g, acc1);
+                const float ddg[1] = {g == 0 ? vg.dd[0] : (g == 1 ? vg.dd[1] : (g == 2 ? vg.dd[2] : vg.dd[3]))};
+                mm<1, 1>(lds + pk::RDF1, lane, ddg, acc1);
+                elu_to<1>(acc1, d1);
+                load_bias<3>(lds + pk::B_RDF2, g, acc3);
+                mm<4, 3>(lds + pk::RDF2, lane, d1, acc3);
+                elu_to<3>(acc3, df);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) S[V - 1][j] = XI[j] + df[j];
+            }
+            // ---- gate of the first weighted mean/var: sigmoid(neuray_fc(e))  (ibrnet.py:469)
+            {
+                f4 acc1[1];
+                float e[8], n1[4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = S[V - 1][9 + j];
+                load_bias<1>(lds + pk::B_NR1, g, acc1);
+                mm<8, 1>(lds + pk::NR1, lane, e, acc1);
+                elu_to<1>(acc1, n1);
+                S[V - 1][17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
+            }
+            S[V - 1][18] = m;
+            if (a.dbg && g == 0 && row_ok) { a.dbg[pt * 32 + v] = hit; a.dbg[pt * 32 + 8 + v] = vis; }
+        }
+
+        // ================= cross-view reduction 1 (ibrnet.py:466-472), in-lane
+        float SV[36];
+        const float inv_msum = 1.f / (msum + 1e-8f);
+        {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                float mu0 = 0.f, mu1 = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float w = S[v][18] * inv_msum;
+                    mu0 += S[v][j] * (S[v][17] * w);
+                    mu1 += S[v][j] * w;
+                }
+                float va0 = 0.f, va1 = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float w = S[v][18] * inv_msum;
+                    const float d0 = S[v][j] - mu0, d1 = S[v][j] - mu1;
+                    va0 += (S[v][17] * w) * d0 * d0;
+                    va1 += w * d1 * d1;
+                }
+                SV[j] = mu0; SV[9 + j] = va0; SV[18 + j] = mu1; SV[27 + j] = va1;
+            }
+        }
+        // view-invariant 140 columns of base_fc.0, once per point (+ bias)
+        f4 G[4];
+        load_bias<4>(lds + pk::B_HOIST, g, G);
+        mm<36, 4>(lds + pk::HOIST, lane, SV, G);
+
+        // ================= phase 2: per view, base_fc / vis_fc / vis_fc2 (/ rgb_fc)
+        float vsum = 0.f;
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            float X[9], E[8];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) X[j] = S[0][j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) E[j] = S[0][9 + j];
+            const float m = S[0][18], rgbraw = S[0][19];
+#pragma unroll
+            for (int k = 0; k < V - 1; ++k)
+#pragma unroll
+                for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
+            const float w = m * inv_msum;
+            float Hh[8];
+            {
+                f4 acc4[4] = {G[0], G[1], G[2], G[3]};
+                float b1[16];
+                mm<9, 4>(lds + pk::BASE1, lane, X, acc4);
+                mm<8, 4, 9>(lds + pk::BASE1, lane, E, acc4);
+                elu_to<4>(acc4, b1);
+                f4 acc[2];
+                load_bias<2>(lds + pk::B_BASE2, g, acc);
+                mm<16, 2>(lds + pk::BASE2, lane, b1, acc);
+                elu_to<2>(acc, Hh);
+            }
+            float vis1;
+            {
+                f4 acc[2];
+                float xin[8], v1[8], res[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * w;
+                load_bias<2>(lds + pk::B_VIS1, g, acc);
+                mm<8, 2>(lds + pk::VIS1, lane, xin, acc);
+                elu_to<2>(acc, v1);
+                load_bias<2>(lds + pk::B_VIS2, g, acc);
+                mm<8, 2>(lds + pk::VIS2, lane, v1, acc);
+                elu_to<2>(acc, res);
+                const float logit = elu1(gsum(dot8(lds + pk::T_VIS2R, g, v1)) + lds[pk::T_SCAL + 1]);
+                vis1 = sigmoid1(logit) * m;                                    // ibrnet.py:479
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Hh[j] += res[j];                    // :480
+            }
+            float v2;
+            {
+                f4 acc[2];
+                float xin[8], t1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * vis1;
+                load_bias<2>(lds + pk::B_VISB1, g, acc);
+                mm<8, 2>(lds + pk::VISB1, lane, xin, acc);
+                elu_to<2>(acc, t1);
+                v2 = sigmoid1(gsum(dot8(lds + pk::T_VISB2, g, t1)) + lds[pk::T_SCAL + 2]) * m;   // :481
+            }
+            vsum += v2;
+            float clog = 0.f;
+            if constexpr (RENDER) {                                             // ibrnet.py:507-509
+                const float* vp = a.viewp + (b * V + v) * VIEWP_FLOATS;
+                ViewGeom vg;
+                project_view<true>(vp, p, qd, a.H, a.W, vg);
+                f4 acc1[1];
+                float c1[4], c2[4];
+                load_bias<1>(lds + pk::B_RGB1, g, acc1);
+                mm<8, 1>(lds + pk::RGB1, lane, Hh, acc1);
+                const float ex[2] = {g == 0 ? v2 : (g == 1 ? vg.dd[0] : (g == 2 ? vg.dd[1] : vg.dd[2])), g == 0 ? vg.dd[3] : 0.f};
+                mm<2, 1, 8>(lds + pk::RGB1, lane, ex, acc1);
+                elu_to<1>(acc1, c1);
+                load_bias<1>(lds + pk::B_RGB2, g, acc1);
+                mm<4, 1>(lds + pk::RGB2, lane, c1, acc1);
+                elu_to<1>(acc1, c2);
+                clog = gsum(dot4(lds + pk::T_RGB3, g, c2)) + lds[pk::T_SCAL + 3];
+                if (m == 0.f) clog = -1e9f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) S[V - 1][j] = Hh[j];
+            S[V - 1][8] = v2;
+            S[V - 1][9] = clog;
+            S[V - 1][10] = rgbraw;
+            if (a.dbg && g == 0 && row_ok) a.dbg[pt * 32 + 16 + v] = v2;
+        }
+
+        // ================= cross-view reduction 2 (ibrnet.py:482-484,488) + colour blend (:510-511)
+        float Z[23];
+        float wbar = 0.f;
+        {
+            const float inv_vsum = 1.f / (vsum + 1e-8f);
+#pragma unroll
+            for (int v = 0; v < V; ++v) wbar += S[v][8] * inv_vsum;
+            wbar *= (1.f / (float)V);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float mu = 0.f, va = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) mu += S[v][j] * (S[v][8] * inv_vsum);
+#pragma unroll
+                for (int v = 0; v < V; ++v) { const float d = S[v][j] - mu; va += (S[v][8] * inv_vsum) * d * d; }
+                Z[j] = mu; Z[8 + j] = va;
+            }
+        }
+        if constexpr (RENDER) {
+            float cmax = -3.0e38f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) cmax = fmaxf(cmax, S[v][9]);
+            float den = 0.f, num = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) { const float e = __expf(S[v][9] - cmax); den += e; num += S[v][10] * e; }
+            if (g < 3 && row_ok) a.colors[pt * 3 + g] = num / den;
+        }
+        // ================= geometry_fc on [mean, var, wbar, embed(p)]  (ibrnet.py:487-489)
+        {
+            const float pc = g == 1 ? p[0] : (g == 2 ? p[1] : p[2]);
+            float s1, c1, s2, c2, s4, c4;
+            sincosf(pc, &s1, &c1);
+            sincosf(2.f * pc, &s2, &c2);
+            sincosf(4.f * pc, &s4, &c4);
+            const bool g0 = g == 0;
+            Z[16] = g0 ? wbar : pc; Z[17] = g0 ? 0.f : s1; Z[18] = g0 ? 0.f : c1; Z[19] = g0 ? 0.f : s2;
+            Z[20] = g0 ? 0.f : c2; Z[21] = g0 ? 0.f : s4; Z[22] = g0 ? 0.f : c4;
+        }
+        f4 U[4];
+        float u64[16];
+        load_bias<4>(lds + pk::B_GEO1, g, U);
+        mm<23, 4>(lds + pk::GEO1, lane, Z, U);
+        elu_to<4>(U, u64);
+        f4 g16[1];
+        load_bias<1>(lds + pk::B_GEO2, g, g16);
+        mm<16, 1>(lds + pk::GEO2, lane, u64, g16);
+        float gg[4];
+        elu_to<1>(g16, gg);
+
+        // ================= record
+        if (row_ok) {
+            float* rec = a.rec + pt * REC;
+            const f4 gv = {gg[0], gg[1], gg[2], gg[3]};
+            reinterpret_cast<f4*>(rec)[g] = gv;
+            if constexpr (RENDER) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const f4 uv = {u64[nb * 4], u64[nb * 4 + 1], u64[nb * 4 + 2], u64[nb * 4 + 3]};
+                    reinterpret_cast<f4*>(rec + 16 + 16 * nb)[g] = uv;
+                }
+                if (g == 0) rec[80] = msum;
+            } else {
+                if (g == 0) rec[16] = msum;
+            }
+            if (a.vmask && g == 0) a.vmask[pt] = (unsigned char)vbits;
+            if (a.dbg && g == 0) {
+                float* d = a.dbg + pt * 32;
+                d[24] = msum; d[25] = wbar; d[26] = Z[0]; d[27] = Z[8]; d[28] = SV[8]; d[29] = G[0].x; d[30] = gg[0]; d[31] = vsum;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_ray: one wavefront per ray / voxel column, lane = sample
+// ---------------------------------------------------------------------------------------
+struct RayArgs {
+    const float* wpk;        // packed level blob (RAY section used)
+    const float* rec;        // [nrays*dn][REC]
+    const float* desc;       // [nrays*dn][8]
+    const float* depth;      // [nrays*dn]                     (RENDER)
+    const float* colors;     // [nrays*dn][3]                  (RENDER)
+    const float* que_dr;     // [B][2]                         (RENDER)
+    const unsigned char* vmask_pts;  // [nrays*dn] point order, or null
+    int nrays, dn, rays_per_scene;
+    // volume outputs
+    float* volume;           // [B][R*R][R] with z flipped back
+    unsigned char* vmask_out;
+    // render outputs (nullable)
+    float *sdf, *alpha, *hit, *pix, *rdepth, *gerr_part, *grad;
+    unsigned char* rmask;
+    int view_num, point_num;
+    // inverse-CDF resampling (coarse pass only; nullable)
+    float* fine_depth; int* fine_inds; int fdn;
+};
+
+// wave-level ordering of LDS traffic between lanes of the same wavefront
+DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DEV float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+template <bool RENDER>
+__global__ __launch_bounds__(256) void k_ray(RayArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= a.nrays) return;
+    const int dn = a.dn;
+    constexpr int PER = RENDER ? 76 : 32;            // floats of scratch per sample
+    float* sc = sm + (size_t)wave * dn * PER;
+    float* Kb = sc;                                   // [dn][16]
+    float* Vb = sc + dn * 16;                         // [dn][16]
+    float* Qb = sc + dn * 32;                         // [dn][16]   (RENDER)
+    float* Ob = sc + dn * 48;                         // [dn][16]   dO  (RENDER)
+    float* St = sc + dn * 64;                         // [dn][12]   max[4], 1/sum[4], rs[4] (RENDER)
+    const bool act = lane < dn;
+    const int i = act ? lane : dn - 1;
+    const size_t pt = (size_t)ray * dn + i;
+    constexpr int REC = RENDER ? REC_RAY : REC_VOL;
+    const float* rec = a.rec + pt * REC;
+    const float* W = a.wpk;
+
+    float g16[16], t[16];
+    {
+        const f4* r4 = reinterpret_cast<const f4*>(rec);
+        const f4* pe = reinterpret_cast<const f4*>(W + pk::R_PE + i * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 x = r4[q], e = pe[q];
+            g16[4 * q] = x.x; g16[4 * q + 1] = x.y; g16[4 * q + 2] = x.z; g16[4 * q + 3] = x.w;
+            t[4 * q] = x.x + e.x; t[4 * q + 1] = x.y + e.y; t[4 * q + 2] = x.z + e.z; t[4 * q + 3] = x.w + e.w;
+        }
+    }
+    const float nvalid = rec[RENDER ? 80 : 16];
+    const bool rowok = nvalid > 1.f;                  // ibrnet.py:493 query-row mask
+
+    // ---- q, k, v projections (no bias)      ibrnet.py:81-86
+    float q[16], kk[16], vv[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        float sq = 0.f, sk = 0.f, sv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            sq = fmaf(W[pk::R_WQ + f * 16 + c], t[c], sq);
+            sk = fmaf(W[pk::R_WK + f * 16 + c], t[c], sk);
+            sv = fmaf(W[pk::R_WV + f * 16 + c], t[c], sv);
+        }
+        q[f] = sq; kk[f] = sk; vv[f] = sv;
+    }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f4 k4 = {kk[4 * c], kk[4 * c + 1], kk[4 * c + 2], kk[4 * c + 3]};
+            const f4 v4 = {vv[4 * c], vv[4 * c + 1], vv[4 * c + 2], vv[4 * c + 3]};
+            reinterpret_cast<f4*>(Kb + i * 16)[c] = k4;
+            reinterpret_cast<f4*>(Vb + i * 16)[c] = v4;
+            if constexpr (RENDER) {
+                const f4 q4 = {q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]};
+                reinterpret_cast<f4*>(Qb + i * 16)[c] = q4;
+            }
+        }
+    }
+    wave_sync();
+
+    // ---- attention, lane = query row (ibrnet.py:15-27): softmax over dn keys per head
+    float o[16], amax[4], ainv[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float mx = -3.0e38f;
+        for (int j = 0; j < dn; ++j) {
+            const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
+            float s = 0.5f * (q[4 * h] * kj.x + q[4 * h + 1] * kj.y + q[4 * h + 2] * kj.z + q[4 * h + 3] * kj.w);
+            s = rowok ? s : -1e9f;
+            mx = fmaxf(mx, s);
+        }
+        float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        for (int j = 0; j < dn; ++j) {
+            const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
+            const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
+            float s = 0.5f * (q[4 * h] * kj.x + q[4 * h + 1] * kj.y + q[4 * h + 2] * kj.z + q[4 * h + 3] * kj.w);
+            s = rowok ? s : -1e9f;
+            const float pj = __expf(s - mx);
+            l += pj;
+            o0 = fmaf(pj, vj.x, o0); o1 = fmaf(pj, vj.y, o1); o2 = fmaf(pj, vj.z, o2); o3 = fmaf(pj, vj.w, o3);
+        }
+        const float il = 1.f / l;
+        o[4 * h] = o0 * il; o[4 * h + 1] = o1 * il; o[4 * h + 2] = o2 * il; o[4 * h + 3] = o3 * il;
+        amax[h] = mx; ainv[h] = il;
+    }
+    // ---- fc + residual, LayerNorm(eps 1e-6), out_geometry_fc (two linears), clip   ibrnet.py:97-100,494-495
+    float y[16], xh[16], nrm[16];
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float s = t[c];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) s = fmaf(W[pk::R_WFC + c * 16 + f], o[f], s);
+        y[c] = s; mean += s;
+    }
+    mean *= (1.f / 16.f);
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { const float d = y[c] - mean; var += d * d; }
+    var *= (1.f / 16.f);
+    const float rstd = 1.f / sqrtf(var + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { xh[c] = (y[c] - mean) * rstd; nrm[c] = xh[c] * W[pk::R_LNW + c] + W[pk::R_LNB + c]; }
+    float sraw = W[pk::R_OUT1B];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        float rr = W[pk::R_OUT0B + f];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) rr = fmaf(W[pk::R_OUT0W + f * 16 + c], nrm[c], rr);
+        sraw = fmaf(W[pk::R_OUT1W + f], rr, sraw);
+    }
+    float sdf = fminf(fmaxf(sraw, -1.f), 1.f);
+    if (nvalid < 1.f) sdf = 1.f;
+
+    if constexpr (!RENDER) {
+        // renderer.py:197-198: column (x,y), sample i is voxel z = R-1-i
+        if (act) {
+            const size_t o_idx = (size_t)ray * dn + (dn - 1 - i);
+            a.volume[o_idx] = sdf;
+            if (a.vmask_out && a.vmask_pts) a.vmask_out[o_idx] = a.vmask_pts[pt];
+        }
+        return;
+    } else {
+        // ================= in-forward VJP of sum(sdf) w.r.t. the sample points (ibrnet.py:497-504)
+        const float ds = (sraw >= -1.f && sraw <= 1.f && nvalid >= 1.f && act) ? 1.f : 0.f;
+        float dnrm[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) s = fmaf(W[pk::R_OUT0W + f * 16 + c], W[pk::R_OUT1W + f], s);
+            dnrm[c] = s * ds;
+        }
+        float dy[16];
+        {
+            float m1 = 0.f, m2 = 0.f, dxh[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { dxh[c] = dnrm[c] * W[pk::R_LNW + c]; m1 += dxh[c]; m2 += dxh[c] * xh[c]; }
+            m1 *= (1.f / 16.f); m2 *= (1.f / 16.f);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dy[c] = rstd * (dxh[c] - m1 - xh[c] * m2);
+        }
+        float dO[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) s = fmaf(dy[c], W[pk::R_WFC + c * 16 + f], s);
+            dO[f] = s;
+        }
+        // row pass: rs_h = sum_j P dA ;  dQ = (sum_j P dA k_j - rs sum_j P k_j) / 2
+        float dQ[16], rsv[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float rs = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            for (int j = 0; j < dn; ++j) {
+                const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
+                const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
+                float s = 0.5f * (q[4 * h] * kj.x + q[4 * h + 1] * kj.y + q[4 * h + 2] * kj.z + q[4 * h + 3] * kj.w);
+                s = rowok ? s : -1e9f;
+                const float pj = __expf(s - amax[h]) * ainv[h];
+                const float dA = dO[4 * h] * vj.x + dO[4 * h + 1] * vj.y + dO[4 * h + 2] * vj.z + dO[4 * h + 3] * vj.w;
+                const float pd = pj * dA;
+                rs += pd;
+                a0 = fmaf(pd, kj.x, a0); a1 = fmaf(pd, kj.y, a1); a2 = fmaf(pd, kj.z, a2); a3 = fmaf(pd, kj.w, a3);
+                b0 = fmaf(pj, kj.x, b0); b1 = fmaf(pj, kj.y, b1); b2 = fmaf(pj, kj.z, b2); b3 = fmaf(pj, kj.w, b3);
+            }
+            const float sc2 = rowok ? 0.5f : 0.f;       // masked query rows: d logits = 0
+            dQ[4 * h] = (a0 - rs * b0) * sc2; dQ[4 * h + 1] = (a1 - rs * b1) * sc2;
+            dQ[4 * h + 2] = (a2 - rs * b2) * sc2; dQ[4 * h + 3] = (a3 - rs * b3) * sc2;
+            rsv[h] = rs;
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f4 d4 = {dO[4 * c], dO[4 * c + 1], dO[4 * c + 2], dO[4 * c + 3]};
+                reinterpret_cast<f4*>(Ob + i * 16)[c] = d4;
+            }
+            const f4 m4 = {amax[0], amax[1], amax[2], amax[3]}, i4 = {ainv[0], ainv[1], ainv[2], ainv[3]};
+            const f4 r4 = {rsv[0], rsv[1], rsv[2], rsv[3]};
+            reinterpret_cast<f4*>(St + i * 12)[0] = m4;
+            reinterpret_cast<f4*>(St + i * 12)[1] = i4;
+            // rs < 0 sentinel is not possible to encode; keep a separate row-ok flag in the sign of 1/sum
+            reinterpret_cast<f4*>(St + i * 12)[2] = r4;
+        }
+        // row-ok flags of all rows as a wave mask
+        const unsigned long long okmask = __ballot(rowok && act);
+        wave_sync();
+        // column pass (lane = key j = i): dK_j = sum_i dL_ij q_i / 2 ; dV_j = sum_i P_ij dO_i
+        float dK[16], dV[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { dK[f] = 0.f; dV[f] = 0.f; }
+        for (int qi = 0; qi < dn; ++qi) {
+            const bool ok = (okmask >> qi) & 1ull;
+            const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
+            const f4 il4 = reinterpret_cast<const f4*>(St + qi * 12)[1];
+            const f4 rs4 = reinterpret_cast<const f4*>(St + qi * 12)[2];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f4 qv = reinterpret_cast<const f4*>(Qb + qi * 16)[h];
+                const f4 dov = reinterpret_cast<const f4*>(Ob + qi * 16)[h];
+                float s = 0.5f * (qv.x * kk[4 * h] + qv.y * kk[4 * h + 1] + qv.z * kk[4 * h + 2] + qv.w * kk[4 * h + 3]);
+                s = ok ? s : -1e9f;
+                const float pj = __expf(s - mx4[h]) * il4[h];
+                const float dA = dov.x * vv[4 * h] + dov.y * vv[4 * h + 1] + dov.z * vv[4 * h + 2] + dov.w * vv[4 * h + 3];
+                const float dL = ok ? pj * (dA - rs4[h]) * 0.5f : 0.f;
+                dK[4 * h] = fmaf(dL, qv.x, dK[4 * h]); dK[4 * h + 1] = fmaf(dL, qv.y, dK[4 * h + 1]);
+                dK[4 * h + 2] = fmaf(dL, qv.z, dK[4 * h + 2]); dK[4 * h + 3] = fmaf(dL, qv.w, dK[4 * h + 3]);
+                dV[4 * h] = fmaf(pj, dov.x, dV[4 * h]); dV[4 * h + 1] = fmaf(pj, dov.y, dV[4 * h + 1]);
+                dV[4 * h + 2] = fmaf(pj, dov.z, dV[4 * h + 2]); dV[4 * h + 3] = fmaf(pj, dov.w, dV[4 * h + 3]);
+            }
+        }
+        // dT = dy (residual) + Wq^T dQ + Wk^T dK + Wv^T dV ; dc = dT * ELU'(c) with ELU' = g>0 ? 1 : g+1
+        float dc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float s = dy[c];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                s = fmaf(W[pk::R_WQ + f * 16 + c], dQ[f], s);
+                s = fmaf(W[pk::R_WK + f * 16 + c], dK[f], s);
+                s = fmaf(W[pk::R_WV + f * 16 + c], dV[f], s);
+            }
+            dc[c] = s * (g16[c] > 0.f ? 1.f : g16[c] + 1.f);
+        }
+        // geometry_fc backward, streamed over the 64 hidden units; only the 21 embed columns matter
+        float de[21];
+#pragma unroll
+        for (int e = 0; e < 21; ++e) de[e] = 0.f;
+#pragma unroll 4
+        for (int h = 0; h < 64; ++h) {
+            float du = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) du = fmaf(W[pk::R_GEO2W + c * 64 + h], dc[c], du);
+            const float uh = rec[16 + h];
+            const float da = du * (uh > 0.f ? 1.f : uh + 1.f);
+#pragma unroll
+            for (int e = 0; e < 21; ++e) de[e] = fmaf(W[pk::R_GEO1E + h * 24 + e], da, de[e]);
+        }
+        const float* dsc = a.desc + pt * DESC_FLOATS;
+        float grad[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float pc = dsc[c];
+            float s1, c1, s2, c2, s4, c4;
+            sincosf(pc, &s1, &c1); sincosf(2.f * pc, &s2, &c2); sincosf(4.f * pc, &s4, &c4);
+            grad[c] = de[c] + c1 * de[3 + c] - s1 * de[6 + c] + 2.f * c2 * de[9 + c] - 2.f * s2 * de[12 + c]
+                      + 4.f * c4 * de[15 + c] - 4.f * s4 * de[18 + c];
+        }
+        // ================= NeuS alpha (aggregate_net.py:105-121), compositing (render_ops.py:72-80)
+        const float z = a.depth[pt];
+        const float znext = (lane + 1 < dn) ? a.depth[pt + 1] : 0.f;
+        const float dist = (lane + 1 < dn) ? znext - z : 1e6f;
+        const float inv_s = fminf(fmaxf(__expf(W[pk::R_VARIANCE] * 10.f), 1e-6f), 1e6f);
+        const float tcos = -(dsc[3] * grad[0] + dsc[4] * grad[1] + dsc[5] * grad[2]);
+        const float icos = fminf(tcos, 0.f);                        // -relu(-cos)
+        const float nxt = sdf + icos * dist * 0.5f, prv = sdf - icos * dist * 0.5f;
+        const float pcdf = sigmoid1(prv * inv_s), ncdf = sigmoid1(nxt * inv_s);
+        const float alpha = fminf(fmaxf((pcdf - ncdf + 1e-5f) / (pcdf + 1e-5f), 0.f), 1.f);
+        float* Al = Kb;                                              // reuse scratch (all reads of Kb done)
+        wave_sync();
+        if (act) Al[i] = 1.f - alpha + 1e-10f;
+        wave_sync();
+        float T = 1.f;
+        for (int j = 0; j < i; ++j) T *= Al[j];
+        const float hitp = act ? alpha * T : 0.f;
+        const float gn = sqrtf(grad[0] * grad[0] + grad[1] * grad[1] + grad[2] * grad[2]) - 1.f;
+        const float gerr = wave_sum(act ? gn * gn : 0.f);
+        const float cr = a.colors[pt * 3], cg = a.colors[pt * 3 + 1], cb = a.colors[pt * 3 + 2];
+        const float pr = wave_sum(hitp * cr), pg = wave_sum(hitp * cg), pb = wave_sum(hitp * cb);
+        const float rd = wave_sum(hitp * z);
+        const unsigned long long cnt = __ballot(act && nvalid > (float)a.view_num);
+        if (act) {
+            if (a.sdf) a.sdf[pt] = sdf;
+            if (a.alpha) a.alpha[pt] = alpha;
+            if (a.hit) a.hit[pt] = hitp;
+            if (a.grad) { a.grad[pt * 3] = grad[0]; a.grad[pt * 3 + 1] = grad[1]; a.grad[pt * 3 + 2] = grad[2]; }
+        }
+        if (lane == 0) {
+            if (a.pix) { a.pix[(size_t)ray * 3] = pr; a.pix[(size_t)ray * 3 + 1] = pg; a.pix[(size_t)ray * 3 + 2] = pb; }
+            if (a.rdepth) a.rdepth[ray] = rd;
+            if (a.rmask) a.rmask[ray] = (__popcll(cnt) > a.point_num) ? 1 : 0;     // renderer.py:130-132
+            if (a.gerr_part) a.gerr_part[ray] = gerr;
+        }
+        // ================= inverse-CDF resampling for the fine pass (render_ops.py:172-229), eval mode
+        if (a.fine_depth) {
+            const int fdn = a.fdn;
+            const int b = ray / a.rays_per_scene;
+            const float near = __fdiv_rn(-1.f, a.que_dr[b * 2]), far = __fdiv_rn(-1.f, a.que_dr[b * 2 + 1]);
+            const float span = __fsub_rn(far, near);
+            float* Dn = Vb;                 // [dn]   normalised inverse depth
+            float* Pd = Vb + 64;            // [dn]   pdf
+            float* Cd = Vb + 128;           // [dn+1] cdf
+            float* Ce = Vb + 200;           // [dn+1] bin centres
+            float* Fd = Vb + 272;           // [fdn]  unsorted fine depth
+            wave_sync();
+            const float dnv = __fdiv_rn(__fsub_rn(__fdiv_rn(-1.f, z), near), span);
+            const float hp = __fadd_rn(hitp, 1e-5f);
+            const float hsum = wave_sum(act ? hp : 0.f);
+            if (act) { Dn[i] = dnv; Pd[i] = __fdiv_rn(hp, hsum); }
+            wave_sync();
+            if (act) {
+                float c = 0.f;
+                for (int j = 0; j <= i; ++j) c = __fadd_rn(c, Pd[j]);             // sequential cumsum
+                Cd[i + 1] = c;
+                Ce[i + 1] = (i + 1 < dn) ? __fmul_rn(__fadd_rn(Dn[i + 1], Dn[i]), 0.5f) : Dn[dn - 1];
+                if (i == 0) { Cd[0] = 0.f; Ce[0] = Dn[0]; }
+            }
+            wave_sync();
+            const bool fact = lane < fdn;
+            const float interval = 1.f / (float)fdn;
+            const float u = __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)lane, interval));
+            int inds = 0;
+            for (int j = 0; j <= dn; ++j) inds += (Cd[j] <= u) ? 1 : 0;          // searchsorted(right=True)
+            const int below = max(inds - 1, 0), above = min(inds, dn);
+            const float c0 = Cd[below], c1 = Cd[above], b0 = Ce[below], b1 = Ce[above];
+            float den = __fsub_rn(c1, c0);
+            if (den < 1e-5f) den = 1.f;
+            const float tt = __fdiv_rn(__fsub_rn(u, c0), den);
+            float fd = __fadd_rn(b0, __fmul_rn(tt, __fsub_rn(b1, b0)));
+            fd = __fadd_rn(__fmul_rn(fd, span), near);
+            fd = __fdiv_rn(-1.f, fd);
+            if (fact) Fd[lane] = fd;
+            wave_sync();
+            if (fact) {
+                int rank = 0;                                                    // stable rank sort (renderer.py:148)
+                for (int j = 0; j < fdn; ++j) { const float o2 = Fd[j]; rank += (o2 < fd || (o2 == fd && j < lane)) ? 1 : 0; }
+                a.fine_depth[(size_t)ray * fdn + rank] = fd;
+                if (a.fine_inds) a.fine_inds[(size_t)ray * fdn + lane] = inds;
+            }
+        }
+    }
+}
+
+// mean over the scene's rays of the per-ray partial sums / (rn*dn)   (aggregate_net.py:139)
+__global__ void k_gerr_reduce(const float* __restrict__ part, float* __restrict__ out, int rn, int dn) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < rn; i += 256) s += part[(size_t)b * rn + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[b] = red[0] / (float)(rn * dn);
+}
+
+// pixel_colors_gt: bilinear, zeros padding, align_corners=True  (renderer.py:125-127, ops.py:29-33)
+__global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restrict__ coords, float* __restrict__ out,
+                           int rn, int H, int W, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * rn) return;
+    const int b = i / rn;
+    const float x = coords[(size_t)i * 2], y = coords[(size_t)i * 2 + 1];
+    const float xn = x / (float)(W - 1) * 2.f - 1.f, yn = y / (float)(H - 1) * 2.f - 1.f;
+    const float px = (xn + 1.f) * 0.5f * (float)(W - 1), py = (yn + 1.f) * 0.5f * (float)(H - 1);
+    const float x0 = floorf(px), y0 = floorf(py);
+    const int x0i = (int)x0, y0i = (int)y0;
+    const float wx1 = px - x0, wy1 = py - y0;
+    for (int c = 0; c < 3; ++c) {
+        const float* im = imgs + ((size_t)b * 3 + c) * H * W;
+        auto tap = [&](int yy, int xx) { return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? im[yy * W + xx] : 0.f; };
+        out[(size_t)i * 3 + c] = tap(y0i, x0i) * (1.f - wx1) * (1.f - wy1) + tap(y0i, x0i + 1) * wx1 * (1.f - wy1) +
+                                 tap(y0i + 1, x0i) * (1.f - wx1) * wy1 + tap(y0i + 1, x0i + 1) * wx1 * wy1;
+    }
+}
+
+}  // namespace gnr
+
+#include "gnr_capi.inc"

@@ -1,0 +1,129 @@
+// Packed-weight layout shared by the host packer (gnr_pack.cpp) and the gfx950 kernels.
+//
+// Execution model of the per-(point, view) chain (k_chain in gnr_kernels.hip):
+//   one wavefront owns a TILE of 16 points and all V views of those points.
+//   lane l = (r = l & 15 : point within the tile, g = l >> 4 : feature group 0..3).
+//   A feature vector is held "B-operand style": float v[J]; on lane (r,g) v[j] is logical
+//   feature phi(j,g) of point r.  A linear layer  y = W x  is a chain of
+//   v_mfma_f32_16x16x4_f32 with  A = weight fragment (row i = output feature, k = g),
+//   B = v[j]  ->  D[i][r]; lane (r,g) register t of block nb then holds output feature
+//   psi(nb, 4g+t), i.e. the output is again in B-operand layout.  No cross-lane movement
+//   between layers; only the k-order of each dot product is permuted (fp32 reassociation).
+//   "natural" layout: phi(j,g) = 16*(j/4) + 4*g + (j%4)   <->   psi(nb,i) = 16*nb + i.
+//
+// A-fragment storage of a layer with J k-steps and NB output blocks (floats):
+//   NB = 2 : [J][64 lanes][2]      ds_read_b64  per k-step
+//   NB = 4 : [J][64][4]            ds_read_b128 per k-step
+//   NB = 3 : [J][64][4] (4th = 0)  ds_read_b128 per k-step
+//   NB = 1 : [ceil(J/4)][64][4]    ds_read_b128 per 4 k-steps (component = j % 4)
+#pragma once
+
+namespace gnr {
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int frag_floats(int J, int NB) {
+    return NB == 1 ? cdiv(J, 4) * 256 : (NB == 3 ? J * 256 : J * 64 * NB);
+}
+
+// ---- canonical (reference state-dict order) blob of one level: decoder + agg net --------
+// ref: dist_decoder.py:64-88, aggregate_net.py:29-33, ibrnet.py:382-423, neus.py:9
+namespace can {
+constexpr int DEC_BRANCH = 32 * 32 + 32 + 32 * 32 + 32;       // .0 and .2 of one branch
+constexpr int MEAN0_W = 0, MEAN0_B = MEAN0_W + 1024, MEAN2_W = MEAN0_B + 32, MEAN2_B = MEAN2_W + 1024;
+constexpr int MEAN4_W = MEAN2_B + 32, MEAN4_B = MEAN4_W + 64;
+constexpr int VAR0_W = MEAN4_B + 2, VAR0_B = VAR0_W + 1024, VAR2_W = VAR0_B + 32, VAR2_B = VAR2_W + 1024;
+constexpr int VAR4_W = VAR2_B + 32, VAR4_B = VAR4_W + 64;
+constexpr int AW0_W = VAR4_B + 2, AW0_B = AW0_W + 1024, AW2_W = AW0_B + 32, AW2_B = AW2_W + 1024;
+constexpr int AW4_W = AW2_B + 32, AW4_B = AW4_W + 32;
+constexpr int PE0_W = AW4_B + 1, PE0_B = PE0_W + 32 * 34, PE2_W = PE0_B + 32, PE2_B = PE2_W + 1024;
+constexpr int RDF0_W = PE2_B + 32, RDF0_B = RDF0_W + 64, RDF2_W = RDF0_B + 16, RDF2_B = RDF2_W + 35 * 16;
+constexpr int BASE0_W = RDF2_B + 35, BASE0_B = BASE0_W + 64 * 207, BASE2_W = BASE0_B + 64, BASE2_B = BASE2_W + 32 * 64;
+constexpr int VIS0_W = BASE2_B + 32, VIS0_B = VIS0_W + 1024, VIS2_W = VIS0_B + 32, VIS2_B = VIS2_W + 33 * 32;
+constexpr int VISB0_W = VIS2_B + 33, VISB0_B = VISB0_W + 1024, VISB2_W = VISB0_B + 32, VISB2_B = VISB2_W + 32;
+constexpr int GEO0_W = VISB2_B + 1, GEO0_B = GEO0_W + 64 * 86, GEO2_W = GEO0_B + 64, GEO2_B = GEO2_W + 16 * 64;
+constexpr int WQ = GEO2_B + 16, WK = WQ + 256, WV = WK + 256, WFC = WV + 256, LN_W = WFC + 256, LN_B = LN_W + 16;
+constexpr int OUT0_W = LN_B + 16, OUT0_B = OUT0_W + 256, OUT1_W = OUT0_B + 16, OUT1_B = OUT1_W + 16;
+constexpr int RGB0_W = OUT1_B + 1, RGB0_B = RGB0_W + 16 * 37, RGB2_W = RGB0_B + 16, RGB2_B = RGB2_W + 128;
+constexpr int RGB4_W = RGB2_B + 8, RGB4_B = RGB4_W + 8;
+constexpr int NR0_W = RGB4_B + 1, NR0_B = NR0_W + 256, NR2_W = NR0_B + 8, NR2_B = NR2_W + 8;
+constexpr int VARIANCE = NR2_B + 1;
+constexpr int TOTAL = VARIANCE + 1;
+static_assert(TOTAL == 36958, "canonical size must equal the reference parameter count");
+}  // namespace can
+
+// ---- packed blob of one level ------------------------------------------------------------
+// CHAIN section: copied verbatim into LDS by k_chain.  All offsets in floats.
+namespace pk {
+// MFMA A-fragments                 J   NB
+constexpr int DEC1 = 0;          //  8   2   x3 branches (mean, var, aw), 1024 floats each
+constexpr int DEC2 = DEC1 + 3 * frag_floats(8, 2);        //  8   2   x3
+constexpr int PE1 = DEC2 + 3 * frag_floats(8, 2);         //  9   2
+constexpr int PE2 = PE1 + frag_floats(9, 2);              //  8   2
+constexpr int RDF1 = PE2 + frag_floats(8, 2);             //  1   1
+constexpr int RDF2 = RDF1 + frag_floats(1, 1);            //  4   3
+constexpr int NR1 = RDF2 + frag_floats(4, 3);             //  8   1
+constexpr int BASE1 = NR1 + frag_floats(8, 1);            // 17   4
+constexpr int BASE2 = BASE1 + frag_floats(17, 4);         // 16   2
+constexpr int VIS1 = BASE2 + frag_floats(16, 2);          //  8   2
+constexpr int VIS2 = VIS1 + frag_floats(8, 2);            //  8   2   (rows 0..31 of the 33)
+constexpr int VISB1 = VIS2 + frag_floats(8, 2);           //  8   2
+constexpr int RGB1 = VISB1 + frag_floats(8, 2);           // 10   1
+constexpr int RGB2 = RGB1 + frag_floats(10, 1);           //  4   1
+constexpr int HOIST = RGB2 + frag_floats(4, 1);           // 36   4
+constexpr int GEO1 = HOIST + frag_floats(36, 4);          // 23   4
+constexpr int GEO2 = GEO1 + frag_floats(23, 4);           // 16   1
+constexpr int FRAG_END = GEO2 + frag_floats(16, 1);
+// bias tables: [NB][4 groups][4 regs] floats per layer (lane reads float4 at nb*4+g)
+constexpr int B_DEC1 = FRAG_END;            // 3 x 32
+constexpr int B_DEC2 = B_DEC1 + 96;         // 3 x 32
+constexpr int B_PE1 = B_DEC2 + 96;
+constexpr int B_PE2 = B_PE1 + 32;
+constexpr int B_RDF1 = B_PE2 + 32;
+constexpr int B_RDF2 = B_RDF1 + 16;         // 48 (3 blocks)
+constexpr int B_NR1 = B_RDF2 + 48;
+constexpr int B_HOIST = B_NR1 + 16;         // base_fc.0 bias, 64
+constexpr int B_BASE2 = B_HOIST + 64;
+constexpr int B_VIS1 = B_BASE2 + 32;
+constexpr int B_VIS2 = B_VIS1 + 32;
+constexpr int B_VISB1 = B_VIS2 + 32;
+constexpr int B_RGB1 = B_VISB1 + 32;
+constexpr int B_RGB2 = B_RGB1 + 16;
+constexpr int B_GEO1 = B_RGB2 + 16;         // 64
+constexpr int B_GEO2 = B_GEO1 + 64;         // 16
+constexpr int BIAS_END = B_GEO2 + 16;
+// VALU tables for the 1..2-row output layers: per lane-group weights [g][8] (or [g][4])
+constexpr int T_DEC3 = BIAS_END;            // 5 outputs x [4 g][8 j] = 160 ; order mean0 mean1 var0 var1 aw
+constexpr int T_DEC3_B = T_DEC3 + 160;      // 5 biases (+3 pad)
+constexpr int T_NR2 = T_DEC3_B + 8;         // [4][4]
+constexpr int T_VIS2R = T_NR2 + 16;         // row 32 of vis_fc.2: [4][8]
+constexpr int T_VISB2 = T_VIS2R + 32;       // vis_fc2.2: [4][8]
+constexpr int T_RGB3 = T_VISB2 + 32;        // rgb_fc.4: [4][4]
+constexpr int T_SCAL = T_RGB3 + 16;         // scalars: [0]=nr2 bias [1]=vis2 row32 bias [2]=visb2 bias [3]=rgb3 bias
+constexpr int CHAIN_END = T_SCAL + 8;
+static_assert(CHAIN_END % 4 == 0, "CHAIN section must be float4 copyable");
+static_assert(CHAIN_END * 4 <= 160 * 1024, "CHAIN section must fit the 160 KiB LDS");
+
+// RAY section (k_ray): plain row-major matrices, read with wave-uniform (scalar) loads
+constexpr int R_WQ = CHAIN_END, R_WK = R_WQ + 256, R_WV = R_WK + 256, R_WFC = R_WV + 256;
+constexpr int R_LNW = R_WFC + 256, R_LNB = R_LNW + 16;
+constexpr int R_OUT0W = R_LNB + 16, R_OUT0B = R_OUT0W + 256, R_OUT1W = R_OUT0B + 16, R_OUT1B = R_OUT1W + 16;
+constexpr int R_GEO2W = R_OUT1B + 4;        // [16][64]
+constexpr int R_GEO1E = R_GEO2W + 1024;     // geometry_fc.0 weight columns 65..85: [64][21 -> 24]
+constexpr int R_VARIANCE = R_GEO1E + 64 * 24;
+constexpr int R_PE = R_VARIANCE + 4;        // sinusoid table [64 positions][16]
+constexpr int TOTAL = R_PE + 64 * 16;
+}  // namespace pk
+
+// per-point descriptor (k_points_* -> k_chain): 8 floats
+//   [0..2] world point, [3..5] query direction, [6] lo, [7] hi  (half-intervals in the
+//   reference views' normalised inverse depth; ref: dist_decoder.py:34-49)
+constexpr int DESC_FLOATS = 8;
+// per-view parameter block (k_view_setup -> k_chain): 24 floats
+//   [0..11] H = K*[R|t] row-major 3x4, [12..14] camera centre, [15] -1/near, [16] (-1/far)-(-1/near)
+constexpr int VIEWP_FLOATS = 24;
+// per-point record (k_chain -> k_ray)
+constexpr int REC_VOL = 20;     // g16[16], nvalid, pad
+constexpr int REC_RAY = 84;     // g16[16], u[64], nvalid, pad
+constexpr int MAX_DN = 64;      // samples per ray / column handled by one wavefront in k_ray
+
+}  // namespace gnr

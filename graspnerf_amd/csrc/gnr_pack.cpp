@@ -1,0 +1,207 @@
+// Host-side weight packer: reference state-dict order (canonical blob) -> MFMA A-fragment
+// blob consumed by the gfx950 kernels.  See gnr_layout.h for the execution model.
+// Parameter shapes/order: ref dist_decoder.py:64-88, aggregate_net.py:29-33, ibrnet.py:382-423.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "gnr_layout.h"
+#include "../../include/gnr.h"
+
+namespace {
+using namespace gnr;
+using IdxFn = std::function<int(int, int)>;
+
+inline int nat_in(int j, int g) { return 16 * (j / 4) + 4 * g + (j % 4); }
+inline int nat_out(int nb, int i) { return 16 * nb + i; }
+// layout of the 35-wide colour feature x = [r,g,b, img_feats(32)] in 9 slots
+inline int xfeat(int j, int g) { return j < 8 ? 3 + 8 * g + j : (g < 3 ? g : -1); }
+
+// frag[(j,nb,lane)] = W[psi(nb, lane&15)][phi(j, lane>>4)]
+void pack_frag(float* dst, const float* W, int ldw, int J, int NB, const IdxFn& phi, const IdxFn& psi) {
+    std::memset(dst, 0, sizeof(float) * frag_floats(J, NB));
+    for (int j = 0; j < J; ++j)
+        for (int nb = 0; nb < NB; ++nb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = psi(nb, lane & 15), i = phi(j, lane >> 4);
+                const float v = (o >= 0 && i >= 0) ? W[o * ldw + i] : 0.f;
+                int idx;
+                if (NB == 1) idx = ((j / 4) * 64 + lane) * 4 + (j % 4);
+                else if (NB == 3) idx = (j * 64 + lane) * 4 + nb;
+                else idx = (j * 64 + lane) * NB + nb;
+                dst[idx] = v;
+            }
+}
+
+void pack_bias(float* dst, const float* b, int NB, const IdxFn& psi) {
+    for (int nb = 0; nb < NB; ++nb)
+        for (int i = 0; i < 16; ++i) {
+            const int o = psi(nb, i);
+            dst[nb * 16 + i] = o >= 0 ? b[o] : 0.f;   // i = 4g + reg
+        }
+}
+
+// per-lane-group table of one output row over a natural-layout input of J slots: T[g][j]
+void pack_row(float* dst, const float* wrow, int J, int limit = 1 << 30) {
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < J; ++j) {
+            const int i = nat_in(j, g);
+            dst[g * J + j] = i < limit ? wrow[i] : 0.f;
+        }
+}
+}  // namespace
+
+// name -> float offset inside the packed blob (tests / tooling); -1 if unknown
+extern "C" int gnr_layout_offset(const char* name) {
+    using namespace gnr::pk;
+    struct E { const char* n; int o; };
+    static const E tab[] = {
+        {"DEC1", DEC1}, {"DEC2", DEC2}, {"PE1", PE1}, {"PE2", PE2}, {"RDF1", RDF1}, {"RDF2", RDF2}, {"NR1", NR1},
+        {"BASE1", BASE1}, {"BASE2", BASE2}, {"VIS1", VIS1}, {"VIS2", VIS2}, {"VISB1", VISB1}, {"RGB1", RGB1},
+        {"RGB2", RGB2}, {"HOIST", HOIST}, {"GEO1", GEO1}, {"GEO2", GEO2}, {"FRAG_END", FRAG_END},
+        {"B_DEC1", B_DEC1}, {"B_DEC2", B_DEC2}, {"B_PE1", B_PE1}, {"B_PE2", B_PE2}, {"B_RDF1", B_RDF1},
+        {"B_RDF2", B_RDF2}, {"B_NR1", B_NR1}, {"B_HOIST", B_HOIST}, {"B_BASE2", B_BASE2}, {"B_VIS1", B_VIS1},
+        {"B_VIS2", B_VIS2}, {"B_VISB1", B_VISB1}, {"B_RGB1", B_RGB1}, {"B_RGB2", B_RGB2}, {"B_GEO1", B_GEO1},
+        {"B_GEO2", B_GEO2}, {"T_DEC3", T_DEC3}, {"T_DEC3_B", T_DEC3_B}, {"T_NR2", T_NR2}, {"T_VIS2R", T_VIS2R},
+        {"T_VISB2", T_VISB2}, {"T_RGB3", T_RGB3}, {"T_SCAL", T_SCAL}, {"CHAIN_END", CHAIN_END},
+        {"R_WQ", R_WQ}, {"R_WK", R_WK}, {"R_WV", R_WV}, {"R_WFC", R_WFC}, {"R_LNW", R_LNW}, {"R_LNB", R_LNB},
+        {"R_OUT0W", R_OUT0W}, {"R_OUT0B", R_OUT0B}, {"R_OUT1W", R_OUT1W}, {"R_OUT1B", R_OUT1B},
+        {"R_GEO2W", R_GEO2W}, {"R_GEO1E", R_GEO1E}, {"R_VARIANCE", R_VARIANCE}, {"R_PE", R_PE}, {"TOTAL", TOTAL}};
+    for (const E& e : tab)
+        if (!std::strcmp(e.n, name)) return e.o;
+    return -1;
+}
+
+extern "C" int gnr_canonical_weights_floats(void) { return gnr::can::TOTAL; }
+extern "C" int gnr_packed_weights_floats(void) { return gnr::pk::TOTAL; }
+
+extern "C" int gnr_pack_weights(const float* c, float* p) {
+    if (!c || !p) return GNR_ERR_ARG;
+    using namespace gnr;
+    std::memset(p, 0, sizeof(float) * pk::TOTAL);
+    const IdxFn natI = nat_in, natO = nat_out;
+    const IdxFn ray8 = [](int j, int g) { return 8 * g + j; };
+    const IdxFn first8 = [](int, int i) { return i < 8 ? i : -1; };
+
+    // --- decoder: three branches, layers .0 (input = ray feature channels 8g+j) and .2
+    const int d0w[3] = {can::MEAN0_W, can::VAR0_W, can::AW0_W}, d0b[3] = {can::MEAN0_B, can::VAR0_B, can::AW0_B};
+    const int d2w[3] = {can::MEAN2_W, can::VAR2_W, can::AW2_W}, d2b[3] = {can::MEAN2_B, can::VAR2_B, can::AW2_B};
+    for (int br = 0; br < 3; ++br) {
+        pack_frag(p + pk::DEC1 + br * frag_floats(8, 2), c + d0w[br], 32, 8, 2, ray8, natO);
+        pack_bias(p + pk::B_DEC1 + br * 32, c + d0b[br], 2, natO);
+        pack_frag(p + pk::DEC2 + br * frag_floats(8, 2), c + d2w[br], 32, 8, 2, natI, natO);
+        pack_bias(p + pk::B_DEC2 + br * 32, c + d2b[br], 2, natO);
+    }
+    // decoder .4 rows on the VALU: mean0 mean1 var0 var1 aw
+    pack_row(p + pk::T_DEC3 + 0 * 32, c + can::MEAN4_W, 8);
+    pack_row(p + pk::T_DEC3 + 1 * 32, c + can::MEAN4_W + 32, 8);
+    pack_row(p + pk::T_DEC3 + 2 * 32, c + can::VAR4_W, 8);
+    pack_row(p + pk::T_DEC3 + 3 * 32, c + can::VAR4_W + 32, 8);
+    pack_row(p + pk::T_DEC3 + 4 * 32, c + can::AW4_W, 8);
+    p[pk::T_DEC3_B + 0] = c[can::MEAN4_B]; p[pk::T_DEC3_B + 1] = c[can::MEAN4_B + 1];
+    p[pk::T_DEC3_B + 2] = c[can::VAR4_B]; p[pk::T_DEC3_B + 3] = c[can::VAR4_B + 1];
+    p[pk::T_DEC3_B + 4] = c[can::AW4_B];
+
+    // --- prob_embed: 34 -> 32 -> 32 ; slot 8 carries (hit', vis') on groups 0,1
+    pack_frag(p + pk::PE1, c + can::PE0_W, 34, 9, 2,
+              [](int j, int g) { return j < 8 ? 8 * g + j : (g == 0 ? 32 : (g == 1 ? 33 : -1)); }, natO);
+    pack_bias(p + pk::B_PE1, c + can::PE0_B, 2, natO);
+    pack_frag(p + pk::PE2, c + can::PE2_W, 32, 8, 2, natI, natO);
+    pack_bias(p + pk::B_PE2, c + can::PE2_B, 2, natO);
+
+    // --- ray_dir_fc: 4 -> 16 -> 35, output laid out like x (see xfeat)
+    pack_frag(p + pk::RDF1, c + can::RDF0_W, 4, 1, 1, [](int, int g) { return g; }, natO);
+    pack_bias(p + pk::B_RDF1, c + can::RDF0_B, 1, natO);
+    const IdxFn xout = [](int nb, int i) {
+        const int g = i >> 2, r = i & 3;
+        if (nb == 0) return 3 + 8 * g + r;
+        if (nb == 1) return 3 + 8 * g + 4 + r;
+        return (r == 0 && g < 3) ? g : -1;
+    };
+    pack_frag(p + pk::RDF2, c + can::RDF2_W, 16, 4, 3, natI, xout);
+    pack_bias(p + pk::B_RDF2, c + can::RDF2_B, 3, xout);
+
+    // --- neuray_fc: 32 -> 8 (MFMA) -> 1 (VALU)
+    pack_frag(p + pk::NR1, c + can::NR0_W, 32, 8, 1, natI, first8);
+    pack_bias(p + pk::B_NR1, c + can::NR0_B, 1, first8);
+    for (int g = 0; g < 4; ++g)
+        for (int r = 0; r < 4; ++r) p[pk::T_NR2 + g * 4 + r] = (4 * g + r < 8) ? c[can::NR2_W + 4 * g + r] : 0.f;
+    p[pk::T_SCAL + 0] = c[can::NR2_B];
+
+    // --- base_fc.0 split: view-invariant 140 columns (HOIST) + per-view 67 columns (BASE1)
+    pack_frag(p + pk::HOIST, c + can::BASE0_W, 207, 36, 4,
+              [](int j, int g) { const int x = xfeat(j % 9, g); return x < 0 ? -1 : 35 * (j / 9) + x; }, natO);
+    pack_bias(p + pk::B_HOIST, c + can::BASE0_B, 4, natO);
+    pack_frag(p + pk::BASE1, c + can::BASE0_W, 207, 17, 4,
+              [](int j, int g) {
+                  if (j < 9) { const int x = xfeat(j, g); return x < 0 ? -1 : 140 + x; }
+                  return 175 + nat_in(j - 9, g);
+              }, natO);
+    pack_frag(p + pk::BASE2, c + can::BASE2_W, 64, 16, 2, natI, natO);
+    pack_bias(p + pk::B_BASE2, c + can::BASE2_B, 2, natO);
+
+    // --- vis_fc (32 -> 32 -> 32+1) and vis_fc2 (32 -> 32 -> 1)
+    pack_frag(p + pk::VIS1, c + can::VIS0_W, 32, 8, 2, natI, natO);
+    pack_bias(p + pk::B_VIS1, c + can::VIS0_B, 2, natO);
+    pack_frag(p + pk::VIS2, c + can::VIS2_W, 32, 8, 2, natI, natO);
+    pack_bias(p + pk::B_VIS2, c + can::VIS2_B, 2, natO);
+    pack_row(p + pk::T_VIS2R, c + can::VIS2_W + 32 * 32, 8);
+    p[pk::T_SCAL + 1] = c[can::VIS2_B + 32];
+    pack_frag(p + pk::VISB1, c + can::VISB0_W, 32, 8, 2, natI, natO);
+    pack_bias(p + pk::B_VISB1, c + can::VISB0_B, 2, natO);
+    pack_row(p + pk::T_VISB2, c + can::VISB2_W, 8);
+    p[pk::T_SCAL + 2] = c[can::VISB2_B];
+
+    // --- rgb_fc: [h(32), vis(1), dir_diff(4)] -> 16 -> 8 -> 1
+    pack_frag(p + pk::RGB1, c + can::RGB0_W, 37, 10, 1,
+              [](int j, int g) {
+                  if (j < 8) return nat_in(j, g);
+                  if (j == 8) return g == 0 ? 32 : 33 + (g - 1);
+                  return g == 0 ? 36 : -1;
+              }, natO);
+    pack_bias(p + pk::B_RGB1, c + can::RGB0_B, 1, natO);
+    pack_frag(p + pk::RGB2, c + can::RGB2_W, 16, 4, 1, natI, first8);
+    pack_bias(p + pk::B_RGB2, c + can::RGB2_B, 1, first8);
+    for (int g = 0; g < 4; ++g)
+        for (int r = 0; r < 4; ++r) p[pk::T_RGB3 + g * 4 + r] = (4 * g + r < 8) ? c[can::RGB4_W + 4 * g + r] : 0.f;
+    p[pk::T_SCAL + 3] = c[can::RGB4_B];
+
+    // --- geometry_fc: [mean(32), var(32), wbar, embed(21)] -> 64 -> 16
+    //     slots 16..22: group 0 carries wbar in slot 16; group g>=1 carries coordinate g-1,
+    //     kind k = slot-16 of [p, sin p, cos p, sin 2p, cos 2p, sin 4p, cos 4p]  (neus.py:37-45)
+    pack_frag(p + pk::GEO1, c + can::GEO0_W, 86, 23, 4,
+              [](int j, int g) {
+                  if (j < 8) return nat_in(j, g);
+                  if (j < 16) return 32 + nat_in(j - 8, g);
+                  const int k = j - 16;
+                  if (g == 0) return k == 0 ? 64 : -1;
+                  return 65 + 3 * k + (g - 1);
+              }, natO);
+    pack_bias(p + pk::B_GEO1, c + can::GEO0_B, 4, natO);
+    pack_frag(p + pk::GEO2, c + can::GEO2_W, 64, 16, 1, natI, natO);
+    pack_bias(p + pk::B_GEO2, c + can::GEO2_B, 1, natO);
+
+    // --- RAY section
+    std::memcpy(p + pk::R_WQ, c + can::WQ, sizeof(float) * 256);
+    std::memcpy(p + pk::R_WK, c + can::WK, sizeof(float) * 256);
+    std::memcpy(p + pk::R_WV, c + can::WV, sizeof(float) * 256);
+    std::memcpy(p + pk::R_WFC, c + can::WFC, sizeof(float) * 256);
+    std::memcpy(p + pk::R_LNW, c + can::LN_W, sizeof(float) * 16);
+    std::memcpy(p + pk::R_LNB, c + can::LN_B, sizeof(float) * 16);
+    std::memcpy(p + pk::R_OUT0W, c + can::OUT0_W, sizeof(float) * 256);
+    std::memcpy(p + pk::R_OUT0B, c + can::OUT0_B, sizeof(float) * 16);
+    std::memcpy(p + pk::R_OUT1W, c + can::OUT1_W, sizeof(float) * 16);
+    p[pk::R_OUT1B] = c[can::OUT1_B];
+    std::memcpy(p + pk::R_GEO2W, c + can::GEO2_W, sizeof(float) * 1024);
+    for (int h = 0; h < 64; ++h)
+        for (int e = 0; e < 21; ++e) p[pk::R_GEO1E + h * 24 + e] = c[can::GEO0_W + h * 86 + 65 + e];
+    p[pk::R_VARIANCE] = c[can::VARIANCE];
+    // positional table, float64 then cast (ref: ibrnet.py:437-445)
+    for (int pos = 0; pos < 64; ++pos)
+        for (int k = 0; k < 16; ++k) {
+            const double ang = (double)pos / std::pow(10000.0, 2.0 * (k / 2) / 16.0);
+            p[pk::R_PE + pos * 16 + k] = (float)((k % 2 == 0) ? std::sin(ang) : std::cos(ang));
+        }
+    return GNR_OK;
+}

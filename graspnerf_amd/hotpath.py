@@ -1,0 +1,171 @@
+"""Batched device front-end of libgnr.so.  PyTorch is used for device memory and streams only;
+every number on the hot path is produced by the HIP kernels behind the C ABI (include/gnr.h).
+
+Tensors are float32, contiguous, on one `cuda` device, with a leading scene-batch dim B:
+  ref : imgs[B,V,3,H,W] img_feats[B,V,32,fh,fw] ray_feats[B,V,32,fh,fw] poses[B,V,3,4] Ks[B,V,3,3]
+        depth_range[B,V,2] bbox3d[B,2,3]
+  que : coords[B,rn,2] pose[B,3,4] K[B,3,3] depth_range[B,2] (imgs[B,3,H,W])
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GnrScene, GnrRays, GnrRenderOut
+
+RENDER_KEYS = ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'pixel_colors_gt',
+               'render_depth', 'ray_mask', 'sdf_gradient_error']
+
+
+def _f32(t, device):
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HotPath:
+    def __init__(self, packed_coarse, packed_fine=None, device='cuda:0'):
+        self.L = _lib.lib()                      # raises if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise _lib.GnrError('graspnerf_amd hot path needs a ROCm GPU (torch.cuda.is_available() is False); '
+                                'there is no CPU fallback')
+        self.device = torch.device(device)
+        self.wc = torch.from_numpy(np.ascontiguousarray(packed_coarse, np.float32)).to(self.device)
+        self.wf = None if packed_fine is None else torch.from_numpy(np.ascontiguousarray(packed_fine, np.float32)).to(self.device)
+        self._ws = None
+        self._keep = []
+
+    # ---- plumbing ------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _scene(self, ref):
+        d = self.device
+        t = {k: _f32(ref[k], d) for k in ('imgs', 'img_feats', 'ray_feats', 'poses', 'Ks', 'depth_range')}
+        B, V, _, H, W = t['imgs'].shape
+        fh, fw = t['img_feats'].shape[-2:]
+        assert t['img_feats'].shape == (B, V, 32, fh, fw) and t['ray_feats'].shape == (B, V, 32, fh, fw)
+        assert t['poses'].shape == (B, V, 3, 4) and t['Ks'].shape == (B, V, 3, 3) and t['depth_range'].shape == (B, V, 2)
+        s = GnrScene(B, V, H, W, fh, fw, t['imgs'].data_ptr(), t['img_feats'].data_ptr(), t['ray_feats'].data_ptr(),
+                     t['poses'].data_ptr(), t['Ks'].data_ptr(), t['depth_range'].data_ptr())
+        return s, t
+
+    def _workspace(self, scene, res, rn, dn):
+        need = self.L.gnr_workspace_bytes(C.byref(scene), res, rn, dn)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def prepare(self, ref, res=40, rn=0, dn=0):
+        """Repack feature maps + per-view projection blocks (timed part of a forward)."""
+        scene, keep = self._scene(ref)
+        ws = self._workspace(scene, res, rn, dn)
+        _lib.check(self.L.gnr_prepare(C.byref(scene), ws.data_ptr(), ws.numel(), self._stream()), 'gnr_prepare')
+        self._prepared = (scene, keep, ws)
+        return self._prepared
+
+    # ---- sample_volume (ref: renderer.py:164-199) ------------------------------------------
+    def sample_volume(self, ref, res=40, want_mask=False, prepared=None):
+        scene, keep, ws = prepared or self.prepare(ref, res)
+        B = scene.B
+        bbox_min = _f32(ref['bbox3d'], self.device)[:, 0].contiguous()
+        vol = torch.empty(B, 1, res, res, res, dtype=torch.float32, device=self.device)
+        vmask = torch.empty(B, res, res, res, dtype=torch.uint8, device=self.device) if want_mask else None
+        _lib.check(self.L.gnr_sample_volume_fwd(C.byref(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(),
+                                                vol.data_ptr(), vmask.data_ptr() if want_mask else None,
+                                                ws.data_ptr(), ws.numel(), self._stream()), 'gnr_sample_volume_fwd')
+        return (vol, vmask) if want_mask else vol
+
+    def debug_volume_chain(self, ref, res=40, prepared=None):
+        scene, keep, ws = prepared or self.prepare(ref, res)
+        bbox_min = _f32(ref['bbox3d'], self.device)[:, 0].contiguous()
+        dbg = torch.zeros(scene.B, res ** 3, 32, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.gnr_debug_volume_chain(C.byref(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(),
+                                                 dbg.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                   'gnr_debug_volume_chain')
+        return dbg
+
+    # ---- render (ref: renderer.py:140-162, 201-220) ----------------------------------------
+    def _rays(self, que, dn, fdn, cfg, H, W):
+        d = self.device
+        t = {'coords': _f32(que['coords'], d), 'pose': _f32(que['pose'], d), 'K': _f32(que['K'], d),
+             'depth_range': _f32(que['depth_range'], d)}
+        B, rn, _ = t['coords'].shape
+        imgs = _f32(que['imgs'], d) if 'imgs' in que else None
+        if imgs is not None:
+            assert imgs.shape == (B, 3, H, W)
+            t['imgs'] = imgs
+        r = GnrRays(rn, dn, fdn, cfg.get('ray_mask_view_num', 2), cfg.get('ray_mask_point_num', 8),
+                    t['coords'].data_ptr(), t['pose'].data_ptr(), t['K'].data_ptr(), t['depth_range'].data_ptr(),
+                    imgs.data_ptr() if imgs is not None else None)
+        return r, t
+
+    def _alloc_out(self, B, rn, dn, with_gt, debug):
+        d = self.device
+        o = {'depth': torch.empty(B, rn, dn, device=d), 'sdf_values': torch.empty(B, rn, dn, device=d),
+             'alpha_values': torch.empty(B, rn, dn, device=d), 'colors_nr': torch.empty(B, rn, dn, 3, device=d),
+             'hit_prob_nr': torch.empty(B, rn, dn, device=d), 'pixel_colors_nr': torch.empty(B, rn, 3, device=d),
+             'render_depth': torch.empty(B, rn, device=d), 'ray_mask': torch.empty(B, rn, dtype=torch.uint8, device=d),
+             'sdf_gradient_error': torch.empty(B, device=d)}
+        if with_gt:
+            o['pixel_colors_gt'] = torch.empty(B, rn, 3, device=d)
+        if debug:
+            o['sdf_gradient'] = torch.empty(B, rn, dn, 3, device=d)
+            o['view_mask'] = torch.empty(B, rn, dn, dtype=torch.uint8, device=d)
+        s = GnrRenderOut(*[o[k].data_ptr() if k in o else None for k in _lib.RENDER_OUT_FIELDS])
+        return s, o
+
+    def render(self, ref, que, cfg=None, fine_depth_in=None, debug=False, prepared=None):
+        """-> (coarse dict, fine dict[, fine_inds]) of device tensors with a leading batch dim."""
+        cfg = cfg or {}
+        dn, fdn = cfg.get('depth_sample_num', 40), cfg.get('fine_depth_sample_num', 40)
+        if self.wf is None:
+            raise _lib.GnrError('render() needs the fine-level weights')
+        B, rn = que['coords'].shape[:2]
+        scene, keep, ws = prepared or self.prepare(ref, 1, rn, max(dn, fdn))
+        rays, rkeep = self._rays(que, dn, fdn, cfg, scene.H, scene.W)
+        co_s, co = self._alloc_out(B, rn, dn, 'imgs' in que, debug)
+        fi_s, fi = self._alloc_out(B, rn, fdn, 'imgs' in que, debug)
+        fd_in = _f32(fine_depth_in, self.device) if fine_depth_in is not None else None
+        inds = torch.empty(B, rn, fdn, dtype=torch.int32, device=self.device) if debug else None
+        _lib.check(self.L.gnr_render_rays_fwd(C.byref(scene), C.byref(rays), self.wc.data_ptr(), self.wf.data_ptr(),
+                                              C.byref(co_s), C.byref(fi_s),
+                                              fd_in.data_ptr() if fd_in is not None else None,
+                                              inds.data_ptr() if debug else None,
+                                              ws.data_ptr(), ws.numel(), self._stream()), 'gnr_render_rays_fwd')
+        for o in (co, fi):
+            o['ray_mask'] = o['ray_mask'].bool()
+        return (co, fi, inds) if debug else (co, fi)
+
+    def render_by_depth(self, ref, que, depth, level='coarse', cfg=None, debug=False, prepared=None):
+        cfg = cfg or {}
+        depth = _f32(depth, self.device)
+        B, rn, dn = depth.shape
+        scene, keep, ws = prepared or self.prepare(ref, 1, rn, dn)
+        rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
+        o_s, o = self._alloc_out(B, rn, dn, 'imgs' in que, debug)
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_render_by_depth_fwd(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
+                                                  C.byref(o_s), ws.data_ptr(), ws.numel(), self._stream()),
+                   'gnr_render_by_depth_fwd')
+        o['ray_mask'] = o['ray_mask'].bool()
+        return o
+
+    def time_chain_kernel(self, ref, res=40, iters=10):
+        """Average ms per launch of the dominant kernel (k_chain on the volume points), HIP events
+        recorded on the launch stream inside the library."""
+        scene, keep, ws = self.prepare(ref, res)
+        ms = C.c_float(0)
+        _lib.check(self.L.gnr_time_chain_kernel(C.byref(scene), res, self.wc.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                iters, C.byref(ms), self._stream()), 'gnr_time_chain_kernel')
+        return ms.value
+
+
+def batch_scenes(scenes):
+    """list of (ref, que) numpy dicts from synth.make_scene -> batched numpy dicts."""
+    ref = {k: np.stack([s[0][k] for s in scenes]) for k in scenes[0][0]}
+    que = {k: np.stack([s[1][k] for s in scenes]) for k in scenes[0][1]}
+    if 'imgs' in que:
+        que['imgs'] = que['imgs'][:, 0]
+    return ref, que

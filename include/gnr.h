@@ -1,0 +1,140 @@
+/* gnr.h -- C ABI of the MI355X-native GraspNeRF volumetric hot path (libgnr.so).
+ *
+ * Drop-in boundary for the reference's `NeuralRayRenderer.sample_volume` / `.render`
+ * (ref: src/nr/network/renderer.py:164-199, :201-220, :110-138) for a BATCH of scenes.
+ * Plain pointers and sizes only: every `const float*` below is a DEVICE pointer to
+ * contiguous fp32 unless the name says `_host`.  `stream` is a hipStream_t passed as void*.
+ * All entry points are stateless and return 0 (GNR_OK) or a negative error code; nothing
+ * throws across the ABI.  The caller owns every buffer, including the workspace.
+ *
+ * Typical call sequence (what graspnerf_amd/renderer.py does through ctypes):
+ *   gnr_pack_weights(canonical_host, packed_host)         once per load_state_dict, per level
+ *   gnr_workspace_bytes(&scene, R, rn, dn)                once per shape
+ *   gnr_prepare(&scene, ws, ws_bytes, stream)             per forward (feature-map repack)
+ *   gnr_sample_volume_fwd(...) / gnr_render_rays_fwd(...) per forward
+ */
+#ifndef GNR_H
+#define GNR_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNR_OK 0
+#define GNR_ERR_ARG (-1)       /* null pointer / bad enum                                   */
+#define GNR_ERR_SHAPE (-2)     /* unsupported V, dn, feature width ...                      */
+#define GNR_ERR_HIP (-3)       /* a HIP call or kernel launch failed                        */
+#define GNR_ERR_WORKSPACE (-4) /* workspace too small                                       */
+
+/* Reference views of B scenes.  Replaces the `ref_imgs_info` dict
+ * (ref: src/nr/utils/imgs_info.py:120, src/nr/main.py:228-242) after the 2D backbones
+ * (renderer.py:275-279) have produced img_feats / ray_feats. */
+typedef struct GnrScene {
+    int B, V;                 /* scenes, views per scene (V in 2..8)                        */
+    int H, W;                 /* image size                                                 */
+    int fh, fw;               /* feature-map size (reference: H/4, W/4)                     */
+    const float* imgs;        /* [B,V,3,H,W]  in [0,1]                                      */
+    const float* img_feats;   /* [B,V,32,fh,fw]  image_encoder output   (renderer.py:275)   */
+    const float* ray_feats;   /* [B,V,32,fh,fw]  vis_encoder output     (renderer.py:279)   */
+    const float* poses;       /* [B,V,3,4] world->camera, OpenCV                            */
+    const float* Ks;          /* [B,V,3,3]                                                  */
+    const float* depth_range; /* [B,V,2] near, far                                          */
+} GnrScene;
+
+/* Query rays of B scenes.  Replaces the `que_imgs_info` dict (imgs_info.py:126-135). */
+typedef struct GnrRays {
+    int rn;                   /* rays per scene                                             */
+    int dn;                   /* coarse samples per ray   (cfg depth_sample_num)            */
+    int fdn;                  /* fine samples per ray     (cfg fine_depth_sample_num)       */
+    int ray_mask_view_num;    /* cfg ray_mask_view_num  (renderer.py:37)                    */
+    int ray_mask_point_num;   /* cfg ray_mask_point_num (renderer.py:38)                    */
+    const float* coords;      /* [B,rn,2] pixel (x,y)                                       */
+    const float* que_pose;    /* [B,3,4]                                                    */
+    const float* que_K;       /* [B,3,3]                                                    */
+    const float* que_depth_range; /* [B,2]                                                  */
+    const float* que_imgs;    /* [B,3,H,W] or NULL (then pixel_colors_gt is not written)    */
+} GnrRays;
+
+/* Outputs of one render pass (coarse or fine).  Keys follow renderer.py:90-138; any
+ * pointer may be NULL to skip that output.  `dn` below = GnrRays.dn (coarse) / .fdn (fine). */
+typedef struct GnrRenderOut {
+    float* depth;              /* [B,rn,dn] sample depths used by this pass                 */
+    float* sdf_values;         /* [B,rn,dn]                                                 */
+    float* alpha_values;       /* [B,rn,dn]                                                 */
+    float* colors_nr;          /* [B,rn,dn,3]  (required: also an internal hand-off)        */
+    float* hit_prob_nr;        /* [B,rn,dn]                                                 */
+    float* pixel_colors_nr;    /* [B,rn,3]                                                  */
+    float* pixel_colors_gt;    /* [B,rn,3]                                                  */
+    float* render_depth;       /* [B,rn]                                                    */
+    unsigned char* ray_mask;   /* [B,rn] 0/1                                                */
+    float* sdf_gradient_error; /* [B]   mean((|grad|-1)^2) over the scene's rays            */
+    float* sdf_gradient;       /* [B,rn,dn,3] optional (debug / eikonal loss)               */
+    unsigned char* view_mask;  /* [B,rn,dn] optional: bit v = point inside view v's image   */
+} GnrRenderOut;
+
+/* ---- weights ---------------------------------------------------------------------------
+ * canonical blob = the parameters of ONE level (decoder + aggregation net) flattened and
+ * concatenated in reference state-dict order:
+ *   <dec>.mean_decoder.{0,2,4}.{weight,bias}, <dec>.var_decoder..., <dec>.aw_decoder...,
+ *   <agg>.prob_embed.{0,2}, <agg>.agg_impl.{ray_dir_fc,base_fc,vis_fc,vis_fc2,geometry_fc}.{0,2},
+ *   <agg>.agg_impl.ray_attention.{w_qs,w_ks,w_vs,fc}.weight, .layer_norm.{weight,bias},
+ *   <agg>.agg_impl.out_geometry_fc.{0,1}, .rgb_fc.{0,2,4}, .neuray_fc.{0,2},
+ *   <agg>.deviation_network.variance
+ * with <dec>,<agg> = dist_decoder,agg_net (coarse) or fine_dist_decoder,fine_agg_net (fine).
+ * (ref: dist_decoder.py:64-88, aggregate_net.py:29-33, ibrnet.py:382-423, neus.py:9)      */
+int gnr_canonical_weights_floats(void);   /* 36958 */
+int gnr_packed_weights_floats(void);
+int gnr_pack_weights(const float* canonical_host, float* packed_host);
+/* float offset of a named section of the packed blob (see csrc/gnr_layout.h), -1 if unknown */
+int gnr_layout_offset(const char* name);
+
+/* ---- workspace -------------------------------------------------------------------------*/
+size_t gnr_workspace_bytes(const GnrScene* scene, int volume_res, int rn, int dn_max);
+
+/* Repack img_feats/ray_feats to channel-last and build the per-view projection blocks.
+ * Must precede the forward calls that use the same workspace (stream ordered). */
+int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, void* stream);
+
+/* sample_volume (renderer.py:164-199), volume_type [sdf]:
+ *   sdf_out[b,x,y,z] for voxel centre bbox_min[b] + ((x,y,z)+.5)*(0.3/res).
+ *   view_mask_out: optional [B, res^3] bytes in (x,y,z) order, bit v = in-image mask of view v. */
+int gnr_sample_volume_fwd(const GnrScene* scene, const float* bbox_min /*[B,3]*/, int volume_res,
+                          const float* packed_coarse /*device*/, float* sdf_out /*[B,res,res,res]*/,
+                          unsigned char* view_mask_out, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* render_by_depth (renderer.py:110-138): one pass over given sample depths [B,rn,dn]
+ * (ascending along each ray).  `level_weights` = packed coarse or fine blob (device). */
+int gnr_render_by_depth_fwd(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn,
+                            const float* level_weights, GnrRenderOut* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* render (renderer.py:140-162, :201-220), eval mode: coarse pass on disparity-uniform
+ * depths, inverse-CDF fine resampling (render_ops.py:172-229) + sort, fine pass.
+ *   fine_depth_in : optional [B,rn,fdn]; when given it replaces the resampled depths
+ *   fine_inds_out : optional [B,rn,fdn] int32 searchsorted indices of the resampling      */
+int gnr_render_rays_fwd(const GnrScene* scene, const GnrRays* rays, const float* packed_coarse,
+                        const float* packed_fine, GnrRenderOut* coarse, GnrRenderOut* fine,
+                        const float* fine_depth_in, int* fine_inds_out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Bring-up aid: per-point intermediates of the chain kernel on the volume points (column order,
+ * top->down); dbg is [B*res^3][32] floats, layout documented at the definition (gnr_capi.inc). */
+int gnr_debug_volume_chain(const GnrScene* scene, const float* bbox_min, int volume_res,
+                           const float* packed_coarse, float* dbg, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ---- introspection / measurement -------------------------------------------------------*/
+/* name of the dominant kernel as it appears in rocprofv3 traces, and the last HIP error text */
+const char* gnr_dominant_kernel_name(void);
+const char* gnr_last_error(void);
+/* Time `iters` launches of the dominant kernel alone (volume points of `scene`) with HIP
+ * events on `stream`; returns average milliseconds per launch in *ms_out. */
+int gnr_time_chain_kernel(const GnrScene* scene, int volume_res, const float* packed_coarse,
+                          void* workspace, size_t workspace_bytes, int iters, float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNR_H */

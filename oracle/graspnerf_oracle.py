@@ -210,7 +210,7 @@ def weighted_mean_var(x, w):
 
 
 def aggregate(sd, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, rn, dn,
-              want_grad=True, want_rgb=True):
+              want_grad=True, want_rgb=True, debug=None):
     """Everything after the decoder for N = rn*dn points.
     f_ray/f_img [V,N,32], rgb [V,N,3], hit/vis/mask [V,N], dirv [V,N,3], qdir [N,3], pts [N,3].
     -> dict(sdf [rn,dn], grad [rn,dn,3] or None, rgb [rn,dn,3] or None)
@@ -271,6 +271,10 @@ def aggregate(sd, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, rn, d
         if want_grad:
             grad = torch.autograd.grad(sdf, p, torch.ones_like(sdf))[0].reshape(rn, dn, 3)
     out = {'sdf': sdf.detach(), 'grad': grad, 'rgb': None, 'nvalid': nvalid.reshape(rn, dn)}
+    if debug is not None:      # stage-by-stage intermediates for kernel bring-up (tests only)
+        debug.update(v2=v2[..., 0].detach(), msum=nvalid, wbar=wbar[:, 0].detach(), mean_f0=mean[:, 0].detach(),
+                     var_f0=var[:, 0].detach(), mean0_rgb0=mean0[:, 0].detach(), pre_f0=pre[:, 0].detach(),
+                     g_f0=g[:, 0].detach(), vsum=torch.sum(v2, 0)[:, 0].detach())
     if want_rgb:                                                          # ibrnet.py:506-512
         c = torch.cat([h, v2, dd], -1)
         c = F.elu(_lin(c, sd, a + 'rgb_fc.0'))
@@ -296,7 +300,7 @@ def sample_volume(sd, inp, res=40, dec='dist_decoder.', agg='agg_net.', debug=No
         hit, vis = decode_hit_vis(sd, dec, f_ray, z, mask, inp['depth_range'], 0.005, 0.005)
         qdir = torch.tensor([0., 0., 1.]).expand(pts.shape[0], 3)        # renderer.py:179
     o = aggregate(sd, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, res * res, res,
-                  want_grad=False, want_rgb=False)
+                  want_grad=False, want_rgb=False, debug=debug)
     if debug is not None:
         debug.update(mask=mask, uv=uv, z=z, hit=hit, vis=vis)
     vol = o['sdf'].reshape(1, 1, res, res, res)

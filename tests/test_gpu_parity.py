@@ -1,0 +1,155 @@
+"""Parity of the HIP hot path (through the C ABI, libgnr.so) against the CPU oracle and the
+golden vectors produced by the imported reference.  Needs a real MI355X:  pytest -m gpu
+
+Tolerances (BASELINE.json north_star): 1e-3 relative on SDF / alpha (we use
+|a-b| <= ATOL + RTOL*|b| with RTOL = 1e-3, ATOL = 2e-4 for quantities of O(1) magnitude);
+bit-exact on index-valued outputs (in-image view masks, ray masks, voxel index map, resampling
+indices away from cdf edges)."""
+import numpy as np
+import pytest
+import torch
+
+from graspnerf_amd import weights
+from graspnerf_amd.synth import make_scene, CONFIGS
+from oracle import graspnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-3, 2e-4
+DN = {'cfg1': 16, 'cfg2': 40}
+
+
+def close(a, b, what, rtol=RTOL, atol=ATOL):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64).reshape(a.shape)
+    assert not np.isnan(a).any(), f'{what}: NaN'
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert err.max() <= 0, f'{what}: max abs diff {np.abs(a - b).max():.3e} exceeds tolerance'
+
+
+@pytest.fixture(scope='module')
+def hot(weights_np):
+    from graspnerf_amd.hotpath import HotPath
+    return HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+
+
+@pytest.fixture(scope='module')
+def W(weights_np):
+    return {k: torch.from_numpy(v) for k, v in weights_np.items()}
+
+
+def _batched(name, seeds=(0,)):
+    from graspnerf_amd.hotpath import batch_scenes
+    scenes = [make_scene(s, name) for s in seeds]
+    return scenes, batch_scenes(scenes)
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2'])
+def test_volume_matches_reference_and_oracle(name, hot, W, golden):
+    G = golden(name)
+    res, V = CONFIGS[name]['res'], CONFIGS[name]['V']
+    scenes, (bref, bque) = _batched(name)
+    vol, vm = hot.sample_volume(bref, res, want_mask=True)
+    torch.cuda.synchronize()
+    vol = vol.cpu().numpy()
+    assert vol.shape == (1, 1, res, res, res)
+    close(vol[0], G['volume'][0], 'volume vs reference golden')
+    close(vol[0], O.sample_volume(W, O.to_torch(scenes[0][0]), res).numpy()[0], 'volume vs oracle')
+    # index-valued: per-view in-image masks, bit exact vs the reference (golden stores [V, column, top->down])
+    gm = np.unpackbits(G['volume_mask_bits']).reshape(V, res * res, res).astype(bool)
+    mine = vm.cpu().numpy()[0]
+    for v in range(V):
+        mv = ((mine >> v) & 1).astype(bool).reshape(res * res, res)[:, ::-1]
+        assert np.array_equal(mv, gm[v]), f'view {v} mask differs'
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2'])
+def test_render_matches_reference(name, hot, W, golden):
+    G = golden(name)
+    dn = DN[name]
+    cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn}
+    scenes, (bref, bque) = _batched(name)
+    # fine pass teacher-forced on the reference's resampled depths (inverse-CDF resampling is
+    # ill-conditioned where the coarse pdf ~ 0; see oracle.render docstring)
+    co, fi, inds = hot.render(bref, bque, cfg, fine_depth_in=G['fine_depth_sorted'][None], debug=True)
+    torch.cuda.synchronize()
+    for k in ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'pixel_colors_gt',
+              'render_depth', 'sdf_gradient_error']:
+        close(co[k].cpu().numpy(), G['render.' + k], 'coarse ' + k)
+        close(fi[k].cpu().numpy(), G['render.' + k + '_fine'], 'fine ' + k)
+    assert np.array_equal(co['ray_mask'].cpu().numpy(), G['render.ray_mask'])
+    assert np.array_equal(fi['ray_mask'].cpu().numpy(), G['render.ray_mask_fine'])
+    # resampling indices: exact except where u sits within float noise of a cdf edge
+    ii = inds.cpu().numpy()[0]
+    assert (ii != G['fine_inds']).mean() <= 2e-3
+    # SDF gradient (the in-forward VJP) against the oracle's autograd
+    dbo = {}
+    O.render(W, O.to_torch(scenes[0][0]), O.to_torch(scenes[0][1]), cfg, debug=dbo,
+             fine_depth_override=torch.from_numpy(G['fine_depth_sorted']))
+    close(co['sdf_gradient'].cpu().numpy()[0], dbo['coarse']['grad'].numpy(), 'coarse sdf gradient', atol=2e-3)
+    close(fi['sdf_gradient'].cpu().numpy()[0], dbo['fine']['grad'].numpy(), 'fine sdf gradient', atol=2e-3)
+
+
+def test_free_running_fine_depths(hot, golden):
+    """End to end (no teacher forcing): resampled depths agree with the reference except on the
+    ill-conditioned samples; sorted ascending; inside the depth range."""
+    G = golden('cfg2')
+    scenes, (bref, bque) = _batched('cfg2')
+    co, fi = hot.render(bref, bque, {})
+    torch.cuda.synchronize()
+    fd = fi['depth'].cpu().numpy()[0]
+    assert np.all(np.diff(fd, axis=1) >= 0)
+    assert fd.min() >= 0.2 - 1e-4 and fd.max() <= 0.8 + 1e-4
+    assert np.mean(np.abs(fd - G['fine_depth_sorted']) > 1e-3) < 0.02
+
+
+def test_batch_equals_per_scene(hot):
+    """Scenes are independent: a batched launch is bitwise the per-scene result."""
+    name = 'cfg1'
+    res, dn = CONFIGS[name]['res'], DN[name]
+    cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn}
+    scenes, (bref, bque) = _batched(name, seeds=(0, 1, 2))
+    vol = hot.sample_volume(bref, res).cpu().numpy()
+    co, fi = hot.render(bref, bque, cfg)
+    co = {k: v.cpu().numpy() for k, v in co.items()}
+    from graspnerf_amd.hotpath import batch_scenes
+    for i, sc in enumerate(scenes):
+        r1, q1 = batch_scenes([sc])
+        v1 = hot.sample_volume(r1, res).cpu().numpy()
+        assert np.array_equal(v1[0], vol[i])
+        c1, f1 = hot.render(r1, q1, cfg)
+        for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth'):
+            assert np.array_equal(c1[k].cpu().numpy()[0], co[k][i]), k
+
+
+def test_full_size_properties(hot):
+    """BASELINE config 3 shape (batch of 6-view 40^3 scenes): size-independent invariants."""
+    scenes, (bref, bque) = _batched('cfg2', seeds=(3, 4, 5, 6))
+    vol = hot.sample_volume(bref, 40).cpu().numpy()
+    assert vol.shape == (4, 1, 40, 40, 40) and np.isfinite(vol).all()
+    assert vol.min() >= -1.0 and vol.max() <= 1.0                      # clip(-1,1)  ibrnet.py:494
+    co, fi = hot.render(bref, bque, {})
+    for o in (co, fi):
+        a, h = o['alpha_values'].cpu().numpy(), o['hit_prob_nr'].cpu().numpy()
+        assert a.min() >= 0 and a.max() <= 1
+        assert h.min() >= 0 and h.sum(-1).max() <= 1 + 1e-4           # transmittance partition
+        # hit_k = alpha_k * prod_{j<k}(1 - alpha_j + 1e-10)  (render_ops.py:72-80), recomputed in float64
+        T = np.cumprod(np.concatenate([np.ones_like(a[..., :1]), 1 - a + 1e-10], -1).astype(np.float64), -1)[..., :-1]
+        np.testing.assert_allclose(h, a * T, rtol=1e-4, atol=1e-6)
+        z = o['depth'].cpu().numpy()
+        np.testing.assert_allclose(o['render_depth'].cpu().numpy(), (h * z).sum(-1), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(o['pixel_colors_nr'].cpu().numpy(), (h[..., None] * o['colors_nr'].cpu().numpy()).sum(-2),
+                                   rtol=1e-4, atol=1e-5)
+
+
+def test_error_codes(hot):
+    """The ABI reports bad shapes / tiny workspaces instead of crashing."""
+    import ctypes as C
+    from graspnerf_amd import _lib
+    scenes, (bref, bque) = _batched('cfg1')
+    scene, keep, ws = hot.prepare(bref, 16)
+    bad = _lib.GnrScene(scene.B, 7, scene.H, scene.W, scene.fh, scene.fw, scene.imgs, scene.img_feats, scene.ray_feats,
+                        scene.poses, scene.Ks, scene.depth_range)
+    assert hot.L.gnr_prepare(C.byref(bad), ws.data_ptr(), ws.numel(), None) == -2
+    assert hot.L.gnr_prepare(C.byref(scene), ws.data_ptr(), 16, None) == -4
+    assert hot.L.gnr_prepare(C.byref(scene), None, 0, None) == -1

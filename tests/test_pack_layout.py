@@ -1,0 +1,219 @@
+"""CPU checks of the C-ABI library that need no GPU:
+  * libgnr.so loads and exports every symbol include/gnr.h declares,
+  * the weight packer's MFMA A-fragment layout: every layer is emulated in numpy with the ISA
+    lane mapping of v_mfma_f32_16x16x4_f32 (A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+    D[i=4*(l>>4)+t][j=l&15]) and compared with the dense  W x + b  of the reference layer.
+The feature layouts (phi/psi) are re-derived here independently from gnr_layout.h's prose."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from graspnerf_amd import _lib, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_header_symbols():
+    hdr = open(os.path.join(ROOT, 'include', 'gnr.h')).read()
+    declared = set(re.findall(r'\b(gnr_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f'libgnr.so does not export {name}'
+    assert set(_lib.EXPORTED) <= declared
+
+
+def off(name):
+    o = _lib.lib().gnr_layout_offset(name.encode())
+    assert o >= 0, name
+    return o
+
+
+# ---- numpy emulation of one chained-MFMA layer on a 16-point tile ---------------------------
+def frag_lane(packed, base, J, NB, j, nb, lane):
+    if NB == 1:
+        return packed[base + ((j // 4) * 64 + lane) * 4 + (j % 4)]
+    if NB == 3:
+        return packed[base + (j * 64 + lane) * 4 + nb]
+    return packed[base + (j * 64 + lane) * NB + nb]
+
+
+def emulate(packed, base, J, NB, B_in, acc=None):
+    """B_in[j][lane] -> acc[nb][t][lane] following the MFMA semantics."""
+    lanes = np.arange(64)
+    out = np.zeros((NB, 4, 64), np.float64) if acc is None else acc.astype(np.float64).copy()
+    for j in range(J):
+        for nb in range(NB):
+            A = np.array([frag_lane(packed, base, J, NB, j, nb, l) for l in lanes], np.float64)   # A[i][k] @ lane i+16k
+            Bm = B_in[j].astype(np.float64)                                                    # B[k][col] @ lane col+16k
+            for t in range(4):
+                for l in lanes:
+                    i, col = 4 * (l >> 4) + t, l & 15
+                    out[nb, t, l] += sum(A[i + 16 * k] * Bm[col + 16 * k] for k in range(4))
+    return out
+
+
+def nat(j, g):
+    return 16 * (j // 4) + 4 * g + (j % 4)
+
+
+def xfeat(j, g):
+    return 3 + 8 * g + j if j < 8 else (g if g < 3 else -1)
+
+
+def to_B(x, J, phi):
+    """x[point r][feature] -> B_in[j][lane] with lane=(r,g)."""
+    B = np.zeros((J, 64), np.float32)
+    for j in range(J):
+        for l in range(64):
+            f = phi(j, l >> 4)
+            B[j, l] = x[l & 15, f] if f >= 0 else 0.0
+    return B
+
+
+def from_D(acc, NB, psi, nout):
+    """acc[nb][t][lane] -> y[point][feature]."""
+    y = np.full((16, nout), np.nan)
+    for nb in range(NB):
+        for t in range(4):
+            for l in range(64):
+                o = psi(nb, 4 * (l >> 4) + t)
+                if o >= 0:
+                    y[l & 15, o] = acc[nb, t, l]
+                else:
+                    assert acc[nb, t, l] == 0.0        # padded rows stay exactly zero
+    assert not np.isnan(y).any()
+    return y
+
+
+def bias_acc(packed, boff, NB):
+    acc = np.zeros((NB, 4, 64))
+    for nb in range(NB):
+        for l in range(64):
+            for t in range(4):
+                acc[nb, t, l] = packed[boff + nb * 16 + 4 * (l >> 4) + t]
+    return acc
+
+
+@pytest.fixture(scope='module')
+def packed_and_sd(weights_np):
+    can = weights.canonical_blob(weights_np, 'coarse')
+    return weights.pack(can), weights_np
+
+
+LAYERS = [
+    # name, frag, bias, J, NB, key, phi(j,g) -> input idx, psi(nb,i) -> output idx, n_in, n_out
+    ('dec1_var', ('DEC1', 1024), ('B_DEC1', 32), 8, 2, 'dist_decoder.var_decoder.0', lambda j, g: 8 * g + j, lambda nb, i: 16 * nb + i),
+    ('dec2_aw', ('DEC2', 2048), ('B_DEC2', 64), 8, 2, 'dist_decoder.aw_decoder.2', nat, lambda nb, i: 16 * nb + i),
+    ('pe1', ('PE1', 0), ('B_PE1', 0), 9, 2, 'agg_net.prob_embed.0',
+     lambda j, g: 8 * g + j if j < 8 else (32 if g == 0 else (33 if g == 1 else -1)), lambda nb, i: 16 * nb + i),
+    ('pe2', ('PE2', 0), ('B_PE2', 0), 8, 2, 'agg_net.prob_embed.2', nat, lambda nb, i: 16 * nb + i),
+    ('rdf1', ('RDF1', 0), ('B_RDF1', 0), 1, 1, 'agg_net.agg_impl.ray_dir_fc.0', lambda j, g: g, lambda nb, i: i),
+    ('rdf2', ('RDF2', 0), ('B_RDF2', 0), 4, 3, 'agg_net.agg_impl.ray_dir_fc.2', nat,
+     lambda nb, i: (3 + 8 * (i >> 2) + (i & 3)) if nb == 0 else ((3 + 8 * (i >> 2) + 4 + (i & 3)) if nb == 1 else
+                                                                 ((i >> 2) if (i & 3) == 0 and (i >> 2) < 3 else -1))),
+    ('nr1', ('NR1', 0), ('B_NR1', 0), 8, 1, 'agg_net.agg_impl.neuray_fc.0', nat, lambda nb, i: i if i < 8 else -1),
+    ('base2', ('BASE2', 0), ('B_BASE2', 0), 16, 2, 'agg_net.agg_impl.base_fc.2', nat, lambda nb, i: 16 * nb + i),
+    ('vis1', ('VIS1', 0), ('B_VIS1', 0), 8, 2, 'agg_net.agg_impl.vis_fc.0', nat, lambda nb, i: 16 * nb + i),
+    ('visb1', ('VISB1', 0), ('B_VISB1', 0), 8, 2, 'agg_net.agg_impl.vis_fc2.0', nat, lambda nb, i: 16 * nb + i),
+    ('rgb1', ('RGB1', 0), ('B_RGB1', 0), 10, 1, 'agg_net.agg_impl.rgb_fc.0',
+     lambda j, g: nat(j, g) if j < 8 else ((32 if g == 0 else 32 + g) if j == 8 else (36 if g == 0 else -1)), lambda nb, i: i),
+    ('rgb2', ('RGB2', 0), ('B_RGB2', 0), 4, 1, 'agg_net.agg_impl.rgb_fc.2', nat, lambda nb, i: i if i < 8 else -1),
+    ('geo1', ('GEO1', 0), ('B_GEO1', 0), 23, 4, 'agg_net.agg_impl.geometry_fc.0',
+     lambda j, g: nat(j, g) if j < 8 else (32 + nat(j - 8, g) if j < 16 else
+                                           ((64 if j == 16 else -1) if g == 0 else 65 + 3 * (j - 16) + (g - 1))),
+     lambda nb, i: 16 * nb + i),
+    ('geo2', ('GEO2', 0), ('B_GEO2', 0), 16, 1, 'agg_net.agg_impl.geometry_fc.2', nat, lambda nb, i: i),
+]
+
+
+@pytest.mark.parametrize('spec', LAYERS, ids=[l[0] for l in LAYERS])
+def test_layer_fragments(spec, packed_and_sd):
+    packed, sd = packed_and_sd
+    name, (fname, fadd), (bname, badd), J, NB, key, phi, psi = spec
+    W, b = sd[key + '.weight'], sd[key + '.bias']
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((16, W.shape[1])).astype(np.float32)
+    acc = emulate(packed, off(fname) + fadd, J, NB, to_B(x, J, phi), bias_acc(packed, off(bname) + badd, NB))
+    y = from_D(acc, NB, psi, W.shape[0])
+    np.testing.assert_allclose(y, x.astype(np.float64) @ W.T.astype(np.float64) + b, rtol=1e-5, atol=1e-5)
+
+
+def test_base_fc0_split(packed_and_sd):
+    """HOIST (140 view-invariant columns + bias) + BASE1 (x 35, e 32) == base_fc.0 on the 207-wide concat."""
+    packed, sd = packed_and_sd
+    W, b = sd['agg_net.agg_impl.base_fc.0.weight'], sd['agg_net.agg_impl.base_fc.0.bias']
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((16, 207)).astype(np.float32)
+    B_h = to_B(z, 36, lambda j, g: (35 * (j // 9) + xfeat(j % 9, g)) if xfeat(j % 9, g) >= 0 else -1)
+    G = emulate(packed, off('HOIST'), 36, 4, B_h, bias_acc(packed, off('B_HOIST'), 4))
+    B_v = to_B(z, 17, lambda j, g: ((140 + xfeat(j, g)) if xfeat(j, g) >= 0 else -1) if j < 9 else 175 + nat(j - 9, g))
+    acc = emulate(packed, off('BASE1'), 17, 4, B_v, G)
+    y = from_D(acc, 4, lambda nb, i: 16 * nb + i, 64)
+    np.testing.assert_allclose(y, z.astype(np.float64) @ W.T.astype(np.float64) + b, rtol=1e-5, atol=1e-5)
+
+
+def test_vis_fc2_rows_and_tables(packed_and_sd):
+    """vis_fc.2: rows 0..31 via MFMA fragments, row 32 via the per-group VALU table; the other
+    1-row layers (decoder .4, neuray_fc.2, vis_fc2.2, rgb_fc.4) likewise."""
+    packed, sd = packed_and_sd
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal((16, 32)).astype(np.float32)
+
+    def table_dot(toff, J, x, width):
+        # lane (r,g) holds x[r][nat(j,g)] for j<J ; table T[g][j]; sum over the 4 groups
+        out = np.zeros(16)
+        for r in range(16):
+            for g in range(4):
+                for j in range(J):
+                    f = nat(j, g)
+                    out[r] += packed[toff + g * J + j] * (x[r, f] if f < width else 0.0)
+        return out
+
+    W, b = sd['agg_net.agg_impl.vis_fc.2.weight'], sd['agg_net.agg_impl.vis_fc.2.bias']
+    acc = emulate(packed, off('VIS2'), 8, 2, to_B(h, 8, nat), bias_acc(packed, off('B_VIS2'), 2))
+    np.testing.assert_allclose(from_D(acc, 2, lambda nb, i: 16 * nb + i, 32), h @ W[:32].T + b[:32], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(table_dot(off('T_VIS2R'), 8, h, 32) + packed[off('T_SCAL') + 1], h @ W[32] + b[32], rtol=1e-5, atol=1e-5)
+    W2, b2 = sd['agg_net.agg_impl.vis_fc2.2.weight'], sd['agg_net.agg_impl.vis_fc2.2.bias']
+    np.testing.assert_allclose(table_dot(off('T_VISB2'), 8, h, 32) + packed[off('T_SCAL') + 2], h @ W2[0] + b2[0], rtol=1e-5, atol=1e-5)
+    # decoder heads: order mean0 mean1 var0 var1 aw
+    rows = [('mean_decoder', 0), ('mean_decoder', 1), ('var_decoder', 0), ('var_decoder', 1), ('aw_decoder', 0)]
+    for o, (br, k) in enumerate(rows):
+        Wd, bd = sd[f'dist_decoder.{br}.4.weight'], sd[f'dist_decoder.{br}.4.bias']
+        np.testing.assert_allclose(table_dot(off('T_DEC3') + o * 32, 8, h, 32) + packed[off('T_DEC3_B') + o],
+                                   h @ Wd[k] + bd[k], rtol=1e-5, atol=1e-5)
+    # 8-wide inputs living on groups 0,1 (rows 0..7 of a 16-row block): neuray_fc.2, rgb_fc.4
+    h8 = np.zeros((16, 16), np.float32)
+    h8[:, :8] = rng.standard_normal((16, 8))
+    for tname, sidx, key in (('T_NR2', 0, 'agg_net.agg_impl.neuray_fc.2'), ('T_RGB3', 3, 'agg_net.agg_impl.rgb_fc.4')):
+        Wr, br_ = sd[key + '.weight'], sd[key + '.bias']
+        got = np.zeros(16)
+        for r in range(16):
+            for g in range(4):
+                for t in range(4):
+                    got[r] += packed[off(tname) + g * 4 + t] * h8[r, 4 * g + t]
+        np.testing.assert_allclose(got + packed[off('T_SCAL') + sidx], h8[:, :8] @ Wr[0] + br_[0], rtol=1e-5, atol=1e-5)
+
+
+def test_ray_section(packed_and_sd):
+    packed, sd = packed_and_sd
+    a = 'agg_net.agg_impl.'
+    np.testing.assert_array_equal(packed[off('R_WQ'):off('R_WQ') + 256].reshape(16, 16), sd[a + 'ray_attention.w_qs.weight'])
+    np.testing.assert_array_equal(packed[off('R_WFC'):off('R_WFC') + 256].reshape(16, 16), sd[a + 'ray_attention.fc.weight'])
+    np.testing.assert_array_equal(packed[off('R_GEO2W'):off('R_GEO2W') + 1024].reshape(16, 64), sd[a + 'geometry_fc.2.weight'])
+    e = packed[off('R_GEO1E'):off('R_GEO1E') + 64 * 24].reshape(64, 24)[:, :21]
+    np.testing.assert_array_equal(e, sd[a + 'geometry_fc.0.weight'][:, 65:86])
+    assert packed[off('R_VARIANCE')] == sd['agg_net.deviation_network.variance']
+    from oracle.graspnerf_oracle import sinusoid_table
+    np.testing.assert_allclose(packed[off('R_PE'):off('R_PE') + 40 * 16].reshape(40, 16), sinusoid_table(40).numpy(), atol=1e-7)
+
+
+def test_pack_rejects_bad_input():
+    L = _lib.lib()
+    assert L.gnr_pack_weights(None, None) == -1
+    with pytest.raises(ValueError):
+        weights.pack(np.zeros(10, np.float32))
+    assert L.gnr_layout_offset(b'NOPE') == -1
