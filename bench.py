@@ -1,0 +1,151 @@
+"""Benchmark of the MI355X-native GraspNeRF volumetric hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one forward pass of the hot path over a batch of B synthetic scenes per GPU with all
+inputs already resident in HBM: feature-map repack (gnr_prepare) + TSDF volume (sample_volume,
+40^3) + ray rendering (512 rays, 40 coarse + 40 fine samples), 6 views of 288x512.  Scenes are
+independent, so N GPUs shard scenes with no data-path collective (weak scaling: B scenes per GPU).
+Rank 0 prints ONE JSON line (see README / DESIGN.md §Measurement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from graspnerf_amd import weights                        # noqa: E402
+from graspnerf_amd.synth import make_scene, CONFIGS       # noqa: E402
+
+METRIC = 'scenes/sec TSDF+render fwd, 6-view 40^3 grid'
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# algorithmic (un-hoisted) MACs per (view, point) and per point executed by k_chain
+MAC_VIEW_VOL, MAC_VIEW_RAY, MAC_POINT_CHAIN = 27736, 28464, 6528
+
+
+def chain_flops(points, views, render):
+    return 2.0 * points * (views * (MAC_VIEW_RAY if render else MAC_VIEW_VOL) + MAC_POINT_CHAIN)
+
+
+def cpu_baseline(weights_np, budget_s=25.0):
+    """The oracle (torch-CPU fp32 port of the reference path) timed on this box's host cores on a
+    bounded sample: whole scenes of the same workload (volume + 512-ray render)."""
+    from oracle import graspnerf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    W = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    ref, que = make_scene(0, 'cfg2')
+    inp, q = O.to_torch(ref), O.to_torch(que)
+
+    def one():
+        O.sample_volume(W, inp, 40)
+        O.render(W, inp, q)
+    one()                                  # warm-up (allocator, thread pool)
+    t0 = time.time()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 3:
+            break
+    dt = (time.time() - t0) / n
+    return {'value': round(1.0 / dt, 4), 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} whole scene(s) after 1 warm-up: 6 views 288x512, 40^3 volume + 512 rays x (40+40) samples, '
+                      f'oracle/graspnerf_oracle.py (torch {torch.__version__} CPU fp32)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='scenes per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})')
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a ROCm GPU; the hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    wnp = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'weights_seed0.npz')))
+    hp = HotPath(weights.pack_state_dict(wnp, 'coarse'), weights.pack_state_dict(wnp, 'fine'), device=f'cuda:{local}')
+    B = args.batch
+    c = CONFIGS['cfg2']
+    scenes = [make_scene(rank * B + i, 'cfg2', with_query_image=False) for i in range(B)]
+    bref, bque = batch_scenes(scenes)
+    dev = hp.device
+    bref = {k: torch.from_numpy(v).to(dev) for k, v in bref.items()}          # inputs resident in HBM
+    bque = {k: torch.from_numpy(v).to(dev) for k, v in bque.items()}
+    res, rn, dn = c['res'], c['rn'], 40
+
+    def step():
+        prep = hp.prepare(bref, res, rn, dn)
+        vol = hp.sample_volume(bref, res, prepared=prep)
+        co, fi = hp.render(bref, bque, prepared=prep)
+        return vol, fi
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # dominant kernel, timed alone with HIP events on its launch stream (inside libgnr.so)
+        ms = hp.time_chain_kernel(bref, res, iters=10)
+        fl = chain_flops(B * res ** 3, c['V'], render=False)
+        achieved = fl / (ms * 1e-3) / 1e12
+        out = {
+            'metric': METRIC, 'value': round(world * B * args.steps / dt, 3), 'unit': 'scenes/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{B} scenes/GPU/step, 6 views 288x512 (feature maps 72x128x32 x2), 40^3 TSDF volume + '
+                                   f'512 rays x (40 coarse + 40 fine) samples, forward only, inputs resident in HBM '
+                                   f'(BASELINE.json configs[2]/[3])',
+                       'global_batch': world * B, 'parallelism': f'scene-sharded x{world}, no data-path collective'},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'k_chain<6,false> on the volume points', 'ms_per_launch': round(ms, 4),
+                         'flops_per_launch': fl,
+                         'note': 'algorithmic (un-hoisted) fp32 FLOPs: 2*(6*27736+6528) per point, SURVEY.md §8d'},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wnp)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
