@@ -27,12 +27,21 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define DEV __device__ __forceinline__
 
 DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-DEV float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
-DEV float sigmoid1(float x) { return 1.f / (1.f + __expf(-x)); }
-DEV float softplus1(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+// fp32-input MFMA and fp32 VALU share the SIMD's FMA datapath on gfx950 (tools/ubench/mfma_valu.hip:
+// MFMA-only 1.23 ms + VALU-only 0.93 ms = 2.03 ms when issued by partner waves of one SIMD), so every
+// VALU instruction of the chain costs throughput: activations are written for minimum instruction count.
+// ELU(x) = med3(x, e^x - 1, 0): for x > 0 the order is 0 < x <= e^x-1, for x <= 0 it is x <= e^x-1 <= 0.
+DEV float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+// scaled form used inside the MFMA chain: input x' = log2e*x (the packer folds log2e into the producing
+// layer), output log2e*ELU(x) (divided out of the consumer's weights): 3 VALU ops per activation.
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+DEV float elu_s(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), kLog2e, -kLog2e), 0.f); }
+DEV float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV float sigmoid1(float x) { return rcp1(1.f + __expf(-x)); }
+// softplus = max(x,0) + log(1 + e^-|x|)   (== torch's threshold-20 form to fp32 rounding)
+DEV float softplus1(float x) { return fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x))); }
 DEV float tanh1(float x) {            // 1 - 2/(e^{2x}+1); saturates cleanly to +-1
-    const float e = __expf(2.f * x);
-    return 1.f - 2.f / (e + 1.f);
+    return 1.f - 2.f * rcp1(__expf(2.f * x) + 1.f);
 }
 // sum over the 4 lane groups (lanes l, l^16, l^32, l^48); identical bits on all four
 DEV float gsum(float x) {
@@ -95,10 +104,10 @@ template <int NB>
 DEV void elu_to(const f4 (&acc)[NB], float (&out)[NB * 4]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        out[nb * 4 + 0] = elu1(acc[nb].x);
-        out[nb * 4 + 1] = elu1(acc[nb].y);
-        out[nb * 4 + 2] = elu1(acc[nb].z);
-        out[nb * 4 + 3] = elu1(acc[nb].w);
+        out[nb * 4 + 0] = elu_s(acc[nb].x);
+        out[nb * 4 + 1] = elu_s(acc[nb].y);
+        out[nb * 4 + 2] = elu_s(acc[nb].z);
+        out[nb * 4 + 3] = elu_s(acc[nb].w);
     }
 }
 
@@ -159,7 +168,8 @@ __global__ void k_view_setup(const float* __restrict__ poses, const float* __res
     const float nr = -1.f / dr[i * 2], fr = -1.f / dr[i * 2 + 1];
     o[15] = nr;
     o[16] = fr - nr;
-    for (int c = 17; c < VIEWP_FLOATS; ++c) o[c] = 0.f;
+    o[17] = 1.f / (fr - nr);
+    for (int c = 18; c < VIEWP_FLOATS; ++c) o[c] = 0.f;
 }
 
 // ref: field_utils.py:17-27 (float64 arithmetic then cast), renderer.py:167-170,179
@@ -272,8 +282,8 @@ DEV void project_view(const float* __restrict__ vp, const float (&p)[3], const f
     o.m = (!inval && !outside) ? 1.f : 0.f;
     if constexpr (FULL) {
         float d[3] = {p[0] - vp[12], p[1] - vp[13], p[2] - vp[14]};
-        const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-5f);
-        const float inr = -1.f / nrm;
+        // -1 / max(|d|, 1e-5)
+        const float inr = -__builtin_amdgcn_rsqf(fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f));
         d[0] *= inr; d[1] *= inr; d[2] *= inr;
         o.dd[0] = d[0] - qd[0]; o.dd[1] = d[1] - qd[1]; o.dd[2] = d[2] - qd[2];     // aggregate_net.py:13
         o.dd[3] = d[0] * qd[0] + d[1] * qd[1] + d[2] * qd[2];                       // :14
@@ -281,12 +291,11 @@ DEV void project_view(const float* __restrict__ vp, const float (&p)[3], const f
 }
 
 struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
-// bilinear, border padding.  ref: ops.py:29-33 + grid_sample; see oracle bilinear_border
-DEV Taps make_taps(float u, float v, int H, int W, int fh, int fw, bool same_res) {
-    const float xn = u / (float)(W - 1) * 2.f - 1.f, yn = v / (float)(H - 1) * 2.f - 1.f;
-    float px, py;
-    if (same_res) { px = (xn + 1.f) * 0.5f * (float)(fw - 1); py = (yn + 1.f) * 0.5f * (float)(fh - 1); }
-    else { px = ((xn + 1.f) * (float)fw - 1.f) * 0.5f; py = ((yn + 1.f) * (float)fh - 1.f) * 0.5f; }
+// bilinear, border padding.  ref: ops.py:29-33 + grid_sample (see oracle bilinear_border).
+//   feature map (align_corners False): px = u*fw/(W-1) - 0.5 ; full-res image (align_corners True): px = u
+// (the reference's normalise/unnormalise round trip, folded; differs from it by fp32 rounding only)
+DEV Taps make_taps(float u, float v, float sx, float sy, float off, int fh, int fw) {
+    float px = fmaf(u, sx, off), py = fmaf(v, sy, off);
     px = fminf(fmaxf(px, 0.f), (float)(fw - 1));
     py = fminf(fmaxf(py, 0.f), (float)(fh - 1));
     const float x0 = floorf(px), y0 = floorf(py);
@@ -319,6 +328,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
     const int tps = (a.P + 15) >> 4;                       // tiles per scene
     const int ntiles = a.B * tps;
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
+    const float fsx = (float)a.fw / (float)(a.W - 1), fsy = (float)a.fh / (float)(a.H - 1);
 
     for (int tile = blockIdx.x * waves_per_block + wave; tile < ntiles; tile += gridDim.x * waves_per_block) {
         const int b = tile / tps;
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
             // ---- gather: ray channels 8g..8g+7, image-feature channels 8g..8g+7, rgb channel g
             float FR[8], XI[9];
             {
-                const Taps t = make_taps(vg.u, vg.v, a.H, a.W, a.fh, a.fw, false);
+                const Taps t = make_taps(vg.u, vg.v, fsx, fsy, -0.5f, a.fh, a.fw);
                 const float* fb = a.feat64 + (size_t)bv * a.fh * a.fw * 64 + 8 * g;
                 const f4* q00 = reinterpret_cast<const f4*>(fb + (size_t)t.o00 * 64);
                 const f4* q01 = reinterpret_cast<const f4*>(fb + (size_t)t.o01 * 64);
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                     FR[4 * h] = fr.x; FR[4 * h + 1] = fr.y; FR[4 * h + 2] = fr.z; FR[4 * h + 3] = fr.w;
                     XI[4 * h] = fi.x; XI[4 * h + 1] = fi.y; XI[4 * h + 2] = fi.z; XI[4 * h + 3] = fi.w;
                 }
-                const Taps ti = make_taps(vg.u, vg.v, a.H, a.W, a.H, a.W, true);
+                const Taps ti = make_taps(vg.u, vg.v, 1.f, 1.f, 0.f, a.H, a.W);
                 const float* ib = a.imgs + ((size_t)bv * 3 + min(g, 2)) * a.H * a.W;
                 const float rgb = (ib[ti.o00] * ti.w00 + ib[ti.o01] * ti.w01 + ib[ti.o10] * ti.w10 + ib[ti.o11] * ti.w11) * m;
                 XI[8] = g < 3 ? rgb : 0.f;
@@ -404,8 +414,8 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                 const float mean0 = softplus1(o5[0]), mean1 = softplus1(o5[1]);
                 const float var0 = softplus1(o5[2]) + 0.05f, var1 = softplus1(o5[3]) + 0.05f;
                 const float aw = sigmoid1(o5[4]);
-                const float dinv = -1.f / fmaxf(vg.z, 1e-5f);                 // dist_decoder.py:21-23
-                const float dhat = (dinv - vp[15]) / vp[16];
+                const float dinv = -rcp1(fmaxf(vg.z, 1e-5f));                 // dist_decoder.py:21-23
+                const float dhat = (dinv - vp[15]) * vp[17];
                 const float nearv = dhat - lo, farv = dhat + hi;
                 const float c00 = 0.5f + 0.5f * tanh1((nearv - mean0) * var0), c01 = 0.5f + 0.5f * tanh1((nearv - mean1) * var1);
                 const float c10 = 0.5f + 0.5f * tanh1((farv - mean0) * var0), c11 = 0.5f + 0.5f * tanh1((farv - mean1) * var1);
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                 mm<4, 3>(lds + pk::RDF2, lane, d1, acc3);
                 elu_to<3>(acc3, df);
 #pragma unroll
-                for (int j = 0; j < 9; ++j) S[V - 1][j] = XI[j] + df[j];
+                for (int j = 0; j < 9; ++j) S[V - 1][j] = fmaf(df[j], kLn2, XI[j]);
             }
             // ---- gate of the first weighted mean/var: sigmoid(neuray_fc(e))  (ibrnet.py:469)
             {
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
 
         // ================= cross-view reduction 1 (ibrnet.py:466-472), in-lane
         float SV[36];
-        const float inv_msum = 1.f / (msum + 1e-8f);
+        const float inv_msum = rcp1(msum + 1e-8f);
         {
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
         float Z[23];
         float wbar = 0.f;
         {
-            const float inv_vsum = 1.f / (vsum + 1e-8f);
+            const float inv_vsum = rcp1(vsum + 1e-8f);
 #pragma unroll
             for (int v = 0; v < V; ++v) wbar += S[v][8] * inv_vsum;
             wbar *= (1.f / (float)V);
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
             float den = 0.f, num = 0.f;
 #pragma unroll
             for (int v = 0; v < V; ++v) { const float e = __expf(S[v][9] - cmax); den += e; num += S[v][10] * e; }
-            if (g < 3 && row_ok) a.colors[pt * 3 + g] = num / den;
+            if (g < 3 && row_ok) a.colors[pt * 3 + g] = num * rcp1(den);
         }
         // ================= geometry_fc on [mean, var, wbar, embed(p)]  (ibrnet.py:487-489)
         {
@@ -625,12 +635,12 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
         // ================= record
         if (row_ok) {
             float* rec = a.rec + pt * REC;
-            const f4 gv = {gg[0], gg[1], gg[2], gg[3]};
+            const f4 gv = {gg[0] * kLn2, gg[1] * kLn2, gg[2] * kLn2, gg[3] * kLn2};    // back to true scale
             reinterpret_cast<f4*>(rec)[g] = gv;
             if constexpr (RENDER) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    const f4 uv = {u64[nb * 4], u64[nb * 4 + 1], u64[nb * 4 + 2], u64[nb * 4 + 3]};
+                    const f4 uv = {u64[nb * 4] * kLn2, u64[nb * 4 + 1] * kLn2, u64[nb * 4 + 2] * kLn2, u64[nb * 4 + 3] * kLn2};
                     reinterpret_cast<f4*>(rec + 16 + 16 * nb)[g] = uv;
                 }
                 if (g == 0) rec[80] = msum;
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
             if (a.vmask && g == 0) a.vmask[pt] = (unsigned char)vbits;
             if (a.dbg && g == 0) {
                 float* d = a.dbg + pt * 32;
-                d[24] = msum; d[25] = wbar; d[26] = Z[0]; d[27] = Z[8]; d[28] = SV[8]; d[29] = G[0].x; d[30] = gg[0]; d[31] = vsum;
+                d[24] = msum; d[25] = wbar; d[26] = Z[0] * kLn2; d[27] = Z[8] * kLn2 * kLn2; d[28] = SV[8]; d[29] = G[0].x * kLn2; d[30] = gg[0] * kLn2; d[31] = vsum;
             }
         }
     }

@@ -119,7 +119,7 @@ constexpr int TOTAL = R_PE + 64 * 16;
 //   reference views' normalised inverse depth; ref: dist_decoder.py:34-49)
 constexpr int DESC_FLOATS = 8;
 // per-view parameter block (k_view_setup -> k_chain): 24 floats
-//   [0..11] H = K*[R|t] row-major 3x4, [12..14] camera centre, [15] -1/near, [16] (-1/far)-(-1/near)
+//   [0..11] H = K*[R|t] row-major 3x4, [12..14] camera centre, [15] -1/near, [16] (-1/far)-(-1/near), [17] 1/[16]
 constexpr int VIEWP_FLOATS = 24;
 // per-point record (k_chain -> k_ray)
 constexpr int REC_VOL = 20;     // g16[16], nvalid, pad

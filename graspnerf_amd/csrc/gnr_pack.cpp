@@ -18,14 +18,24 @@ inline int nat_out(int nb, int i) { return 16 * nb + i; }
 // layout of the 35-wide colour feature x = [r,g,b, img_feats(32)] in 9 slots
 inline int xfeat(int j, int g) { return j < 8 ? 3 + 8 * g + j : (g < 3 ? g : -1); }
 
-// frag[(j,nb,lane)] = W[psi(nb, lane&15)][phi(j, lane>>4)]
-void pack_frag(float* dst, const float* W, int ldw, int J, int NB, const IdxFn& phi, const IdxFn& psi) {
+// Scaled-ELU convention (saves one VALU multiply per activation in k_chain): a layer that feeds an
+// ELU emits x' = log2(e) * (W x + b), the kernel computes u~ = med3(x', log2e*(2^x' - 1), 0) = log2e * ELU(x),
+// and every consumer of u~ has the factor divided out of its weight columns.  `oscale` multiplies the
+// rows (and bias), `iscale(i)` is the factor carried by logical input i (weights are divided by it).
+using ScaleFn = std::function<double(int)>;
+constexpr double LOG2E = 1.4426950408889634;
+const ScaleFn kTrue = [](int) { return 1.0; };
+const ScaleFn kTilde = [](int) { return LOG2E; };
+
+// frag[(j,nb,lane)] = oscale * W[psi(nb, lane&15)][phi(j, lane>>4)] / iscale(phi)
+void pack_frag(float* dst, const float* W, int ldw, int J, int NB, const IdxFn& phi, const IdxFn& psi,
+               double oscale = 1.0, const ScaleFn& iscale = kTrue) {
     std::memset(dst, 0, sizeof(float) * frag_floats(J, NB));
     for (int j = 0; j < J; ++j)
         for (int nb = 0; nb < NB; ++nb)
             for (int lane = 0; lane < 64; ++lane) {
                 const int o = psi(nb, lane & 15), i = phi(j, lane >> 4);
-                const float v = (o >= 0 && i >= 0) ? W[o * ldw + i] : 0.f;
+                const float v = (o >= 0 && i >= 0) ? (float)((double)W[o * ldw + i] * oscale / iscale(i)) : 0.f;
                 int idx;
                 if (NB == 1) idx = ((j / 4) * 64 + lane) * 4 + (j % 4);
                 else if (NB == 3) idx = (j * 64 + lane) * 4 + nb;
@@ -34,21 +44,18 @@ void pack_frag(float* dst, const float* W, int ldw, int J, int NB, const IdxFn& 
             }
 }
 
-void pack_bias(float* dst, const float* b, int NB, const IdxFn& psi) {
+void pack_bias(float* dst, const float* b, int NB, const IdxFn& psi, double oscale = 1.0) {
     for (int nb = 0; nb < NB; ++nb)
         for (int i = 0; i < 16; ++i) {
             const int o = psi(nb, i);
-            dst[nb * 16 + i] = o >= 0 ? b[o] : 0.f;   // i = 4g + reg
+            dst[nb * 16 + i] = o >= 0 ? (float)((double)b[o] * oscale) : 0.f;   // i = 4g + reg
         }
 }
 
 // per-lane-group table of one output row over a natural-layout input of J slots: T[g][j]
-void pack_row(float* dst, const float* wrow, int J, int limit = 1 << 30) {
+void pack_row(float* dst, const float* wrow, int J, double iscale = 1.0) {
     for (int g = 0; g < 4; ++g)
-        for (int j = 0; j < J; ++j) {
-            const int i = nat_in(j, g);
-            dst[g * J + j] = i < limit ? wrow[i] : 0.f;
-        }
+        for (int j = 0; j < J; ++j) dst[g * J + j] = (float)((double)wrow[nat_in(j, g)] / iscale);
 }
 }  // namespace
 
@@ -88,17 +95,17 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
     const int d0w[3] = {can::MEAN0_W, can::VAR0_W, can::AW0_W}, d0b[3] = {can::MEAN0_B, can::VAR0_B, can::AW0_B};
     const int d2w[3] = {can::MEAN2_W, can::VAR2_W, can::AW2_W}, d2b[3] = {can::MEAN2_B, can::VAR2_B, can::AW2_B};
     for (int br = 0; br < 3; ++br) {
-        pack_frag(p + pk::DEC1 + br * frag_floats(8, 2), c + d0w[br], 32, 8, 2, ray8, natO);
-        pack_bias(p + pk::B_DEC1 + br * 32, c + d0b[br], 2, natO);
-        pack_frag(p + pk::DEC2 + br * frag_floats(8, 2), c + d2w[br], 32, 8, 2, natI, natO);
-        pack_bias(p + pk::B_DEC2 + br * 32, c + d2b[br], 2, natO);
+        pack_frag(p + pk::DEC1 + br * frag_floats(8, 2), c + d0w[br], 32, 8, 2, ray8, natO, LOG2E, kTrue);
+        pack_bias(p + pk::B_DEC1 + br * 32, c + d0b[br], 2, natO, LOG2E);
+        pack_frag(p + pk::DEC2 + br * frag_floats(8, 2), c + d2w[br], 32, 8, 2, natI, natO, LOG2E, kTilde);
+        pack_bias(p + pk::B_DEC2 + br * 32, c + d2b[br], 2, natO, LOG2E);
     }
     // decoder .4 rows on the VALU: mean0 mean1 var0 var1 aw
-    pack_row(p + pk::T_DEC3 + 0 * 32, c + can::MEAN4_W, 8);
-    pack_row(p + pk::T_DEC3 + 1 * 32, c + can::MEAN4_W + 32, 8);
-    pack_row(p + pk::T_DEC3 + 2 * 32, c + can::VAR4_W, 8);
-    pack_row(p + pk::T_DEC3 + 3 * 32, c + can::VAR4_W + 32, 8);
-    pack_row(p + pk::T_DEC3 + 4 * 32, c + can::AW4_W, 8);
+    pack_row(p + pk::T_DEC3 + 0 * 32, c + can::MEAN4_W, 8, LOG2E);
+    pack_row(p + pk::T_DEC3 + 1 * 32, c + can::MEAN4_W + 32, 8, LOG2E);
+    pack_row(p + pk::T_DEC3 + 2 * 32, c + can::VAR4_W, 8, LOG2E);
+    pack_row(p + pk::T_DEC3 + 3 * 32, c + can::VAR4_W + 32, 8, LOG2E);
+    pack_row(p + pk::T_DEC3 + 4 * 32, c + can::AW4_W, 8, LOG2E);
     p[pk::T_DEC3_B + 0] = c[can::MEAN4_B]; p[pk::T_DEC3_B + 1] = c[can::MEAN4_B + 1];
     p[pk::T_DEC3_B + 2] = c[can::VAR4_B]; p[pk::T_DEC3_B + 3] = c[can::VAR4_B + 1];
     p[pk::T_DEC3_B + 4] = c[can::AW4_B];
@@ -111,46 +118,46 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
     pack_bias(p + pk::B_PE2, c + can::PE2_B, 2, natO);
 
     // --- ray_dir_fc: 4 -> 16 -> 35, output laid out like x (see xfeat)
-    pack_frag(p + pk::RDF1, c + can::RDF0_W, 4, 1, 1, [](int, int g) { return g; }, natO);
-    pack_bias(p + pk::B_RDF1, c + can::RDF0_B, 1, natO);
+    pack_frag(p + pk::RDF1, c + can::RDF0_W, 4, 1, 1, [](int, int g) { return g; }, natO, LOG2E, kTrue);
+    pack_bias(p + pk::B_RDF1, c + can::RDF0_B, 1, natO, LOG2E);
     const IdxFn xout = [](int nb, int i) {
         const int g = i >> 2, r = i & 3;
         if (nb == 0) return 3 + 8 * g + r;
         if (nb == 1) return 3 + 8 * g + 4 + r;
         return (r == 0 && g < 3) ? g : -1;
     };
-    pack_frag(p + pk::RDF2, c + can::RDF2_W, 16, 4, 3, natI, xout);
-    pack_bias(p + pk::B_RDF2, c + can::RDF2_B, 3, xout);
+    pack_frag(p + pk::RDF2, c + can::RDF2_W, 16, 4, 3, natI, xout, LOG2E, kTilde);
+    pack_bias(p + pk::B_RDF2, c + can::RDF2_B, 3, xout, LOG2E);
 
     // --- neuray_fc: 32 -> 8 (MFMA) -> 1 (VALU)
-    pack_frag(p + pk::NR1, c + can::NR0_W, 32, 8, 1, natI, first8);
-    pack_bias(p + pk::B_NR1, c + can::NR0_B, 1, first8);
+    pack_frag(p + pk::NR1, c + can::NR0_W, 32, 8, 1, natI, first8, LOG2E, kTrue);
+    pack_bias(p + pk::B_NR1, c + can::NR0_B, 1, first8, LOG2E);
     for (int g = 0; g < 4; ++g)
-        for (int r = 0; r < 4; ++r) p[pk::T_NR2 + g * 4 + r] = (4 * g + r < 8) ? c[can::NR2_W + 4 * g + r] : 0.f;
+        for (int r = 0; r < 4; ++r) p[pk::T_NR2 + g * 4 + r] = (4 * g + r < 8) ? (float)(c[can::NR2_W + 4 * g + r] / LOG2E) : 0.f;
     p[pk::T_SCAL + 0] = c[can::NR2_B];
 
     // --- base_fc.0 split: view-invariant 140 columns (HOIST) + per-view 67 columns (BASE1)
     pack_frag(p + pk::HOIST, c + can::BASE0_W, 207, 36, 4,
-              [](int j, int g) { const int x = xfeat(j % 9, g); return x < 0 ? -1 : 35 * (j / 9) + x; }, natO);
-    pack_bias(p + pk::B_HOIST, c + can::BASE0_B, 4, natO);
+              [](int j, int g) { const int x = xfeat(j % 9, g); return x < 0 ? -1 : 35 * (j / 9) + x; }, natO, LOG2E, kTrue);
+    pack_bias(p + pk::B_HOIST, c + can::BASE0_B, 4, natO, LOG2E);
     pack_frag(p + pk::BASE1, c + can::BASE0_W, 207, 17, 4,
               [](int j, int g) {
                   if (j < 9) { const int x = xfeat(j, g); return x < 0 ? -1 : 140 + x; }
                   return 175 + nat_in(j - 9, g);
-              }, natO);
-    pack_frag(p + pk::BASE2, c + can::BASE2_W, 64, 16, 2, natI, natO);
-    pack_bias(p + pk::B_BASE2, c + can::BASE2_B, 2, natO);
+              }, natO, LOG2E, kTrue);
+    pack_frag(p + pk::BASE2, c + can::BASE2_W, 64, 16, 2, natI, natO, LOG2E, kTilde);
+    pack_bias(p + pk::B_BASE2, c + can::BASE2_B, 2, natO, LOG2E);
 
     // --- vis_fc (32 -> 32 -> 32+1) and vis_fc2 (32 -> 32 -> 1)
-    pack_frag(p + pk::VIS1, c + can::VIS0_W, 32, 8, 2, natI, natO);
-    pack_bias(p + pk::B_VIS1, c + can::VIS0_B, 2, natO);
-    pack_frag(p + pk::VIS2, c + can::VIS2_W, 32, 8, 2, natI, natO);
-    pack_bias(p + pk::B_VIS2, c + can::VIS2_B, 2, natO);
-    pack_row(p + pk::T_VIS2R, c + can::VIS2_W + 32 * 32, 8);
+    pack_frag(p + pk::VIS1, c + can::VIS0_W, 32, 8, 2, natI, natO, LOG2E, kTilde);
+    pack_bias(p + pk::B_VIS1, c + can::VIS0_B, 2, natO, LOG2E);
+    pack_frag(p + pk::VIS2, c + can::VIS2_W, 32, 8, 2, natI, natO, LOG2E, kTilde);
+    pack_bias(p + pk::B_VIS2, c + can::VIS2_B, 2, natO, LOG2E);
+    pack_row(p + pk::T_VIS2R, c + can::VIS2_W + 32 * 32, 8, LOG2E);
     p[pk::T_SCAL + 1] = c[can::VIS2_B + 32];
-    pack_frag(p + pk::VISB1, c + can::VISB0_W, 32, 8, 2, natI, natO);
-    pack_bias(p + pk::B_VISB1, c + can::VISB0_B, 2, natO);
-    pack_row(p + pk::T_VISB2, c + can::VISB2_W, 8);
+    pack_frag(p + pk::VISB1, c + can::VISB0_W, 32, 8, 2, natI, natO, LOG2E, kTilde);
+    pack_bias(p + pk::B_VISB1, c + can::VISB0_B, 2, natO, LOG2E);
+    pack_row(p + pk::T_VISB2, c + can::VISB2_W, 8, LOG2E);
     p[pk::T_SCAL + 2] = c[can::VISB2_B];
 
     // --- rgb_fc: [h(32), vis(1), dir_diff(4)] -> 16 -> 8 -> 1
@@ -159,12 +166,12 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
                   if (j < 8) return nat_in(j, g);
                   if (j == 8) return g == 0 ? 32 : 33 + (g - 1);
                   return g == 0 ? 36 : -1;
-              }, natO);
-    pack_bias(p + pk::B_RGB1, c + can::RGB0_B, 1, natO);
-    pack_frag(p + pk::RGB2, c + can::RGB2_W, 16, 4, 1, natI, first8);
-    pack_bias(p + pk::B_RGB2, c + can::RGB2_B, 1, first8);
+              }, natO, LOG2E, [](int i) { return i < 32 ? LOG2E : 1.0; });
+    pack_bias(p + pk::B_RGB1, c + can::RGB0_B, 1, natO, LOG2E);
+    pack_frag(p + pk::RGB2, c + can::RGB2_W, 16, 4, 1, natI, first8, LOG2E, kTilde);
+    pack_bias(p + pk::B_RGB2, c + can::RGB2_B, 1, first8, LOG2E);
     for (int g = 0; g < 4; ++g)
-        for (int r = 0; r < 4; ++r) p[pk::T_RGB3 + g * 4 + r] = (4 * g + r < 8) ? c[can::RGB4_W + 4 * g + r] : 0.f;
+        for (int r = 0; r < 4; ++r) p[pk::T_RGB3 + g * 4 + r] = (4 * g + r < 8) ? (float)(c[can::RGB4_W + 4 * g + r] / LOG2E) : 0.f;
     p[pk::T_SCAL + 3] = c[can::RGB4_B];
 
     // --- geometry_fc: [mean(32), var(32), wbar, embed(21)] -> 64 -> 16
@@ -177,10 +184,10 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
                   const int k = j - 16;
                   if (g == 0) return k == 0 ? 64 : -1;
                   return 65 + 3 * k + (g - 1);
-              }, natO);
-    pack_bias(p + pk::B_GEO1, c + can::GEO0_B, 4, natO);
-    pack_frag(p + pk::GEO2, c + can::GEO2_W, 64, 16, 1, natI, natO);
-    pack_bias(p + pk::B_GEO2, c + can::GEO2_B, 1, natO);
+              }, natO, LOG2E, [](int i) { return i < 32 ? LOG2E : (i < 64 ? LOG2E * LOG2E : 1.0); });
+    pack_bias(p + pk::B_GEO1, c + can::GEO0_B, 4, natO, LOG2E);
+    pack_frag(p + pk::GEO2, c + can::GEO2_W, 64, 16, 1, natI, natO, LOG2E, kTilde);
+    pack_bias(p + pk::B_GEO2, c + can::GEO2_B, 1, natO, LOG2E);
 
     // --- RAY section
     std::memcpy(p + pk::R_WQ, c + can::WQ, sizeof(float) * 256);

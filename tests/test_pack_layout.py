@@ -104,42 +104,49 @@ def packed_and_sd(weights_np):
     return weights.pack(can), weights_np
 
 
+LOG2E = 1.4426950408889634
+TRUE = lambda i: 1.0          # input carried at true scale
+TILDE = lambda i: LOG2E       # input is a scaled-ELU output (log2e * ELU)
+
 LAYERS = [
-    # name, frag, bias, J, NB, key, phi(j,g) -> input idx, psi(nb,i) -> output idx, n_in, n_out
-    ('dec1_var', ('DEC1', 1024), ('B_DEC1', 32), 8, 2, 'dist_decoder.var_decoder.0', lambda j, g: 8 * g + j, lambda nb, i: 16 * nb + i),
-    ('dec2_aw', ('DEC2', 2048), ('B_DEC2', 64), 8, 2, 'dist_decoder.aw_decoder.2', nat, lambda nb, i: 16 * nb + i),
+    # name, frag, bias, J, NB, key, phi(j,g) -> input idx, psi(nb,i) -> output idx, input scale, output scale
+    ('dec1_var', ('DEC1', 1024), ('B_DEC1', 32), 8, 2, 'dist_decoder.var_decoder.0', lambda j, g: 8 * g + j, lambda nb, i: 16 * nb + i, TRUE, LOG2E),
+    ('dec2_aw', ('DEC2', 2048), ('B_DEC2', 64), 8, 2, 'dist_decoder.aw_decoder.2', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
     ('pe1', ('PE1', 0), ('B_PE1', 0), 9, 2, 'agg_net.prob_embed.0',
-     lambda j, g: 8 * g + j if j < 8 else (32 if g == 0 else (33 if g == 1 else -1)), lambda nb, i: 16 * nb + i),
-    ('pe2', ('PE2', 0), ('B_PE2', 0), 8, 2, 'agg_net.prob_embed.2', nat, lambda nb, i: 16 * nb + i),
-    ('rdf1', ('RDF1', 0), ('B_RDF1', 0), 1, 1, 'agg_net.agg_impl.ray_dir_fc.0', lambda j, g: g, lambda nb, i: i),
+     lambda j, g: 8 * g + j if j < 8 else (32 if g == 0 else (33 if g == 1 else -1)), lambda nb, i: 16 * nb + i, TRUE, 1.0),
+    ('pe2', ('PE2', 0), ('B_PE2', 0), 8, 2, 'agg_net.prob_embed.2', nat, lambda nb, i: 16 * nb + i, TRUE, 1.0),
+    ('rdf1', ('RDF1', 0), ('B_RDF1', 0), 1, 1, 'agg_net.agg_impl.ray_dir_fc.0', lambda j, g: g, lambda nb, i: i, TRUE, LOG2E),
     ('rdf2', ('RDF2', 0), ('B_RDF2', 0), 4, 3, 'agg_net.agg_impl.ray_dir_fc.2', nat,
      lambda nb, i: (3 + 8 * (i >> 2) + (i & 3)) if nb == 0 else ((3 + 8 * (i >> 2) + 4 + (i & 3)) if nb == 1 else
-                                                                 ((i >> 2) if (i & 3) == 0 and (i >> 2) < 3 else -1))),
-    ('nr1', ('NR1', 0), ('B_NR1', 0), 8, 1, 'agg_net.agg_impl.neuray_fc.0', nat, lambda nb, i: i if i < 8 else -1),
-    ('base2', ('BASE2', 0), ('B_BASE2', 0), 16, 2, 'agg_net.agg_impl.base_fc.2', nat, lambda nb, i: 16 * nb + i),
-    ('vis1', ('VIS1', 0), ('B_VIS1', 0), 8, 2, 'agg_net.agg_impl.vis_fc.0', nat, lambda nb, i: 16 * nb + i),
-    ('visb1', ('VISB1', 0), ('B_VISB1', 0), 8, 2, 'agg_net.agg_impl.vis_fc2.0', nat, lambda nb, i: 16 * nb + i),
+                                                                 ((i >> 2) if (i & 3) == 0 and (i >> 2) < 3 else -1)), TILDE, LOG2E),
+    ('nr1', ('NR1', 0), ('B_NR1', 0), 8, 1, 'agg_net.agg_impl.neuray_fc.0', nat, lambda nb, i: i if i < 8 else -1, TRUE, LOG2E),
+    ('base2', ('BASE2', 0), ('B_BASE2', 0), 16, 2, 'agg_net.agg_impl.base_fc.2', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
+    ('vis1', ('VIS1', 0), ('B_VIS1', 0), 8, 2, 'agg_net.agg_impl.vis_fc.0', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
+    ('visb1', ('VISB1', 0), ('B_VISB1', 0), 8, 2, 'agg_net.agg_impl.vis_fc2.0', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
     ('rgb1', ('RGB1', 0), ('B_RGB1', 0), 10, 1, 'agg_net.agg_impl.rgb_fc.0',
-     lambda j, g: nat(j, g) if j < 8 else ((32 if g == 0 else 32 + g) if j == 8 else (36 if g == 0 else -1)), lambda nb, i: i),
-    ('rgb2', ('RGB2', 0), ('B_RGB2', 0), 4, 1, 'agg_net.agg_impl.rgb_fc.2', nat, lambda nb, i: i if i < 8 else -1),
+     lambda j, g: nat(j, g) if j < 8 else ((32 if g == 0 else 32 + g) if j == 8 else (36 if g == 0 else -1)), lambda nb, i: i,
+     lambda i: LOG2E if i < 32 else 1.0, LOG2E),
+    ('rgb2', ('RGB2', 0), ('B_RGB2', 0), 4, 1, 'agg_net.agg_impl.rgb_fc.2', nat, lambda nb, i: i if i < 8 else -1, TILDE, LOG2E),
     ('geo1', ('GEO1', 0), ('B_GEO1', 0), 23, 4, 'agg_net.agg_impl.geometry_fc.0',
      lambda j, g: nat(j, g) if j < 8 else (32 + nat(j - 8, g) if j < 16 else
                                            ((64 if j == 16 else -1) if g == 0 else 65 + 3 * (j - 16) + (g - 1))),
-     lambda nb, i: 16 * nb + i),
-    ('geo2', ('GEO2', 0), ('B_GEO2', 0), 16, 1, 'agg_net.agg_impl.geometry_fc.2', nat, lambda nb, i: i),
+     lambda nb, i: 16 * nb + i, lambda i: LOG2E if i < 32 else (LOG2E ** 2 if i < 64 else 1.0), LOG2E),
+    ('geo2', ('GEO2', 0), ('B_GEO2', 0), 16, 1, 'agg_net.agg_impl.geometry_fc.2', nat, lambda nb, i: i, TILDE, LOG2E),
 ]
 
 
 @pytest.mark.parametrize('spec', LAYERS, ids=[l[0] for l in LAYERS])
 def test_layer_fragments(spec, packed_and_sd):
     packed, sd = packed_and_sd
-    name, (fname, fadd), (bname, badd), J, NB, key, phi, psi = spec
+    name, (fname, fadd), (bname, badd), J, NB, key, phi, psi, iscale, oscale = spec
     W, b = sd[key + '.weight'], sd[key + '.bias']
     rng = np.random.default_rng(7)
     x = rng.standard_normal((16, W.shape[1])).astype(np.float32)
-    acc = emulate(packed, off(fname) + fadd, J, NB, to_B(x, J, phi), bias_acc(packed, off(bname) + badd, NB))
+    # what the kernel holds in registers: true inputs times the scale they are carried at
+    xk = (x * np.array([iscale(i) for i in range(W.shape[1])])).astype(np.float32)
+    acc = emulate(packed, off(fname) + fadd, J, NB, to_B(xk, J, phi), bias_acc(packed, off(bname) + badd, NB))
     y = from_D(acc, NB, psi, W.shape[0])
-    np.testing.assert_allclose(y, x.astype(np.float64) @ W.T.astype(np.float64) + b, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y, oscale * (x.astype(np.float64) @ W.T.astype(np.float64) + b), rtol=2e-5, atol=2e-5)
 
 
 def test_base_fc0_split(packed_and_sd):
@@ -153,7 +160,7 @@ def test_base_fc0_split(packed_and_sd):
     B_v = to_B(z, 17, lambda j, g: ((140 + xfeat(j, g)) if xfeat(j, g) >= 0 else -1) if j < 9 else 175 + nat(j - 9, g))
     acc = emulate(packed, off('BASE1'), 17, 4, B_v, G)
     y = from_D(acc, 4, lambda nb, i: 16 * nb + i, 64)
-    np.testing.assert_allclose(y, z.astype(np.float64) @ W.T.astype(np.float64) + b, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y, LOG2E * (z.astype(np.float64) @ W.T.astype(np.float64) + b), rtol=2e-5, atol=2e-5)
 
 
 def test_vis_fc2_rows_and_tables(packed_and_sd):
@@ -174,16 +181,17 @@ def test_vis_fc2_rows_and_tables(packed_and_sd):
         return out
 
     W, b = sd['agg_net.agg_impl.vis_fc.2.weight'], sd['agg_net.agg_impl.vis_fc.2.bias']
-    acc = emulate(packed, off('VIS2'), 8, 2, to_B(h, 8, nat), bias_acc(packed, off('B_VIS2'), 2))
-    np.testing.assert_allclose(from_D(acc, 2, lambda nb, i: 16 * nb + i, 32), h @ W[:32].T + b[:32], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(table_dot(off('T_VIS2R'), 8, h, 32) + packed[off('T_SCAL') + 1], h @ W[32] + b[32], rtol=1e-5, atol=1e-5)
+    hk = (h * LOG2E).astype(np.float32)       # every table below consumes a scaled-ELU vector
+    acc = emulate(packed, off('VIS2'), 8, 2, to_B(hk, 8, nat), bias_acc(packed, off('B_VIS2'), 2))
+    np.testing.assert_allclose(from_D(acc, 2, lambda nb, i: 16 * nb + i, 32), LOG2E * (h @ W[:32].T + b[:32]), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(table_dot(off('T_VIS2R'), 8, hk, 32) + packed[off('T_SCAL') + 1], h @ W[32] + b[32], rtol=1e-5, atol=1e-5)
     W2, b2 = sd['agg_net.agg_impl.vis_fc2.2.weight'], sd['agg_net.agg_impl.vis_fc2.2.bias']
-    np.testing.assert_allclose(table_dot(off('T_VISB2'), 8, h, 32) + packed[off('T_SCAL') + 2], h @ W2[0] + b2[0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(table_dot(off('T_VISB2'), 8, hk, 32) + packed[off('T_SCAL') + 2], h @ W2[0] + b2[0], rtol=1e-5, atol=1e-5)
     # decoder heads: order mean0 mean1 var0 var1 aw
     rows = [('mean_decoder', 0), ('mean_decoder', 1), ('var_decoder', 0), ('var_decoder', 1), ('aw_decoder', 0)]
     for o, (br, k) in enumerate(rows):
         Wd, bd = sd[f'dist_decoder.{br}.4.weight'], sd[f'dist_decoder.{br}.4.bias']
-        np.testing.assert_allclose(table_dot(off('T_DEC3') + o * 32, 8, h, 32) + packed[off('T_DEC3_B') + o],
+        np.testing.assert_allclose(table_dot(off('T_DEC3') + o * 32, 8, hk, 32) + packed[off('T_DEC3_B') + o],
                                    h @ Wd[k] + bd[k], rtol=1e-5, atol=1e-5)
     # 8-wide inputs living on groups 0,1 (rows 0..7 of a 16-row block): neuray_fc.2, rgb_fc.4
     h8 = np.zeros((16, 16), np.float32)
@@ -194,7 +202,7 @@ def test_vis_fc2_rows_and_tables(packed_and_sd):
         for r in range(16):
             for g in range(4):
                 for t in range(4):
-                    got[r] += packed[off(tname) + g * 4 + t] * h8[r, 4 * g + t]
+                    got[r] += packed[off(tname) + g * 4 + t] * h8[r, 4 * g + t] * LOG2E
         np.testing.assert_allclose(got + packed[off('T_SCAL') + sidx], h8[:, :8] @ Wr[0] + br_[0], rtol=1e-5, atol=1e-5)
 
 
