@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libgnr.so')
+LIB_PATH = os.path.join(_HERE, 'csrc', os.environ.get('GNR_LIB', 'libgnr.so'))   # GNR_LIB: A/B builds
 
 GNR_OK = 0
 ERRORS = {-1: 'GNR_ERR_ARG', -2: 'GNR_ERR_SHAPE', -3: 'GNR_ERR_HIP', -4: 'GNR_ERR_WORKSPACE'}
