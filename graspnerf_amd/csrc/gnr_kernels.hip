@@ -691,8 +691,22 @@ DEV float wave_sum(float x) {
     return x;
 }
 
+// logits of one query against key j for the 4 heads; `ok` false reproduces the reference's
+// query-row mask (whole row = -1e9 -> uniform softmax; ibrnet.py:19-23,492-493)
+DEV void head_logits(const float (&q)[16], const float* __restrict__ Kj, bool ok, float (&s)[4]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const f4 k = reinterpret_cast<const f4*>(Kj)[h];
+        const float d = 0.5f * (q[4 * h] * k.x + q[4 * h + 1] * k.y + q[4 * h + 2] * k.z + q[4 * h + 3] * k.w);
+        s[h] = ok ? d : -1e9f;
+    }
+}
+
+#ifndef GNR_RAY_UNROLL
+#define GNR_RAY_UNROLL 1
+#endif
 template <bool RENDER>
-__global__ __launch_bounds__(256) void k_ray(RayArgs a) {
+__global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -712,6 +726,7 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
     const float* rec = a.rec + pt * REC;
     const float* W = a.wpk;
+    constexpr int UA = RENDER ? GNR_RAY_UNROLL : 4;       // key-loop unroll (register pressure vs LDS latency)
 
     float g16[16], t[16];
     {
@@ -755,30 +770,40 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
     }
     wave_sync();
 
-    // ---- attention, lane = query row (ibrnet.py:15-27): softmax over dn keys per head
-    float o[16], amax[4], ainv[4];
+    // ---- attention, lane = query row (ibrnet.py:15-27): softmax over dn keys, 4 heads per key visit.
+    // Loops are unrolled so the LDS broadcast reads of several keys are in flight at once (this
+    // kernel is latency-bound, not throughput-bound).
+    float amax[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll UA
+    for (int j = 0; j < dn; ++j) {
+        float sj[4];
+        head_logits(q, Kb + j * 16, rowok, sj);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        float mx = -3.0e38f;
+        for (int h = 0; h < 4; ++h) amax[h] = fmaxf(amax[h], sj[h]);
+    }
+    float o[16], ainv[4];
+    {
+        float l[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 16; ++f) o[f] = 0.f;
+#pragma unroll UA
         for (int j = 0; j < dn; ++j) {
-            const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
-            float s = 0.5f * (q[4 * h] * kj.x + q[4 * h + 1] * kj.y + q[4 * h + 2] * kj.z + q[4 * h + 3] * kj.w);
-            s = rowok ? s : -1e9f;
-            mx = fmaxf(mx, s);
+            float sj[4];
+            head_logits(q, Kb + j * 16, rowok, sj);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
+                const float pj = __expf(sj[h] - amax[h]);
+                l[h] += pj;
+                o[4 * h] = fmaf(pj, vj.x, o[4 * h]); o[4 * h + 1] = fmaf(pj, vj.y, o[4 * h + 1]);
+                o[4 * h + 2] = fmaf(pj, vj.z, o[4 * h + 2]); o[4 * h + 3] = fmaf(pj, vj.w, o[4 * h + 3]);
+            }
         }
-        float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-        for (int j = 0; j < dn; ++j) {
-            const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
-            const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
-            float s = 0.5f * (q[4 * h] * kj.x + q[4 * h + 1] * kj.y + q[4 * h + 2] * kj.z + q[4 * h + 3] * kj.w);
-            s = rowok ? s : -1e9f;
-            const float pj = __expf(s - mx);
-            l += pj;
-            o0 = fmaf(pj, vj.x, o0); o1 = fmaf(pj, vj.y, o1); o2 = fmaf(pj, vj.z, o2); o3 = fmaf(pj, vj.w, o3);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            ainv[h] = 1.f / l[h];
+            o[4 * h] *= ainv[h]; o[4 * h + 1] *= ainv[h]; o[4 * h + 2] *= ainv[h]; o[4 * h + 3] *= ainv[h];
         }
-        const float il = 1.f / l;
-        o[4 * h] = o0 * il; o[4 * h + 1] = o1 * il; o[4 * h + 2] = o2 * il; o[4 * h + 3] = o3 * il;
-        amax[h] = mx; ainv[h] = il;
     }
     // ---- fc + residual, LayerNorm(eps 1e-6), out_geometry_fc (two linears), clip   ibrnet.py:97-100,494-495
     float y[16], xh[16], nrm[16];
@@ -820,19 +845,14 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
     } else {
         // ================= in-forward VJP of sum(sdf) w.r.t. the sample points (ibrnet.py:497-504)
         const float ds = (sraw >= -1.f && sraw <= 1.f && nvalid >= 1.f && act) ? 1.f : 0.f;
-        float dnrm[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float s = 0.f;
-#pragma unroll
-            for (int f = 0; f < 16; ++f) s = fmaf(W[pk::R_OUT0W + f * 16 + c], W[pk::R_OUT1W + f], s);
-            dnrm[c] = s * ds;
-        }
         float dy[16];
         {
             float m1 = 0.f, m2 = 0.f, dxh[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { dxh[c] = dnrm[c] * W[pk::R_LNW + c]; m1 += dxh[c]; m2 += dxh[c] * xh[c]; }
+            for (int c = 0; c < 16; ++c) {
+                dxh[c] = ds * W[pk::R_OUTVJP + c] * W[pk::R_LNW + c];
+                m1 += dxh[c]; m2 += dxh[c] * xh[c];
+            }
             m1 *= (1.f / 16.f); m2 *= (1.f / 16.f);
 #pragma unroll
             for (int c = 0; c < 16; ++c) dy[c] = rstd * (dxh[c] - m1 - xh[c] * m2);
@@ -842,30 +862,36 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
         for (int f = 0; f < 16; ++f) {
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) s = fmaf(dy[c], W[pk::R_WFC + c * 16 + f], s);
+            for (int c = 0; c < 16; ++c) s = fmaf(dy[c], W[pk::R_WFCT + f * 16 + c], s);
             dO[f] = s;
         }
         // row pass: rs_h = sum_j P dA ;  dQ = (sum_j P dA k_j - rs sum_j P k_j) / 2
-        float dQ[16], rsv[4];
+        float dQ[16], rsv[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            float A1[16], B1[16];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            float rs = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            for (int f = 0; f < 16; ++f) { A1[f] = 0.f; B1[f] = 0.f; }
+#pragma unroll GNR_RAY_UNROLL
             for (int j = 0; j < dn; ++j) {
-                const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
-                const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
-                float s = 0.5f * (q[4 * h] * kj.x + q[4 * h + 1] * kj.y + q[4 * h + 2] * kj.z + q[4 * h + 3] * kj.w);
-                s = rowok ? s : -1e9f;
-                const float pj = __expf(s - amax[h]) * ainv[h];
-                const float dA = dO[4 * h] * vj.x + dO[4 * h + 1] * vj.y + dO[4 * h + 2] * vj.z + dO[4 * h + 3] * vj.w;
-                const float pd = pj * dA;
-                rs += pd;
-                a0 = fmaf(pd, kj.x, a0); a1 = fmaf(pd, kj.y, a1); a2 = fmaf(pd, kj.z, a2); a3 = fmaf(pd, kj.w, a3);
-                b0 = fmaf(pj, kj.x, b0); b1 = fmaf(pj, kj.y, b1); b2 = fmaf(pj, kj.z, b2); b3 = fmaf(pj, kj.w, b3);
+                float sj[4];
+                head_logits(q, Kb + j * 16, rowok, sj);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
+                    const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
+                    const float pj = __expf(sj[h] - amax[h]) * ainv[h];
+                    const float dA = dO[4 * h] * vj.x + dO[4 * h + 1] * vj.y + dO[4 * h + 2] * vj.z + dO[4 * h + 3] * vj.w;
+                    const float pd = pj * dA;
+                    rsv[h] += pd;
+                    A1[4 * h] = fmaf(pd, kj.x, A1[4 * h]); A1[4 * h + 1] = fmaf(pd, kj.y, A1[4 * h + 1]);
+                    A1[4 * h + 2] = fmaf(pd, kj.z, A1[4 * h + 2]); A1[4 * h + 3] = fmaf(pd, kj.w, A1[4 * h + 3]);
+                    B1[4 * h] = fmaf(pj, kj.x, B1[4 * h]); B1[4 * h + 1] = fmaf(pj, kj.y, B1[4 * h + 1]);
+                    B1[4 * h + 2] = fmaf(pj, kj.z, B1[4 * h + 2]); B1[4 * h + 3] = fmaf(pj, kj.w, B1[4 * h + 3]);
+                }
             }
             const float sc2 = rowok ? 0.5f : 0.f;       // masked query rows: d logits = 0
-            dQ[4 * h] = (a0 - rs * b0) * sc2; dQ[4 * h + 1] = (a1 - rs * b1) * sc2;
-            dQ[4 * h + 2] = (a2 - rs * b2) * sc2; dQ[4 * h + 3] = (a3 - rs * b3) * sc2;
-            rsv[h] = rs;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) dQ[f] = (A1[f] - rsv[f >> 2] * B1[f]) * sc2;
         }
         if (act) {
 #pragma unroll
@@ -877,16 +903,15 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
             const f4 r4 = {rsv[0], rsv[1], rsv[2], rsv[3]};
             reinterpret_cast<f4*>(St + i * 12)[0] = m4;
             reinterpret_cast<f4*>(St + i * 12)[1] = i4;
-            // rs < 0 sentinel is not possible to encode; keep a separate row-ok flag in the sign of 1/sum
             reinterpret_cast<f4*>(St + i * 12)[2] = r4;
         }
-        // row-ok flags of all rows as a wave mask
-        const unsigned long long okmask = __ballot(rowok && act);
+        const unsigned long long okmask = __ballot(rowok && act);     // row-ok flags of all query rows
         wave_sync();
         // column pass (lane = key j = i): dK_j = sum_i dL_ij q_i / 2 ; dV_j = sum_i P_ij dO_i
         float dK[16], dV[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) { dK[f] = 0.f; dV[f] = 0.f; }
+#pragma unroll GNR_RAY_UNROLL
         for (int qi = 0; qi < dn; ++qi) {
             const bool ok = (okmask >> qi) & 1ull;
             const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
@@ -914,9 +939,9 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
             float s = dy[c];
 #pragma unroll
             for (int f = 0; f < 16; ++f) {
-                s = fmaf(W[pk::R_WQ + f * 16 + c], dQ[f], s);
-                s = fmaf(W[pk::R_WK + f * 16 + c], dK[f], s);
-                s = fmaf(W[pk::R_WV + f * 16 + c], dV[f], s);
+                s = fmaf(W[pk::R_WQT + c * 16 + f], dQ[f], s);
+                s = fmaf(W[pk::R_WKT + c * 16 + f], dK[f], s);
+                s = fmaf(W[pk::R_WVT + c * 16 + f], dV[f], s);
             }
             dc[c] = s * (g16[c] > 0.f ? 1.f : g16[c] + 1.f);
         }
@@ -924,21 +949,28 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
         float de[21];
 #pragma unroll
         for (int e = 0; e < 21; ++e) de[e] = 0.f;
-#pragma unroll 4
-        for (int h = 0; h < 64; ++h) {
-            float du = 0.f;
+#pragma unroll 2
+        for (int h4 = 0; h4 < 16; ++h4) {
+            const f4 u4 = reinterpret_cast<const f4*>(rec + 16)[h4];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) du = fmaf(W[pk::R_GEO2W + c * 64 + h], dc[c], du);
-            const float uh = rec[16 + h];
-            const float da = du * (uh > 0.f ? 1.f : uh + 1.f);
+            for (int hh = 0; hh < 4; ++hh) {
+                const int h = 4 * h4 + hh;
+                float du = 0.f;
 #pragma unroll
-            for (int e = 0; e < 21; ++e) de[e] = fmaf(W[pk::R_GEO1E + h * 24 + e], da, de[e]);
+                for (int c = 0; c < 16; ++c) du = fmaf(W[pk::R_GEO2WT + h * 16 + c], dc[c], du);
+                const float uh = u4[hh];
+                const float da = du * (uh > 0.f ? 1.f : uh + 1.f);
+#pragma unroll
+                for (int e = 0; e < 21; ++e) de[e] = fmaf(W[pk::R_GEO1E + h * 24 + e], da, de[e]);
+            }
         }
         const float* dsc = a.desc + pt * DESC_FLOATS;
+        const f4 ds0 = reinterpret_cast<const f4*>(dsc)[0], ds1 = reinterpret_cast<const f4*>(dsc)[1];
+        const float pp[3] = {ds0.x, ds0.y, ds0.z}, qd[3] = {ds0.w, ds1.x, ds1.y};
         float grad[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float pc = dsc[c];
+            const float pc = pp[c];
             float s1, c1, s2, c2, s4, c4;
             sincosf(pc, &s1, &c1); sincosf(2.f * pc, &s2, &c2); sincosf(4.f * pc, &s4, &c4);
             grad[c] = de[c] + c1 * de[3 + c] - s1 * de[6 + c] + 2.f * c2 * de[9 + c] - 2.f * s2 * de[12 + c]
@@ -946,20 +978,24 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
         }
         // ================= NeuS alpha (aggregate_net.py:105-121), compositing (render_ops.py:72-80)
         const float z = a.depth[pt];
-        const float znext = (lane + 1 < dn) ? a.depth[pt + 1] : 0.f;
+        const float znext = __shfl_down(z, 1);
         const float dist = (lane + 1 < dn) ? znext - z : 1e6f;
         const float inv_s = fminf(fmaxf(__expf(W[pk::R_VARIANCE] * 10.f), 1e-6f), 1e6f);
-        const float tcos = -(dsc[3] * grad[0] + dsc[4] * grad[1] + dsc[5] * grad[2]);
+        const float tcos = -(qd[0] * grad[0] + qd[1] * grad[1] + qd[2] * grad[2]);
         const float icos = fminf(tcos, 0.f);                        // -relu(-cos)
         const float nxt = sdf + icos * dist * 0.5f, prv = sdf - icos * dist * 0.5f;
         const float pcdf = sigmoid1(prv * inv_s), ncdf = sigmoid1(nxt * inv_s);
         const float alpha = fminf(fmaxf((pcdf - ncdf + 1e-5f) / (pcdf + 1e-5f), 0.f), 1.f);
-        float* Al = Kb;                                              // reuse scratch (all reads of Kb done)
-        wave_sync();
-        if (act) Al[i] = 1.f - alpha + 1e-10f;
-        wave_sync();
-        float T = 1.f;
-        for (int j = 0; j < i; ++j) T *= Al[j];
+        // exclusive transmittance product as a wave prefix scan (6 shuffle steps instead of a dn-long
+        // dependent chain; differs from the sequential cumprod by fp32 rounding only)
+        float incl = act ? 1.f - alpha + 1e-10f : 1.f;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const float up = __shfl_up(incl, o2);
+            if (lane >= o2) incl *= up;
+        }
+        float T = __shfl_up(incl, 1);
+        if (lane == 0) T = 1.f;
         const float hitp = act ? alpha * T : 0.f;
         const float gn = sqrtf(grad[0] * grad[0] + grad[1] * grad[1] + grad[2] * grad[2]) - 1.f;
         const float gerr = wave_sum(act ? gn * gn : 0.f);
@@ -996,18 +1032,25 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
             const float hsum = wave_sum(act ? hp : 0.f);
             if (act) { Dn[i] = dnv; Pd[i] = __fdiv_rn(hp, hsum); }
             wave_sync();
-            if (act) {
-                float c = 0.f;
-                for (int j = 0; j <= i; ++j) c = __fadd_rn(c, Pd[j]);             // sequential cumsum
-                Cd[i + 1] = c;
-                Ce[i + 1] = (i + 1 < dn) ? __fmul_rn(__fadd_rn(Dn[i + 1], Dn[i]), 0.5f) : Dn[dn - 1];
-                if (i == 0) { Cd[0] = 0.f; Ce[0] = Dn[0]; }
+            {
+                float c = 0.f;                                                   // sequential cumsum, same
+#pragma unroll 8
+                for (int j = 0; j < dn; ++j) {                                   // add order on every lane
+                    const float pj = Pd[j];
+                    if (j <= i) c = __fadd_rn(c, pj);
+                }
+                if (act) {
+                    Cd[i + 1] = c;
+                    Ce[i + 1] = (i + 1 < dn) ? __fmul_rn(__fadd_rn(Dn[i + 1], Dn[i]), 0.5f) : Dn[dn - 1];
+                    if (i == 0) { Cd[0] = 0.f; Ce[0] = Dn[0]; }
+                }
             }
             wave_sync();
             const bool fact = lane < fdn;
             const float interval = 1.f / (float)fdn;
             const float u = __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)lane, interval));
             int inds = 0;
+#pragma unroll 8
             for (int j = 0; j <= dn; ++j) inds += (Cd[j] <= u) ? 1 : 0;          // searchsorted(right=True)
             const int below = max(inds - 1, 0), above = min(inds, dn);
             const float c0 = Cd[below], c1 = Cd[above], b0 = Ce[below], b1 = Ce[above];
@@ -1021,6 +1064,7 @@ __global__ __launch_bounds__(256) void k_ray(RayArgs a) {
             wave_sync();
             if (fact) {
                 int rank = 0;                                                    // stable rank sort (renderer.py:148)
+#pragma unroll 8
                 for (int j = 0; j < fdn; ++j) { const float o2 = Fd[j]; rank += (o2 < fd || (o2 == fd && j < lane)) ? 1 : 0; }
                 a.fine_depth[(size_t)ray * fdn + rank] = fd;
                 if (a.fine_inds) a.fine_inds[(size_t)ray * fdn + lane] = inds;

@@ -111,7 +111,11 @@ constexpr int R_GEO2W = R_OUT1B + 4;        // [16][64]
 constexpr int R_GEO1E = R_GEO2W + 1024;     // geometry_fc.0 weight columns 65..85: [64][21 -> 24]
 constexpr int R_VARIANCE = R_GEO1E + 64 * 24;
 constexpr int R_PE = R_VARIANCE + 4;        // sinusoid table [64 positions][16]
-constexpr int TOTAL = R_PE + 64 * 16;
+// transposed copies / products for the VJP so that every inner loop reads contiguous scalars
+constexpr int R_WQT = R_PE + 64 * 16, R_WKT = R_WQT + 256, R_WVT = R_WKT + 256, R_WFCT = R_WVT + 256;   // [in][out]
+constexpr int R_GEO2WT = R_WFCT + 256;      // geometry_fc.2 weight transposed: [64][16]
+constexpr int R_OUTVJP = R_GEO2WT + 1024;   // out_geometry_fc.0^T @ out_geometry_fc.1 : d sdf / d LayerNorm output, [16]
+constexpr int TOTAL = R_OUTVJP + 16;
 }  // namespace pk
 
 // per-point descriptor (k_points_* -> k_chain): 8 floats

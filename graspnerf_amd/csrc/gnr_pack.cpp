@@ -74,7 +74,8 @@ extern "C" int gnr_layout_offset(const char* name) {
         {"T_VISB2", T_VISB2}, {"T_RGB3", T_RGB3}, {"T_SCAL", T_SCAL}, {"CHAIN_END", CHAIN_END},
         {"R_WQ", R_WQ}, {"R_WK", R_WK}, {"R_WV", R_WV}, {"R_WFC", R_WFC}, {"R_LNW", R_LNW}, {"R_LNB", R_LNB},
         {"R_OUT0W", R_OUT0W}, {"R_OUT0B", R_OUT0B}, {"R_OUT1W", R_OUT1W}, {"R_OUT1B", R_OUT1B},
-        {"R_GEO2W", R_GEO2W}, {"R_GEO1E", R_GEO1E}, {"R_VARIANCE", R_VARIANCE}, {"R_PE", R_PE}, {"TOTAL", TOTAL}};
+        {"R_GEO2W", R_GEO2W}, {"R_GEO1E", R_GEO1E}, {"R_VARIANCE", R_VARIANCE}, {"R_PE", R_PE}, {"R_WQT", R_WQT},
+        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"TOTAL", TOTAL}};
     for (const E& e : tab)
         if (!std::strcmp(e.n, name)) return e.o;
     return -1;
@@ -210,5 +211,19 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
             const double ang = (double)pos / std::pow(10000.0, 2.0 * (k / 2) / 16.0);
             p[pk::R_PE + pos * 16 + k] = (float)((k % 2 == 0) ? std::sin(ang) : std::cos(ang));
         }
+    for (int i = 0; i < 16; ++i)
+        for (int o = 0; o < 16; ++o) {
+            p[pk::R_WQT + i * 16 + o] = c[can::WQ + o * 16 + i];
+            p[pk::R_WKT + i * 16 + o] = c[can::WK + o * 16 + i];
+            p[pk::R_WVT + i * 16 + o] = c[can::WV + o * 16 + i];
+            p[pk::R_WFCT + i * 16 + o] = c[can::WFC + o * 16 + i];
+        }
+    for (int h = 0; h < 64; ++h)
+        for (int o = 0; o < 16; ++o) p[pk::R_GEO2WT + h * 16 + o] = c[can::GEO2_W + o * 64 + h];
+    for (int i = 0; i < 16; ++i) {
+        double acc = 0;
+        for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT0_W + f * 16 + i] * (double)c[can::OUT1_W + f];
+        p[pk::R_OUTVJP + i] = (float)acc;
+    }
     return GNR_OK;
 }
