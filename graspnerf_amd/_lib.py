@@ -65,6 +65,9 @@ def lib():
     L.gnr_debug_volume_chain.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_debug_volume_chain.restype = C.c_int
+    L.gnr_depth_mean_fwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_depth_mean_fwd.restype = C.c_int
     L.gnr_render_by_depth_fwd.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_int, C.c_void_p,
                                           C.POINTER(GnrRenderOut), C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_render_by_depth_fwd.restype = C.c_int
@@ -82,7 +85,7 @@ def lib():
 
 
 EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_layout_offset', 'gnr_workspace_bytes',
-            'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
+            'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel']
 
 

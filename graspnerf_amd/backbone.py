@@ -1,0 +1,174 @@
+"""PyTorch-ROCm side of the model that stays outside the HIP hot path (north_star: "host code stays
+Python on PyTorch-ROCm for the 2D backbone and grasp head"): the residual U-Net feature extractors,
+the visibility encoder and the VGN 3D-conv grasp head.  Written from the architecture description
+of the reference with IDENTICAL module / parameter names, so a reference checkpoint
+(`network_state_dict`) loads with strict=True.
+
+ref: src/nr/network/ops.py:43-230 (blocks, ResUNetLight), init_net.py:8-35, vis_encoder.py:6-22,
+     src/gd/networks.py:39-97 (ConvNet).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _inorm(ch):
+    return nn.InstanceNorm2d(ch, track_running_stats=False, affine=True)
+
+
+def _c3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride, 1, bias=False, padding_mode='reflect')
+
+
+def _c1(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 1, stride, bias=False, padding_mode='reflect')
+
+
+class BasicBlock(nn.Module):
+    """3x3 -> IN -> ReLU -> 3x3 -> IN, + identity (1x1/IN downsample when the shape changes)."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv1, self.bn1 = _c3(cin, cout, stride), _inorm(cout)
+        self.conv2, self.bn2 = _c3(cout, cout), _inorm(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(_c1(cin, cout, stride), _inorm(cout))
+
+    def forward(self, x):
+        y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class conv(nn.Module):       # lower-case name kept: it is part of the checkpoint key path
+    def __init__(self, cin, cout, k, stride):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, padding_mode='reflect')
+        self.bn = _inorm(cout)
+
+    def forward(self, x):
+        return F.elu(self.bn(self.conv(x)))
+
+
+class upconv(nn.Module):
+    def __init__(self, cin, cout, k, scale):
+        super().__init__()
+        self.scale = scale
+        self.conv = conv(cin, cout, k, 1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=self.scale, mode='bilinear', align_corners=True))
+
+
+class ResUNetLight(nn.Module):
+    """stride-2 stem, three residual stages (1/4, 1/8, 1/16), two up-convolutions with skip
+    connections back to 1/4 resolution, 1x1 head.   ref: ops.py:150-230"""
+
+    def __init__(self, in_dim=3, layers=(2, 3, 6, 3), out_dim=32, inplanes=32):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_dim, inplanes, 7, 2, 3, bias=False, padding_mode='reflect')
+        self.bn1 = _inorm(inplanes)
+        chans, c = (32, 64, 128), inplanes
+        stages = []
+        for planes, n in zip(chans, layers[:3]):
+            blocks = [BasicBlock(c, planes, 2)] + [BasicBlock(planes, planes) for _ in range(n - 1)]
+            stages.append(nn.Sequential(*blocks))
+            c = planes
+        self.layer1, self.layer2, self.layer3 = stages
+        self.upconv3 = upconv(128, 64, 3, 2)
+        self.iconv3 = conv(128, 64, 3, 1)
+        self.upconv2 = upconv(64, 32, 3, 2)
+        self.iconv2 = conv(64, 32, 3, 1)
+        self.out_conv = nn.Conv2d(32, out_dim, 1, 1)
+
+    @staticmethod
+    def _skip(skip, up):
+        dy, dx = up.shape[2] - skip.shape[2], up.shape[3] - skip.shape[3]
+        skip = F.pad(skip, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+        return torch.cat([up, skip], 1)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        x1 = self.layer1(x)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        y = self.iconv3(self._skip(x2, self.upconv3(x3)))
+        y = self.iconv2(self._skip(x1, self.upconv2(y)))
+        return self.out_conv(y)
+
+
+class ResidualBlock(nn.Module):
+    """pre-activation block: IN-ReLU-3x3-IN-ReLU-3x3 + shortcut.   ref: ops.py:43-76"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Sequential(_inorm(cin), nn.ReLU(True), _c3(cin, cout), _inorm(cout), nn.ReLU(True), _c3(cout, cout))
+        self.short_cut = nn.Conv2d(cin, cout, 1, 1) if cin != cout else None
+
+    def forward(self, x):
+        return self.conv(x) + (x if self.short_cut is None else self.short_cut(x))
+
+
+class CostVolumeInitNet(nn.Module):
+    """`init_net_type: cost_volume` is, despite its name, a 2D U-Net + 3 convs.
+    The ImageNet mean/std buffers exist in the checkpoint but are unused by forward
+    (ref: init_net.py:16-19,33-35)."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.register_buffer('imagenet_mean', torch.tensor([0.485, 0.456, 0.406])[None, :, None, None])
+        self.register_buffer('imagenet_std', torch.tensor([0.229, 0.224, 0.225])[None, :, None, None])
+        self.res_net = ResUNetLight(out_dim=32)
+        self.out_conv = nn.Sequential(_c3(32, 32), ResidualBlock(32, 32), _c1(32, 32))
+
+    def forward(self, ref_imgs_info, src_imgs_info=None, is_train=False):
+        return self.out_conv(self.res_net(ref_imgs_info['imgs']))
+
+
+class DefaultVisEncoder(nn.Module):
+    """ref: vis_encoder.py:6-22"""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.out_conv = nn.Sequential(_c3(64, 32), ResidualBlock(32, 32), ResidualBlock(32, 32), _c1(32, 32))
+
+    def forward(self, ray_feats, img_feats):
+        return self.out_conv(torch.cat([img_feats, ray_feats], 1))
+
+
+# ---------------------------------------------------------------------------------------------
+# VGN grasp head (consumes the 1 x R^3 volume)          ref: src/gd/networks.py:39-97
+# ---------------------------------------------------------------------------------------------
+def _c3d(cin, cout, k, stride=1):
+    return nn.Conv3d(cin, cout, k, stride=stride, padding=k // 2)
+
+
+class _Encoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1, self.conv2, self.conv3 = _c3d(1, 16, 5, 2), _c3d(16, 32, 3, 2), _c3d(32, 64, 3, 2)
+
+    def forward(self, x):
+        return F.relu(self.conv3(F.relu(self.conv2(F.relu(self.conv1(x))))))
+
+
+class _Decoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1, self.conv2, self.conv3 = _c3d(64, 64, 3), _c3d(64, 32, 3), _c3d(32, 16, 5)
+
+    def forward(self, x):
+        x = F.interpolate(F.relu(self.conv1(x)), 10)        # nearest, fixed sizes 10/20/40 (networks.py:88-96)
+        x = F.interpolate(F.relu(self.conv2(x)), 20)
+        return F.interpolate(F.relu(self.conv3(x)), 40)
+
+
+class ConvNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.encoder, self.decoder = _Encoder(), _Decoder()
+        self.conv_qual, self.conv_rot, self.conv_width = _c3d(16, 1, 5), _c3d(16, 4, 5), _c3d(16, 1, 5)
+
+    def forward(self, x):
+        f = self.decoder(self.encoder(x))
+        return torch.sigmoid(self.conv_qual(f)), F.normalize(self.conv_rot(f), dim=1), self.conv_width(f)

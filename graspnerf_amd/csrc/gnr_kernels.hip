@@ -1073,6 +1073,61 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_depth_mean: predict_mean_for_depth_loss (renderer.py:222-266): bilinear gather of ray_feats at
+// pixel coordinates shared by all views of a scene + the decoder's mean branch (32->32->32->2,
+// Softplus).  Same chained-MFMA tile as k_chain; one wavefront per 16 points of one view.
+// ---------------------------------------------------------------------------------------
+struct DepthMeanArgs {
+    const float* wpk; const float* feat64; const float* coords;   // coords [B][pn][2] (x, y) in full-res pixels
+    float* out;                                                    // [B][V][pn][2]
+    int B, V, pn, H, W, fh, fw;
+};
+
+__global__ __launch_bounds__(256) void k_depth_mean(DepthMeanArgs a) {
+    __shared__ __attribute__((aligned(16))) float w[2 * 1024 + 64 + 64 + 8];
+    float* W1 = w; float* W2 = w + 1024; float* B1 = w + 2048; float* B2 = w + 2080; float* T3 = w + 2112; float* TB = w + 2176;
+    for (int i = threadIdx.x; i < 1024; i += 256) { W1[i] = a.wpk[pk::DEC1 + i]; W2[i] = a.wpk[pk::DEC2 + i]; }
+    if (threadIdx.x < 32) { B1[threadIdx.x] = a.wpk[pk::B_DEC1 + threadIdx.x]; B2[threadIdx.x] = a.wpk[pk::B_DEC2 + threadIdx.x]; }
+    if (threadIdx.x < 64) T3[threadIdx.x] = a.wpk[pk::T_DEC3 + threadIdx.x];
+    if (threadIdx.x < 2) TB[threadIdx.x] = a.wpk[pk::T_DEC3_B + threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int tpv = (a.pn + 15) >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.B * a.V * tpv) return;
+    const int bv = tile / tpv, b = bv / a.V;
+    const int n_raw = (tile - bv * tpv) * 16 + r;
+    const bool ok = n_raw < a.pn;
+    const int n = ok ? n_raw : a.pn - 1;
+    const float x = a.coords[((size_t)b * a.pn + n) * 2], y = a.coords[((size_t)b * a.pn + n) * 2 + 1];
+    const float fsx = (float)a.fw / (float)(a.W - 1), fsy = (float)a.fh / (float)(a.H - 1);
+    const Taps t = make_taps(x, y, fsx, fsy, -0.5f, a.fh, a.fw);
+    const float* fb = a.feat64 + (size_t)bv * a.fh * a.fw * 64 + 8 * g;
+    float FR[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f4 a0 = reinterpret_cast<const f4*>(fb + (size_t)t.o00 * 64)[h], a1 = reinterpret_cast<const f4*>(fb + (size_t)t.o01 * 64)[h];
+        const f4 a2 = reinterpret_cast<const f4*>(fb + (size_t)t.o10 * 64)[h], a3 = reinterpret_cast<const f4*>(fb + (size_t)t.o11 * 64)[h];
+        const f4 fr = a0 * t.w00 + a1 * t.w01 + a2 * t.w10 + a3 * t.w11;
+        FR[4 * h] = fr.x; FR[4 * h + 1] = fr.y; FR[4 * h + 2] = fr.z; FR[4 * h + 3] = fr.w;
+    }
+    f4 acc[2];
+    float h1[8], h2[8];
+    load_bias<2>(B1, g, acc);
+    mm<8, 2>(W1, lane, FR, acc);
+    elu_to<2>(acc, h1);
+    load_bias<2>(B2, g, acc);
+    mm<8, 2>(W2, lane, h1, acc);
+    elu_to<2>(acc, h2);
+    const float m0 = softplus1(gsum(dot8(T3, g, h2)) + TB[0]);
+    const float m1 = softplus1(gsum(dot8(T3 + 32, g, h2)) + TB[1]);
+    if (ok && g == 0) {
+        float* o = a.out + ((size_t)bv * a.pn + n) * 2;
+        o[0] = m0; o[1] = m1;
+    }
+}
+
 // mean over the scene's rays of the per-ray partial sums / (rn*dn)   (aggregate_net.py:139)
 __global__ void k_gerr_reduce(const float* __restrict__ part, float* __restrict__ out, int rn, int dn) {
     __shared__ float red[256];

@@ -152,6 +152,17 @@ class HotPath:
         o['ray_mask'] = o['ray_mask'].bool()
         return o
 
+    def depth_mean(self, ref, coords, level='coarse', prepared=None):
+        """predict_mean_for_depth_loss for one level: coords [B,pn,2] (x,y) -> mean [B,V,pn,2]."""
+        scene, keep, ws = prepared or self.prepare(ref, 1)
+        coords = _f32(coords, self.device)
+        B, pn, _ = coords.shape
+        out = torch.empty(B, scene.V, pn, 2, dtype=torch.float32, device=self.device)
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_depth_mean_fwd(C.byref(scene), coords.data_ptr(), pn, w.data_ptr(), out.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), self._stream()), 'gnr_depth_mean_fwd')
+        return out
+
     def time_chain_kernel(self, ref, res=40, iters=10):
         """Average ms per launch of the dominant kernel (k_chain on the volume points), HIP events
         recorded on the launch stream inside the library."""

@@ -1,0 +1,238 @@
+"""Drop-in mirror of the reference's model API for the volumetric path:
+`NeuralRayRenderer(cfg).forward / sample_volume / render / render_by_depth / predict_mean_for_depth_loss`
+and `GraspNeRF(cfg).forward / select` with the reference's names, dict schemas, output keys and
+state-dict keys (ref: src/nr/network/renderer.py:13-335), so `src/gd`'s consumers and reference
+checkpoints plug in unchanged.  The 2D backbones and the grasp head are PyTorch-ROCm modules
+(backbone.py); everything between `ray_feats` and `volume` / the render dict runs in the HIP
+kernels behind libgnr.so (hotpath.py).  Forward / eval only in this round.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import weights as _w
+from .backbone import ResUNetLight, CostVolumeInitNet, DefaultVisEncoder, ConvNet
+from .hotpath import HotPath
+
+
+def _kaiming(mods):
+    for m in mods.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.kaiming_normal_(m.weight.data)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias.data)
+
+
+def _mlp(dims, skip_act_index=True):
+    """Linear layers at the reference's nn.Sequential indices (0, 2, 4, ...): parameter holders."""
+    layers = []
+    for i in range(len(dims) - 1):
+        layers += [nn.Linear(dims[i], dims[i + 1]), nn.Identity()]
+    return nn.Sequential(*layers[:-1])
+
+
+class _DistDecoderParams(nn.Module):
+    """ref: dist_decoder.py:53-88 (use_vis False)"""
+
+    def __init__(self):
+        super().__init__()
+        self.mean_decoder, self.var_decoder, self.aw_decoder = _mlp([32, 32, 32, 2]), _mlp([32, 32, 32, 2]), _mlp([32, 32, 32, 1])
+
+
+class _Attention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w_qs, self.w_ks, self.w_vs, self.fc = (nn.Linear(16, 16, bias=False) for _ in range(4))
+        self.layer_norm = nn.LayerNorm(16, eps=1e-6)
+
+
+class _AggImplParams(nn.Module):
+    """ref: ibrnet.py:373-435 (IBRNetWithNeuRayNeus)"""
+
+    def __init__(self):
+        super().__init__()
+        self.ray_dir_fc = _mlp([4, 16, 35])
+        self.base_fc = _mlp([207, 64, 32])
+        self.vis_fc = _mlp([32, 32, 33])
+        self.vis_fc2 = _mlp([32, 32, 1])
+        self.geometry_fc = _mlp([86, 64, 16])
+        self.ray_attention = _Attention()
+        self.out_geometry_fc = nn.Sequential(nn.Linear(16, 16), nn.Linear(16, 1))
+        self.rgb_fc = _mlp([37, 16, 8, 1])
+        self.neuray_fc = _mlp([32, 8, 1])
+        for m in (self.base_fc, self.vis_fc2, self.vis_fc, self.geometry_fc, self.rgb_fc, self.neuray_fc):
+            _kaiming(m)                                                   # ibrnet.py:430-435
+
+
+class _Deviation(nn.Module):
+    def __init__(self, init_val):
+        super().__init__()
+        self.variance = nn.Parameter(torch.tensor(float(init_val)), requires_grad=False)    # neus.py:9-10
+
+
+class _AggNetParams(nn.Module):
+    """ref: aggregate_net.py:19-33,87-101"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.prob_embed = _mlp([34, 32, 32])
+        self.agg_impl = _AggImplParams()
+        self.deviation_network = _Deviation(cfg.get('init_s', 0.3))
+
+
+class NeuralRayRenderer(nn.Module):
+    base_cfg = {
+        'vis_encoder_type': 'default', 'vis_encoder_cfg': {}, 'dist_decoder_type': 'mixture_logistics',
+        'dist_decoder_cfg': {}, 'agg_net_type': 'default', 'agg_net_cfg': {}, 'use_hierarchical_sampling': False,
+        'fine_agg_net_cfg': {}, 'fine_dist_decoder_cfg': {}, 'fine_depth_sample_num': 64, 'fine_depth_use_all': False,
+        'ray_batch_num': 2048, 'depth_sample_num': 64, 'alpha_value_ground_state': -15, 'use_dr_prediction': False,
+        'use_nr_color_for_dr': False, 'use_self_hit_prob': False, 'use_ray_mask': True, 'ray_mask_view_num': 2,
+        'ray_mask_point_num': 8, 'render_depth': False, 'disable_view_dir': False, 'render_rgb': False,
+        'init_net_type': 'depth', 'init_net_cfg': {}, 'depth_loss_coords_num': 8192,
+    }                                                                       # renderer.py:14-45
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = {**self.base_cfg, **cfg}
+        c = self.cfg
+        unsupported = [k for k, ok in (
+            ('agg_net_type', c['agg_net_type'] == 'neus'), ('init_net_type', c['init_net_type'] == 'cost_volume'),
+            ('use_hierarchical_sampling', bool(c['use_hierarchical_sampling'])),
+            ('dist_decoder_cfg.use_vis', not c['dist_decoder_cfg'].get('use_vis', True)),
+            ('fine_depth_use_all', not c['fine_depth_use_all']), ('disable_view_dir', not c['disable_view_dir']),
+            ('volume_type', list(c.get('volume_type', ['sdf'])) == ['sdf'])) if not ok]
+        if unsupported:
+            raise NotImplementedError(f'config options outside configs/nrvgn_sdf.yaml are not built: {unsupported}')
+        self.vis_encoder = DefaultVisEncoder(c['vis_encoder_cfg'])
+        self.dist_decoder = _DistDecoderParams()
+        self.image_encoder = ResUNetLight(3, [1, 2, 6, 4], 32, inplanes=16)
+        self.init_net = CostVolumeInitNet(c['init_net_cfg'])
+        self.agg_net = _AggNetParams(c['agg_net_cfg'])
+        self.fine_dist_decoder = _DistDecoderParams()
+        self.fine_agg_net = _AggNetParams(c['fine_agg_net_cfg'])
+        self.use_sdf = True
+        self._hot = None
+
+    # ---- HIP hot path handle (re-packed when parameters change device or values) -----------------
+    def _apply(self, fn, *a, **k):
+        self._hot = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._hot = None
+        return super().load_state_dict(*a, **k)
+
+    def hot(self):
+        if self._hot is None:
+            sd = self.state_dict()
+            dev = next(self.parameters()).device
+            self._hot = HotPath(_w.pack_state_dict(sd, 'coarse'), _w.pack_state_dict(sd, 'fine'), device=dev)
+        return self._hot
+
+    @staticmethod
+    def _batched_ref(ref):
+        out = {k: ref[k][None] for k in ('imgs', 'img_feats', 'ray_feats', 'poses', 'Ks', 'depth_range')}
+        out['bbox3d'] = torch.as_tensor(np.asarray(ref['bbox3d'].cpu() if torch.is_tensor(ref['bbox3d']) else ref['bbox3d']),
+                                        dtype=torch.float32)[None]
+        return out
+
+    @staticmethod
+    def _batched_que(que):
+        out = {'coords': que['coords'], 'pose': que['poses'], 'K': que['Ks'], 'depth_range': que['depth_range']}
+        if 'imgs' in que:
+            out['imgs'] = que['imgs']
+        return out
+
+    def _render_cfg(self):
+        c = self.cfg
+        return {'depth_sample_num': c['depth_sample_num'], 'fine_depth_sample_num': c['fine_depth_sample_num'],
+                'ray_mask_view_num': c['ray_mask_view_num'], 'ray_mask_point_num': c['ray_mask_point_num']}
+
+    # ---- the reference's methods ------------------------------------------------------------------
+    def sample_volume(self, ref_imgs_info):                                 # renderer.py:164-199
+        return self.hot().sample_volume(self._batched_ref(ref_imgs_info), self.cfg['volume_resolution'])
+
+    def _out_dict(self, o, suffix, level_net):
+        keys = ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'ray_mask']
+        if 'pixel_colors_gt' in o:
+            keys.append('pixel_colors_gt')
+        if self.cfg['render_depth']:
+            keys.append('render_depth')
+        out = {k + suffix: o[k] for k in keys}
+        out['sdf_gradient_error' + suffix] = o['sdf_gradient_error'].reshape(1, 1)
+        out['s' + suffix] = level_net.deviation_network.variance.reshape(1, 1)
+        return out
+
+    def render(self, que_imgs_info, ref_imgs_info, is_train):               # renderer.py:201-220 (+140-162)
+        if is_train:
+            raise NotImplementedError('training-mode rendering (random fine sampling, backward) is not built; '
+                                      'DESIGN.md §7')
+        co, fi = self.hot().render(self._batched_ref(ref_imgs_info), self._batched_que(que_imgs_info), self._render_cfg())
+        out = self._out_dict(co, '', self.agg_net)
+        out.update(self._out_dict(fi, '_fine', self.fine_agg_net))
+        return out
+
+    def render_by_depth(self, que_depth, que_imgs_info, ref_imgs_info, is_train, is_fine):   # renderer.py:110-138
+        o = self.hot().render_by_depth(self._batched_ref(ref_imgs_info), self._batched_que(que_imgs_info), que_depth,
+                                       'fine' if is_fine else 'coarse', self._render_cfg())
+        return self._out_dict(o, '', self.fine_agg_net if is_fine else self.agg_net)
+
+    def gen_depth_loss_coords(self, h, w, device):                          # renderer.py:222-228
+        idx = torch.randperm(h * w)[:self.cfg['depth_loss_coords_num']]     # CPU generator, like the reference
+        return torch.stack([idx // w, idx % w], -1).to(device)              # (row, col)
+
+    def predict_mean_for_depth_loss(self, ref_imgs_info):                   # renderer.py:230-266
+        h, w = ref_imgs_info['imgs'].shape[-2:]
+        rfn = ref_imgs_info['imgs'].shape[0]
+        coords = self.gen_depth_loss_coords(h, w, ref_imgs_info['imgs'].device)
+        # the reference feeds (row, col) where (x, y) is expected; kept
+        xy = coords.to(torch.float32)[None]
+        bref = self._batched_ref(ref_imgs_info)
+        hot = self.hot()
+        prep = hot.prepare(bref, 1)
+        mc = hot.depth_mean(bref, xy, 'coarse', prepared=prep)[0]
+        mf = hot.depth_mean(bref, xy, 'fine', prepared=prep)[0]
+        return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
+                'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]}
+
+    def forward(self, data):                                                # renderer.py:268-291
+        ref = dict(data['ref_imgs_info'])
+        que = dict(data['que_imgs_info'])
+        is_train = 'eval' not in data
+        ref['img_feats'] = self.image_encoder(ref['imgs'])
+        ref['ray_feats'] = self.init_net(ref, data.get('src_imgs_info'), is_train)
+        ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
+        out = {}
+        if self.cfg['render_rgb']:
+            out = self.render(que, ref, is_train)
+        if self.cfg.get('sample_volume', False):
+            out['volume'] = self.sample_volume(ref)
+        if (self.cfg.get('use_depth_loss', False) and 'true_depth' in ref) or (not is_train):
+            out.update(self.predict_mean_for_depth_loss(ref))
+        return out
+
+
+class GraspNeRF(nn.Module):
+    default_cfg_vgn = {'nr_initial_training_steps': 0, 'freeze_nr_after_init': False}
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = {**self.default_cfg_vgn, **cfg}
+        self.nr_net = NeuralRayRenderer(self.cfg)
+        self.vgn_net = ConvNet()                                            # gd.networks.get_network("conv")
+
+    @staticmethod
+    def select(out, index):                                                 # renderer.py:305-311
+        qual, rot, width = out
+        b = torch.arange(qual.shape[0])
+        i, j, k = index[:, 0], index[:, 1], index[:, 2]
+        return qual[b, :, i, j, k].squeeze(), rot[b, :, i, j, k], width[b, :, i, j, k].squeeze()
+
+    def forward(self, data):                                                # renderer.py:313-331
+        render_outputs = self.nr_net(data)
+        vgn_pred = self.vgn_net(render_outputs['volume'])
+        render_outputs['vgn_pred'] = vgn_pred if 'full_vol' in data else self.select(vgn_pred, data['grasp_info'][0])
+        return render_outputs
+
+
+name2network = {'grasp_nerf': GraspNeRF}

@@ -64,3 +64,30 @@ def make_scene(scene_id=0, cfg='cfg2', with_query_image=True):
     if with_query_image:
         que['imgs'] = imgs[:1].copy()
     return ref, que
+
+
+def synth_state_dict(shapes, seed=7):
+    """Deterministic, construction-order independent parameters for a whole GraspNeRF model:
+    every tensor is drawn from its own PCG64 stream keyed by crc32(name).  Used by the full-forward
+    golden (tools/make_goldens.py) and its tests, because 4.66 M parameters cannot be a fixture.
+    shapes: {state-dict key: shape}.  Weights ~ N(0, 1/fan_in), biases ~ N(0, 0.05^2), norm scales ~ 1 +- 0.1."""
+    import zlib
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        rng = np.random.default_rng([seed, zlib.crc32(k.encode())])
+        if k.endswith('variance'):
+            v = np.asarray(0.3, np.float32)
+        elif k.endswith(('imagenet_mean', 'imagenet_std')):
+            v = np.asarray([0.485, 0.456, 0.406] if k.endswith('mean') else [0.229, 0.224, 0.225], np.float32).reshape(shp)
+        elif len(shp) >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            v = (rng.standard_normal(shp) / np.sqrt(fan_in)).astype(np.float32)
+        elif 'bn' in k.split('.')[-2] or 'layer_norm' in k or k.endswith('.weight'):
+            # 1-D weights are normalisation scales
+            v = (1.0 + 0.1 * rng.standard_normal(shp)).astype(np.float32) if k.endswith('.weight') \
+                else (0.05 * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            v = (0.05 * rng.standard_normal(shp)).astype(np.float32)
+        out[k] = v
+    return out

@@ -119,6 +119,12 @@ int gnr_render_rays_fwd(const GnrScene* scene, const GnrRays* rays, const float*
                         const float* fine_depth_in, int* fine_inds_out, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* predict_mean_for_depth_loss (renderer.py:222-266) for one level: bilinear gather of ray_feats at
+ * `coords` [B,pn,2] (x,y in full-res pixels, shared by the V views of a scene; the caller keeps the
+ * reference's (row,col)-as-(x,y) quirk) + the decoder mean branch.  mean_out [B,V,pn,2]. */
+int gnr_depth_mean_fwd(const GnrScene* scene, const float* coords, int pn, const float* level_weights,
+                       float* mean_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Bring-up aid: per-point intermediates of the chain kernel on the volume points (column order,
  * top->down); dbg is [B*res^3][32] floats, layout documented at the definition (gnr_capi.inc). */
 int gnr_debug_volume_chain(const GnrScene* scene, const float* bbox_min, int volume_res,

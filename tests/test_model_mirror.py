@@ -1,0 +1,116 @@
+"""The reference-compatible model API (graspnerf_amd/renderer.py): checkpoint key compatibility and
+PyTorch-side backbones on CPU; full GraspNeRF.forward (backbones -> HIP hot path -> grasp head)
+against the imported reference's golden on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from graspnerf_amd.synth import make_scene, synth_state_dict
+from graspnerf_amd import weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the reference's only config (ref: src/nr/configs/nrvgn_sdf.yaml), network section, cfg1 sizes
+CFG = yaml.safe_load("""
+network: grasp_nerf
+init_net_type: cost_volume
+agg_net_type: neus
+use_hierarchical_sampling: true
+use_depth_loss: true
+dist_decoder_cfg: {use_vis: false}
+fine_dist_decoder_cfg: {use_vis: false}
+ray_batch_num: 4096
+sample_volume: true
+render_rgb: true
+volume_type: [sdf]
+volume_resolution: 16
+depth_sample_num: 16
+fine_depth_sample_num: 16
+agg_net_cfg: {sample_num: 16, init_s: 0.3, fix_s: 0}
+fine_agg_net_cfg: {sample_num: 16, init_s: 0.3, fix_s: 0}
+render_depth: true
+""")
+
+
+@pytest.fixture(scope='module')
+def model():
+    from graspnerf_amd.renderer import GraspNeRF
+    net = GraspNeRF(CFG).eval()
+    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()}, strict=True)
+    return net
+
+
+@pytest.fixture(scope='module')
+def G():
+    return dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_full_cfg1.npz')))
+
+
+def test_state_dict_keys_match_reference_checkpoint_layout(model):
+    """348 tensors / 4 656 264 values; hot-path keys are the ones weights.py consumes."""
+    sd = model.state_dict()
+    assert len(sd) == 348 and sum(v.numel() for v in sd.values()) == 4656264
+    for level in ('coarse', 'fine'):
+        for k, shape in weights.level_keys(level, 'nr_net.'):
+            assert tuple(sd[k].shape) == tuple(shape), k
+    assert 'nr_net.init_net.imagenet_mean' in sd and 'vgn_net.conv_rot.weight' in sd
+
+
+def test_backbones_match_reference_on_cpu(model, G):
+    ref, _ = make_scene(0, 'cfg1')
+    imgs = torch.from_numpy(ref['imgs'])
+    with torch.no_grad():
+        f = model.nr_net.image_encoder(imgs)
+        r = model.nr_net.vis_encoder(model.nr_net.init_net({'imgs': imgs}), f)
+    assert f.shape == (3, 32, 24, 32)
+    np.testing.assert_allclose(f.numpy()[:, :, ::2, ::2], G['img_feats_sub'], atol=2e-5)
+    np.testing.assert_allclose(r.numpy()[:, :, ::2, ::2], G['ray_feats_sub'], atol=2e-5)
+
+
+def test_unsupported_config_is_refused():
+    from graspnerf_amd.renderer import NeuralRayRenderer
+    with pytest.raises(NotImplementedError):
+        NeuralRayRenderer({**CFG, 'volume_type': ['alpha']})
+    with pytest.raises(NotImplementedError):
+        NeuralRayRenderer({**CFG, 'agg_net_type': 'default'})
+
+
+def test_select_gathers_grasp_voxels(model):
+    q, r, w = torch.rand(1, 1, 4, 4, 4), torch.rand(1, 4, 4, 4, 4), torch.rand(1, 1, 4, 4, 4)
+    idx = torch.tensor([[1, 2, 3]])
+    lab, rot, wid = model.select((q, r, w), idx)
+    assert lab == q[0, 0, 1, 2, 3] and torch.equal(rot[0], r[0, :, 1, 2, 3]) and wid == w[0, 0, 1, 2, 3]
+
+
+@pytest.mark.gpu
+def test_full_forward_matches_reference(model, G):
+    net = model.cuda()
+    ref, que = make_scene(0, 'cfg1')
+    t = lambda a: torch.from_numpy(a).cuda()
+    ref_info = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    data = {'step': 0, 'eval': True, 'full_vol': True, 'ref_imgs_info': ref_info, 'que_imgs_info': que_info,
+            'src_imgs_info': dict(ref_info)}
+    torch.manual_seed(123)
+    with torch.no_grad():
+        out = net(data)
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-3, atol=3e-4)
+    np.testing.assert_allclose(out['volume'].cpu().numpy(), G['volume'], **tol)
+    assert np.array_equal(out['depth_coords'][0].cpu().numpy(), G['depth_coords'].astype(np.int64))     # index-valued
+    assert out['depth_coords'].shape == (3, 8192, 2) and out['depth_coords'].dtype == torch.int64
+    for k in ('depth_mean', 'depth_mean_2', 'depth_mean_fine', 'depth_mean_fine_2'):
+        np.testing.assert_allclose(out[k].cpu().numpy()[:, ::4], G[k], **tol)
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'pixel_colors_nr'):
+        np.testing.assert_allclose(out[k].cpu().numpy(), G['render.' + k], **tol)
+    assert np.array_equal(out['ray_mask'].cpu().numpy(), G['render.ray_mask'])
+    assert out['s'].shape == (1, 1) and out['sdf_gradient_error_fine'].shape == (1, 1)
+    q, r, w = out['vgn_pred']
+    assert q.shape == (1, 1, 40, 40, 40) and r.shape == (1, 4, 40, 40, 40)
+    np.testing.assert_allclose(q.cpu().numpy()[..., ::2, ::2, ::2], G['vgn_qual_sub'], **tol)
+    np.testing.assert_allclose(r.cpu().numpy()[..., ::2, ::2, ::2], G['vgn_rot_sub'], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(w.cpu().numpy()[..., ::2, ::2, ::2], G['vgn_width_sub'], **tol)
