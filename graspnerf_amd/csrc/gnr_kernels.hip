@@ -308,7 +308,11 @@ DEV Taps make_taps(float u, float v, float sx, float sy, float off, int fh, int 
     return t;
 }
 
-constexpr int SW = 20;     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c rgb
+constexpr int SW = 20;
+#ifndef GNR_VIEW_UNROLL
+#define GNR_VIEW_UNROLL 1
+#endif
+constexpr int view_unroll(int V) { return (GNR_VIEW_UNROLL >= 3 && V % 3 == 0) ? 3 : ((GNR_VIEW_UNROLL >= 2 && V % 2 == 0) ? 2 : 1); }     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c rgb
 
 template <int V, bool RENDER>
 __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
     const int tps = (a.P + 15) >> 4;                       // tiles per scene
     const int ntiles = a.B * tps;
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
+    constexpr int UNR = view_unroll(V);
     const float fsx = (float)a.fw / (float)(a.W - 1), fsy = (float)a.fh / (float)(a.H - 1);
 
     for (int tile = blockIdx.x * waves_per_block + wave; tile < ntiles; tile += gridDim.x * waves_per_block) {
@@ -350,12 +355,20 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
         unsigned vbits = 0;
 
         // ================= phase 1: per view, everything up to the first cross-view reduction
+        // The view loop stays rolled (code size) but runs UNR views per trip, back to back (the
+        // sched_barrier keeps the copies from being interleaved, which would spill), so the per-view
+        // register file S is rotated once per trip instead of once per view.
 #pragma unroll 1
-        for (int v = 0; v < V; ++v) {
+        for (int v0 = 0; v0 < V; v0 += UNR) {
 #pragma unroll
-            for (int k = 0; k < V - 1; ++k)
+            for (int k = 0; k < V - UNR; ++k)
 #pragma unroll
-                for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
+                for (int q = 0; q < SW; ++q) S[k][q] = S[k + UNR][q];
+#pragma unroll
+          for (int vu = 0; vu < UNR; ++vu) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int v = v0 + vu;
+            float (&Sv)[SW] = S[V - UNR + vu];
             const int bv = b * V + v;
             const float* vp = a.viewp + bv * VIEWP_FLOATS;
             ViewGeom vg;
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                 const float rgb = (ib[ti.o00] * ti.w00 + ib[ti.o01] * ti.w01 + ib[ti.o10] * ti.w10 + ib[ti.o11] * ti.w11) * m;
                 XI[8] = g < 3 ? rgb : 0.f;
             }
-            S[V - 1][19] = XI[8];                              // raw rgb for the colour blend
+            Sv[19] = XI[8];                              // raw rgb for the colour blend
 
             // ---- mixture-of-logistics decoder (dist_decoder.py:99-142)
             float o5[5];
@@ -439,8 +452,8 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                 mm<8, 2>(lds + pk::PE2, lane, e1, acc);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    S[V - 1][9 + nb * 4 + 0] = acc[nb].x; S[V - 1][9 + nb * 4 + 1] = acc[nb].y;
-                    S[V - 1][9 + nb * 4 + 2] = acc[nb].z; S[V - 1][9 + nb * 4 + 3] = acc[nb].w;
+                    Sv[9 + nb * 4 + 0] = acc[nb].x; Sv[9 + nb * 4 + 1] = acc[nb].y;
+                    Sv[9 + nb * 4 + 2] = acc[nb].z; Sv[9 + nb * 4 + 3] = acc[nb].w;
                 }
             }
             // ---- x = [rgb, img_feats] + ray_dir_fc(dir_diff)  (ibrnet.py:457-459)
@@ -455,21 +468,22 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                 mm<4, 3>(lds + pk::RDF2, lane, d1, acc3);
                 elu_to<3>(acc3, df);
 #pragma unroll
-                for (int j = 0; j < 9; ++j) S[V - 1][j] = fmaf(df[j], kLn2, XI[j]);
+                for (int j = 0; j < 9; ++j) Sv[j] = fmaf(df[j], kLn2, XI[j]);
             }
             // ---- gate of the first weighted mean/var: sigmoid(neuray_fc(e))  (ibrnet.py:469)
             {
                 f4 acc1[1];
                 float e[8], n1[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = S[V - 1][9 + j];
+                for (int j = 0; j < 8; ++j) e[j] = Sv[9 + j];
                 load_bias<1>(lds + pk::B_NR1, g, acc1);
                 mm<8, 1>(lds + pk::NR1, lane, e, acc1);
                 elu_to<1>(acc1, n1);
-                S[V - 1][17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
+                Sv[17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
             }
-            S[V - 1][18] = m;
+            Sv[18] = m;
             if (a.dbg && g == 0 && row_ok) { a.dbg[pt * 32 + v] = hit; a.dbg[pt * 32 + 8 + v] = vis; }
+        }
         }
 
         // ================= cross-view reduction 1 (ibrnet.py:466-472), in-lane
@@ -504,17 +518,28 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
         // ================= phase 2: per view, base_fc / vis_fc / vis_fc2 (/ rgb_fc)
         float vsum = 0.f;
 #pragma unroll 1
-        for (int v = 0; v < V; ++v) {
-            float X[9], E[8];
+        for (int v0 = 0; v0 < V; v0 += UNR) {
+          float X2[UNR][9], E2[UNR][8], m2[UNR], rgb2[UNR];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) X[j] = S[0][j];
+          for (int vu = 0; vu < UNR; ++vu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) E[j] = S[0][9 + j];
-            const float m = S[0][18], rgbraw = S[0][19];
+            for (int j = 0; j < 9; ++j) X2[vu][j] = S[vu][j];
 #pragma unroll
-            for (int k = 0; k < V - 1; ++k)
+            for (int j = 0; j < 8; ++j) E2[vu][j] = S[vu][9 + j];
+            m2[vu] = S[vu][18]; rgb2[vu] = S[vu][19];
+          }
 #pragma unroll
-                for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
+            for (int k = 0; k < V - UNR; ++k)
+#pragma unroll
+                for (int q = 0; q < SW; ++q) S[k][q] = S[k + UNR][q];
+#pragma unroll
+          for (int vu = 0; vu < UNR; ++vu) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int v = v0 + vu;
+            float (&X)[9] = X2[vu];
+            float (&E)[8] = E2[vu];
+            const float m = m2[vu], rgbraw = rgb2[vu];
+            float (&Sv)[SW] = S[V - UNR + vu];
             const float w = m * inv_msum;
             float Hh[8];
             {
@@ -576,11 +601,12 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                 if (m == 0.f) clog = -1e9f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) S[V - 1][j] = Hh[j];
-            S[V - 1][8] = v2;
-            S[V - 1][9] = clog;
-            S[V - 1][10] = rgbraw;
+            for (int j = 0; j < 8; ++j) Sv[j] = Hh[j];
+            Sv[8] = v2;
+            Sv[9] = clog;
+            Sv[10] = rgbraw;
             if (a.dbg && g == 0 && row_ok) a.dbg[pt * 32 + 16 + v] = v2;
+        }
         }
 
         // ================= cross-view reduction 2 (ibrnet.py:482-484,488) + colour blend (:510-511)
@@ -726,7 +752,8 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
     const float* rec = a.rec + pt * REC;
     const float* W = a.wpk;
-    constexpr int UA = RENDER ? GNR_RAY_UNROLL : 4;       // key-loop unroll (register pressure vs LDS latency)
+    constexpr int UB = GNR_RAY_UNROLL;                    // (no measurable effect: the kernel is VALU-throughput bound)
+    constexpr int UA = RENDER ? UB : 4;                   // key-loop unroll (register pressure vs LDS latency)
 
     float g16[16], t[16];
     {
@@ -871,7 +898,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             float A1[16], B1[16];
 #pragma unroll
             for (int f = 0; f < 16; ++f) { A1[f] = 0.f; B1[f] = 0.f; }
-#pragma unroll GNR_RAY_UNROLL
+#pragma unroll UB
             for (int j = 0; j < dn; ++j) {
                 float sj[4];
                 head_logits(q, Kb + j * 16, rowok, sj);
@@ -911,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         float dK[16], dV[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) { dK[f] = 0.f; dV[f] = 0.f; }
-#pragma unroll GNR_RAY_UNROLL
+#pragma unroll UB
         for (int qi = 0; qi < dn; ++qi) {
             const bool ok = (okmask >> qi) & 1ull;
             const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
