@@ -35,6 +35,18 @@ def chain_flops(points, views, render):
     return 2.0 * points * (views * (MAC_VIEW_RAY if render else MAC_VIEW_VOL) + MAC_POINT_CHAIN)
 
 
+def recorded_traffic(batch):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
+    (profiles/r01_pmc_counters.json: separate --pmc runs of FETCH_SIZE and WRITE_SIZE, gfx950 2x read
+    correction applied).  PMC counters cannot be read from inside this process, so the figure is the
+    recorded one and only reported for the batch size it was measured at."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_counters.json')))
+        return rec['k_chain_volume_traffic_bytes_per_launch'] if batch == 32 else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(weights_np, budget_s=25.0):
     """The oracle (torch-CPU fp32 port of the reference path) timed on this box's host cores on a
     bounded sample: whole scenes of the same workload (volume + 512-ray render)."""
@@ -135,7 +147,7 @@ def main():
                                    f'(BASELINE.json configs[2]/[3])',
                        'global_batch': world * B, 'parallelism': f'scene-sharded x{world}, no data-path collective'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': recorded_traffic(B),
                          'kernel': 'k_chain<6,false> on the volume points', 'ms_per_launch': round(ms, 4),
                          'flops_per_launch': fl,
                          'note': 'algorithmic (un-hoisted) fp32 FLOPs: 2*(6*27736+6528) per point, SURVEY.md §8d'},

@@ -260,6 +260,7 @@ struct ChainArgs {
     unsigned char* vmask;  // [B*P] or null
     float* dbg;            // [B*P][32] or null
     int B, P, H, W, fh, fw;
+    int vol_res;           // volume launches: grid resolution R (tile order is brick-permuted); 0 for ray points
 };
 
 struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
@@ -335,9 +336,30 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
     constexpr int UNR = view_unroll(V);
     const float fsx = (float)a.fw / (float)(a.W - 1), fsy = (float)a.fh / (float)(a.H - 1);
 
-    for (int tile = blockIdx.x * waves_per_block + wave; tile < ntiles; tile += gridDim.x * waves_per_block) {
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on
+    // it).  Each XCD sweeps its own contiguous eighth of the tile list, so consecutive tiles (= neighbouring
+    // voxels / ray samples, i.e. neighbouring feature-map lines) share ONE L2 instead of being fetched into
+    // all eight (measured before this: 7.7 GB fetched per launch against 0.8 GB of inputs).
+    constexpr int NXCD = 8;
+    const int xcd = blockIdx.x % NXCD, lblk = blockIdx.x / NXCD;
+    const int nlblk = ((int)gridDim.x - xcd + NXCD - 1) / NXCD;            // workgroups that share this XCD
+    const int chunk = (ntiles + NXCD - 1) / NXCD;
+    const int t_end = min(ntiles, (xcd + 1) * chunk);
+    for (int tile = xcd * chunk + lblk * waves_per_block + wave; tile < t_end; tile += nlblk * waves_per_block) {
         const int b = tile / tps;
-        const int n_raw = (tile - b * tps) * 16 + r;
+        int ts = tile - b * tps;
+        if (a.vol_res > 0) {
+            // Volume points are stored column-major (x, y, then z top->down).  Visit them in bricks of 4x4
+            // columns instead of whole x-planes: the feature-map footprint of the ~256 tiles in flight on an
+            // XCD then fits its 4 MiB L2 (an x-plane of the 40^3 grid covers ~8 MB of feature lines).
+            // Bijection on 2-column groups (2R points = R/8 tiles); requires R % 8 == 0 (host checks).
+            const int R = a.vol_res, tpg = R >> 3, gpr = R >> 1, bpb = R >> 2;
+            const int sidx = ts / tpg, tin = ts - sidx * tpg;
+            const int brick = sidx >> 3, wi = sidx & 7;
+            const int bx = brick / bpb, by = brick - bx * bpb;
+            ts = ((4 * bx + (wi >> 1)) * gpr + 2 * by + (wi & 1)) * tpg + tin;
+        }
+        const int n_raw = ts * 16 + r;
         const bool row_ok = n_raw < a.P;
         const int n = row_ok ? n_raw : a.P - 1;
         const size_t pt = (size_t)b * a.P + n;
