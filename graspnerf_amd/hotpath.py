@@ -152,7 +152,7 @@ class HotPath:
         o['ray_mask'] = o['ray_mask'].bool()
         return o
 
-    def depth_mean(self, ref, coords, level='coarse', prepared=None):
+    def depth_mean(self, ref, coords, level='coarse', prepared=None):   # noqa: D401
         """predict_mean_for_depth_loss for one level: coords [B,pn,2] (x,y) -> mean [B,V,pn,2]."""
         scene, keep, ws = prepared or self.prepare(ref, 1)
         coords = _f32(coords, self.device)

@@ -132,9 +132,16 @@ class NeuralRayRenderer(nn.Module):
     @staticmethod
     def _batched_ref(ref):
         out = {k: ref[k][None] for k in ('imgs', 'img_feats', 'ray_feats', 'poses', 'Ks', 'depth_range')}
-        out['bbox3d'] = torch.as_tensor(np.asarray(ref['bbox3d'].cpu() if torch.is_tensor(ref['bbox3d']) else ref['bbox3d']),
-                                        dtype=torch.float32)[None]
+        bb = ref['bbox3d']
+        out['bbox3d'] = (bb if torch.is_tensor(bb) else torch.as_tensor(np.asarray(bb), dtype=torch.float32))[None]
         return out
+
+    def _prepare(self, ref_imgs_info, rn=0):
+        """Feature-map repack + view blocks once per forward; shared by volume / render / depth-mean."""
+        c = self.cfg
+        bref = self._batched_ref(ref_imgs_info)
+        return bref, self.hot().prepare(bref, c.get('volume_resolution', 40), rn,
+                                        max(c['depth_sample_num'], c['fine_depth_sample_num']))
 
     @staticmethod
     def _batched_que(que):
@@ -149,8 +156,9 @@ class NeuralRayRenderer(nn.Module):
                 'ray_mask_view_num': c['ray_mask_view_num'], 'ray_mask_point_num': c['ray_mask_point_num']}
 
     # ---- the reference's methods ------------------------------------------------------------------
-    def sample_volume(self, ref_imgs_info):                                 # renderer.py:164-199
-        return self.hot().sample_volume(self._batched_ref(ref_imgs_info), self.cfg['volume_resolution'])
+    def sample_volume(self, ref_imgs_info, _prep=None):                     # renderer.py:164-199
+        bref, prep = _prep or self._prepare(ref_imgs_info)
+        return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
 
     def _out_dict(self, o, suffix, level_net):
         keys = ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'ray_mask']
@@ -163,11 +171,12 @@ class NeuralRayRenderer(nn.Module):
         out['s' + suffix] = level_net.deviation_network.variance.reshape(1, 1)
         return out
 
-    def render(self, que_imgs_info, ref_imgs_info, is_train):               # renderer.py:201-220 (+140-162)
+    def render(self, que_imgs_info, ref_imgs_info, is_train, _prep=None):   # renderer.py:201-220 (+140-162)
         if is_train:
             raise NotImplementedError('training-mode rendering (random fine sampling, backward) is not built; '
                                       'DESIGN.md §7')
-        co, fi = self.hot().render(self._batched_ref(ref_imgs_info), self._batched_que(que_imgs_info), self._render_cfg())
+        bref, prep = _prep or self._prepare(ref_imgs_info, que_imgs_info['coords'].shape[1])
+        co, fi = self.hot().render(bref, self._batched_que(que_imgs_info), self._render_cfg(), prepared=prep)
         out = self._out_dict(co, '', self.agg_net)
         out.update(self._out_dict(fi, '_fine', self.fine_agg_net))
         return out
@@ -181,15 +190,14 @@ class NeuralRayRenderer(nn.Module):
         idx = torch.randperm(h * w)[:self.cfg['depth_loss_coords_num']]     # CPU generator, like the reference
         return torch.stack([idx // w, idx % w], -1).to(device)              # (row, col)
 
-    def predict_mean_for_depth_loss(self, ref_imgs_info):                   # renderer.py:230-266
+    def predict_mean_for_depth_loss(self, ref_imgs_info, _prep=None):       # renderer.py:230-266
         h, w = ref_imgs_info['imgs'].shape[-2:]
         rfn = ref_imgs_info['imgs'].shape[0]
         coords = self.gen_depth_loss_coords(h, w, ref_imgs_info['imgs'].device)
         # the reference feeds (row, col) where (x, y) is expected; kept
         xy = coords.to(torch.float32)[None]
-        bref = self._batched_ref(ref_imgs_info)
+        bref, prep = _prep or self._prepare(ref_imgs_info)
         hot = self.hot()
-        prep = hot.prepare(bref, 1)
         mc = hot.depth_mean(bref, xy, 'coarse', prepared=prep)[0]
         mf = hot.depth_mean(bref, xy, 'fine', prepared=prep)[0]
         return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
@@ -203,12 +211,13 @@ class NeuralRayRenderer(nn.Module):
         ref['ray_feats'] = self.init_net(ref, data.get('src_imgs_info'), is_train)
         ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
         out = {}
+        prep = self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
         if self.cfg['render_rgb']:
-            out = self.render(que, ref, is_train)
+            out = self.render(que, ref, is_train, _prep=prep)
         if self.cfg.get('sample_volume', False):
-            out['volume'] = self.sample_volume(ref)
+            out['volume'] = self.sample_volume(ref, _prep=prep)
         if (self.cfg.get('use_depth_loss', False) and 'true_depth' in ref) or (not is_train):
-            out.update(self.predict_mean_for_depth_loss(ref))
+            out.update(self.predict_mean_for_depth_loss(ref, _prep=prep))
         return out
 
 
