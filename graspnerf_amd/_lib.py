@@ -75,6 +75,16 @@ def lib():
                                       C.POINTER(GnrRenderOut), C.POINTER(GnrRenderOut), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_render_rays_fwd.restype = C.c_int
+    L.gnr_head_canonical_floats.restype = C.c_int
+    L.gnr_head_packed_floats.restype = C.c_int
+    L.gnr_pack_grasp_head.argtypes = [c_float_p, c_float_p]
+    L.gnr_pack_grasp_head.restype = C.c_int
+    L.gnr_grasp_head_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    L.gnr_grasp_head_workspace_bytes.restype = C.c_size_t
+    L.gnr_grasp_head_fwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_grasp_head_fwd.restype = C.c_int
+    L.gnr_head_last_error.restype = C.c_char_p
     L.gnr_time_chain_kernel.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                         c_float_p, C.c_void_p]
     L.gnr_time_chain_kernel.restype = C.c_int
@@ -86,7 +96,9 @@ def lib():
 
 EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_layout_offset', 'gnr_workspace_bytes',
             'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
-            'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel']
+            'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
+            'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
+            'gnr_head_last_error']
 
 
 def check(rc, what):

@@ -1,0 +1,284 @@
+// VGN grasp head (ref: src/gd/networks.py:39-97) as fp32 implicit-GEMM 3D
+// convolutions on v_mfma_f32_16x16x4_f32.  "MFMA only for the 3D conv's im2col GEMM where it is a true
+// dense contraction" (BASELINE.json north_star) -- this is that contraction.
+//
+//   enc: conv(1->16,k5,s2)+ReLU, conv(16->32,k3,s2)+ReLU, conv(32->64,k3,s2)+ReLU
+//   dec: conv(64->64,k3)+ReLU, nearest->10, conv(64->32,k3)+ReLU, nearest->20, conv(32->16,k5)+ReLU, nearest->40
+//   heads (k5): qual = sigmoid(conv 16->1), rot = normalize(conv 16->4), width = conv 16->1
+//
+// Kernel k_conv3d: one wavefront = one 4x4x4 brick of output voxels (4 MFMA column tiles of 4x4 voxels, one
+// per z) x all output channels.  D[cout][voxel] = sum_{tap,cin} W[cout][cin][tap] * In[cin][src(voxel*s+tap-p)]
+// with the weight fragment as the MFMA A operand and the gathered input as B; the k order is tap-major /
+// cin-minor so a k-step (4 input channels of ONE tap) shares its spatial address and bounds test, and the
+// nearest-neighbour upsampling in front of a conv is folded into src() (never materialised).  Inputs are
+// a few hundred KB per scene and stay cache resident, so the B operand is gathered straight from global
+// memory; A fragments are pre-packed [tap][cin/4][cout/16][64 lanes] and read coalesced.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+
+#include "../../include/gnr.h"
+
+namespace gnrh {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define DEV __device__ __forceinline__
+DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int NLAYER = 7;
+struct LayerDesc { int cin, cout, k, stride, off_w, off_b; };   // canonical offsets (floats)
+// canonical blob = ConvNet state-dict order (networks.py:39-47): encoder.conv{1,2,3}, decoder.conv{1,2,3},
+// conv_qual, conv_rot, conv_width, each .weight then .bias
+constexpr int w_sz(int co, int ci, int k) { return co * ci * k * k * k; }
+constexpr int C_E1W = 0, C_E1B = C_E1W + w_sz(16, 1, 5), C_E2W = C_E1B + 16, C_E2B = C_E2W + w_sz(32, 16, 3);
+constexpr int C_E3W = C_E2B + 32, C_E3B = C_E3W + w_sz(64, 32, 3), C_D1W = C_E3B + 64, C_D1B = C_D1W + w_sz(64, 64, 3);
+constexpr int C_D2W = C_D1B + 64, C_D2B = C_D2W + w_sz(32, 64, 3), C_D3W = C_D2B + 32, C_D3B = C_D3W + w_sz(16, 32, 5);
+constexpr int C_QW = C_D3B + 16, C_QB = C_QW + w_sz(1, 16, 5), C_RW = C_QB + 1, C_RB = C_RW + w_sz(4, 16, 5);
+constexpr int C_WW = C_RB + 4, C_WB = C_WW + w_sz(1, 16, 5), C_TOTAL = C_WB + 1;
+
+// packed blob: layer 0 (cin = 1) keeps its canonical weights (VALU kernel); layers 1..6 are A fragments
+// [tap][cin/4][cout_blocks][64] followed by a bias block [cout_blocks*16]
+constexpr int frag_sz(int co, int ci, int k) { return k * k * k * (ci / 4) * ((co + 15) / 16) * 64; }
+constexpr int P_E1 = 0, P_E2 = P_E1 + w_sz(16, 1, 5) + 16, P_E3 = P_E2 + frag_sz(32, 16, 3) + 32;
+constexpr int P_D1 = P_E3 + frag_sz(64, 32, 3) + 64, P_D2 = P_D1 + frag_sz(64, 64, 3) + 64;
+constexpr int P_D3 = P_D2 + frag_sz(32, 64, 3) + 32, P_HD = P_D3 + frag_sz(16, 32, 5) + 16;
+constexpr int P_TOTAL = P_HD + frag_sz(16, 16, 5) + 16;
+
+// ---- layer 0: 1 -> 16 channels, k5, stride 2, ReLU; one thread per output voxel (16 MMAC per scene) -------
+__global__ __launch_bounds__(256) void k_conv_first(const float* __restrict__ vol, const float* __restrict__ wb,
+                                                    float* __restrict__ out, int Din, int Dout, int B) {
+    const int n = Dout * Dout * Dout;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * n) return;
+    const int b = i / n, v = i - b * n;
+    const int z = v / (Dout * Dout), y = (v / Dout) % Dout, x = v % Dout;
+    const float* in = vol + (size_t)b * Din * Din * Din;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = wb[16 * 125 + c];
+    for (int tz = 0; tz < 5; ++tz) {
+        const int iz = 2 * z + tz - 2;
+        for (int ty = 0; ty < 5; ++ty) {
+            const int iy = 2 * y + ty - 2;
+#pragma unroll
+            for (int tx = 0; tx < 5; ++tx) {
+                const int ix = 2 * x + tx - 2;
+                const bool ok = (unsigned)iz < (unsigned)Din && (unsigned)iy < (unsigned)Din && (unsigned)ix < (unsigned)Din;
+                const float val = ok ? in[(iz * Din + iy) * Din + ix] : 0.f;
+                const int tap = (tz * 5 + ty) * 5 + tx;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(wb[c * 125 + tap], val, acc[c]);
+            }
+        }
+    }
+    float* o = out + (size_t)b * 16 * n + v;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[(size_t)c * n] = fmaxf(acc[c], 0.f);
+}
+
+// nearest-neighbour source index of F.interpolate(x, size): min(floor(dst * in/out), in-1)   (networks.py:88-96)
+__global__ void k_umaps(int* __restrict__ um, int d3) {
+    const int i = threadIdx.x;
+    if (i < 10) um[i] = min((int)floorf(i * ((float)d3 / 10.f)), d3 - 1);
+    else if (i < 30) um[i] = min((int)floorf((i - 10) * (10.f / 20.f)), 9);
+    else if (i < 70) um[i] = min((int)floorf((i - 30) * (20.f / 40.f)), 19);
+}
+
+struct ConvArgs {
+    const float* in;      // [B][CIN][Din^3]
+    const float* wfrag;   // [taps][CIN/4][NB][64]
+    const float* bias;    // [NB*16]
+    const int* umap;      // [Deff] source index of each (virtually upsampled) input coordinate, or null
+    float* out;           // [B][COUT][Dout^3]           (EPI 0)
+    float *qual, *rot, *width;   // heads               (EPI 1)
+    int B, Din, Deff, Dout, cout;
+};
+
+// EPI 0: bias + ReLU -> out ; EPI 1: heads (packed channel order rot0..3, qual, width)
+template <int CIN, int NB, int KS, int STRIDE, int EPI>
+__global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
+    constexpr int PAD = KS / 2, C4 = CIN / 4;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int nbr = (a.Dout + 3) >> 2;                         // bricks per axis
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= a.B * nbr * nbr * nbr) return;
+    const int b = task / (nbr * nbr * nbr), br = task - b * nbr * nbr * nbr;
+    const int bz = br / (nbr * nbr), by = (br / nbr) % nbr, bx = br % nbr;
+    const int ox = bx * 4 + (r & 3), oy = by * 4 + (r >> 2);
+    const int Din = a.Din, Din3 = Din * Din * Din;
+    const float* in = a.in + (size_t)b * CIN * Din3 + (size_t)g * Din3;     // lane group g = input channel 4c+g
+
+    f4 acc[4][NB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[nb * 4 + g];
+
+    const float* wf = a.wfrag + lane;
+    for (int tz = 0; tz < KS; ++tz) {
+        int zoff[4];
+        bool zok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int iz = (bz * 4 + t) * STRIDE + tz - PAD;
+            zok[t] = (unsigned)iz < (unsigned)a.Deff;
+            const int izc = zok[t] ? iz : 0;
+            zoff[t] = (a.umap ? a.umap[izc] : izc) * Din * Din;
+        }
+        for (int ty = 0; ty < KS; ++ty) {
+            const int iy = oy * STRIDE + ty - PAD;
+            const bool yok = (unsigned)iy < (unsigned)a.Deff;
+            const int iyc = yok ? iy : 0;
+            const int yoff = (a.umap ? a.umap[iyc] : iyc) * Din;
+#pragma unroll 1
+            for (int tx = 0; tx < KS; ++tx) {
+                const int ix = ox * STRIDE + tx - PAD;
+                const bool xok = yok && (unsigned)ix < (unsigned)a.Deff;
+                const int ixc = (unsigned)ix < (unsigned)a.Deff ? ix : 0;
+                const int xyoff = yoff + (a.umap ? a.umap[ixc] : ixc);
+                const float* wt = wf + (size_t)((tz * KS + ty) * KS + tx) * C4 * NB * 64;
+#pragma unroll
+                for (int c = 0; c < C4; ++c) {
+                    float av[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) av[nb] = wt[(c * NB + nb) * 64];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float v = in[(size_t)(4 * c) * Din3 + zoff[t] + xyoff];
+                        const float bv = (xok && zok[t]) ? v : 0.f;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(av[nb], bv, acc[t][nb]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue: lane (voxel r of tile t, group g) holds output channels 16*nb + 4*g + {0..3}
+    const int D = a.Dout, n = D * D * D;
+    const bool xyok = ox < D && oy < D;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int oz = bz * 4 + t;
+        if (!xyok || oz >= D) continue;
+        const int v = (oz * D + oy) * D + ox;
+        if constexpr (EPI == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float* o = a.out + ((size_t)b * a.cout + 16 * nb + 4 * g) * n + v;
+                o[0] = fmaxf(acc[t][nb].x, 0.f); o[(size_t)n] = fmaxf(acc[t][nb].y, 0.f);
+                o[(size_t)2 * n] = fmaxf(acc[t][nb].z, 0.f); o[(size_t)3 * n] = fmaxf(acc[t][nb].w, 0.f);
+            }
+        } else {
+            const f4 x = acc[t][0];
+            if (g == 0) {                                     // rot: F.normalize(dim=1), eps 1e-12 (networks.py:52)
+                const float nr = fmaxf(sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w), 1e-12f);
+                float* o = a.rot + (size_t)b * 4 * n + v;
+                o[0] = x.x / nr; o[(size_t)n] = x.y / nr; o[(size_t)2 * n] = x.z / nr; o[(size_t)3 * n] = x.w / nr;
+            } else if (g == 1) {
+                a.qual[(size_t)b * n + v] = 1.f / (1.f + __expf(-x.x));   // networks.py:51
+                a.width[(size_t)b * n + v] = x.y;                         // networks.py:53
+            }
+        }
+    }
+}
+
+}  // namespace gnrh
+
+using namespace gnrh;
+
+extern "C" int gnr_head_canonical_floats(void) { return C_TOTAL; }
+extern "C" int gnr_head_packed_floats(void) { return P_TOTAL; }
+
+static void pack_conv(float* dst, const float* W, const float* bias, int cout, int cin, int k, int cout_pad_map(int)) {
+    const int taps = k * k * k, C4 = cin / 4, NB = (cout + 15) / 16;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int c = 0; c < C4; ++c)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int o = cout_pad_map(16 * nb + (lane & 15)), ci = 4 * c + (lane >> 4);
+                    dst[((tap * C4 + c) * NB + nb) * 64 + lane] = (o >= 0 && o < cout) ? W[((size_t)o * cin + ci) * taps + tap] : 0.f;
+                }
+    float* bd = dst + (size_t)taps * C4 * NB * 64;
+    for (int i = 0; i < NB * 16; ++i) { const int o = cout_pad_map(i); bd[i] = (o >= 0 && o < cout) ? bias[o] : 0.f; }
+}
+
+extern "C" int gnr_pack_grasp_head(const float* c, float* p) {
+    if (!c || !p) return GNR_ERR_ARG;
+    for (int i = 0; i < P_TOTAL; ++i) p[i] = 0.f;
+    for (int i = 0; i < w_sz(16, 1, 5); ++i) p[P_E1 + i] = c[C_E1W + i];
+    for (int i = 0; i < 16; ++i) p[P_E1 + w_sz(16, 1, 5) + i] = c[C_E1B + i];
+    auto ident = [](int o) { return o; };
+    pack_conv(p + P_E2, c + C_E2W, c + C_E2B, 32, 16, 3, ident);
+    pack_conv(p + P_E3, c + C_E3W, c + C_E3B, 64, 32, 3, ident);
+    pack_conv(p + P_D1, c + C_D1W, c + C_D1B, 64, 64, 3, ident);
+    pack_conv(p + P_D2, c + C_D2W, c + C_D2B, 32, 64, 3, ident);
+    pack_conv(p + P_D3, c + C_D3W, c + C_D3B, 16, 32, 5, ident);
+    // heads fused into one 16->6 conv; packed channel order: rot0..3, qual, width
+    static float hw[6 * 16 * 125], hb[6];
+    for (int o = 0; o < 4; ++o) { for (int i = 0; i < 2000; ++i) hw[o * 2000 + i] = c[C_RW + o * 2000 + i]; hb[o] = c[C_RB + o]; }
+    for (int i = 0; i < 2000; ++i) { hw[4 * 2000 + i] = c[C_QW + i]; hw[5 * 2000 + i] = c[C_WW + i]; }
+    hb[4] = c[C_QB]; hb[5] = c[C_WB];
+    pack_conv(p + P_HD, hw, hb, 6, 16, 5, ident);
+    return GNR_OK;
+}
+
+static thread_local char h_err[256] = "";
+extern "C" const char* gnr_head_last_error(void) { return h_err; }
+#define HCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(h_err, sizeof(h_err), "%s: %s", #call, hipGetErrorString(e_)); return GNR_ERR_HIP; } } while (0)
+
+extern "C" size_t gnr_grasp_head_workspace_bytes(int B, int R) {
+    const int d1 = (R - 1) / 2 + 1, d2 = (d1 - 1) / 2 + 1, d3 = (d2 - 1) / 2 + 1;
+    size_t fl = (size_t)16 * d1 * d1 * d1 + (size_t)32 * d2 * d2 * d2 + 2 * (size_t)64 * d3 * d3 * d3 + 32 * 1000 + 16 * 8000;
+    return (size_t)B * fl * sizeof(float) + 4096;
+}
+
+template <int CIN, int NB, int KS, int STRIDE, int EPI>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+    const int nbr = (a.Dout + 3) / 4;
+    const long tasks = (long)a.B * nbr * nbr * nbr;
+    hipLaunchKernelGGL((k_conv3d<CIN, NB, KS, STRIDE, EPI>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
+    return GNR_OK;
+}
+
+// ConvNet.forward (networks.py:48-54).  volume [B,1,R,R,R]; outputs qual [B,1,40,40,40], rot [B,4,40^3], width [B,1,40^3]
+// (the reference interpolates to the fixed sizes 10/20/40 whatever R is, networks.py:88-96).
+extern "C" int gnr_grasp_head_fwd(int B, int R, const float* volume, const float* packed, float* qual, float* rot, float* width,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    if (!volume || !packed || !qual || !rot || !width || !ws) { snprintf(h_err, sizeof(h_err), "gnr_grasp_head_fwd: null pointer"); return GNR_ERR_ARG; }
+    if (B < 1 || R < 8 || R > 64) { snprintf(h_err, sizeof(h_err), "gnr_grasp_head_fwd: bad B/R"); return GNR_ERR_SHAPE; }
+    if (ws_bytes < gnr_grasp_head_workspace_bytes(B, R)) { snprintf(h_err, sizeof(h_err), "workspace too small"); return GNR_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int d1 = (R - 1) / 2 + 1, d2 = (d1 - 1) / 2 + 1, d3 = (d2 - 1) / 2 + 1;      // conv k, s2, pad k/2
+    float* a1 = (float*)ws;                                   // [B][16][d1^3]
+    float* a2 = a1 + (size_t)B * 16 * d1 * d1 * d1;           // [B][32][d2^3]
+    float* a3 = a2 + (size_t)B * 32 * d2 * d2 * d2;           // [B][64][d3^3]
+    float* a4 = a3 + (size_t)B * 64 * d3 * d3 * d3;           // [B][64][d3^3]
+    float* a5 = a4 + (size_t)B * 64 * d3 * d3 * d3;           // [B][32][10^3]
+    float* a6 = a5 + (size_t)B * 32 * 1000;                   // [B][16][20^3]
+    int* umaps = (int*)(a6 + (size_t)B * 16 * 8000);          // 3 nearest-neighbour index maps
+    hipLaunchKernelGGL(k_umaps, dim3(1), dim3(128), 0, st, umaps, d3);
+    HCHK(hipGetLastError());
+    {
+        const int n = B * d1 * d1 * d1;
+        hipLaunchKernelGGL(k_conv_first, dim3((n + 255) / 256), dim3(256), 0, st, volume, packed + P_E1, a1, R, d1, B);
+        HCHK(hipGetLastError());
+    }
+    ConvArgs c{};
+    c.B = B;
+    int rc;
+    c.in = a1; c.wfrag = packed + P_E2; c.bias = c.wfrag + frag_sz(32, 16, 3); c.umap = nullptr; c.out = a2; c.Din = d1; c.Deff = d1; c.Dout = d2; c.cout = 32;
+    if ((rc = launch_conv<16, 2, 3, 2, 0>(c, st))) return rc;
+    c.in = a2; c.wfrag = packed + P_E3; c.bias = c.wfrag + frag_sz(64, 32, 3); c.out = a3; c.Din = d2; c.Deff = d2; c.Dout = d3; c.cout = 64;
+    if ((rc = launch_conv<32, 4, 3, 2, 0>(c, st))) return rc;
+    c.in = a3; c.wfrag = packed + P_D1; c.bias = c.wfrag + frag_sz(64, 64, 3); c.out = a4; c.Din = d3; c.Deff = d3; c.Dout = d3; c.cout = 64;
+    if ((rc = launch_conv<64, 4, 3, 1, 0>(c, st))) return rc;
+    c.in = a4; c.wfrag = packed + P_D2; c.bias = c.wfrag + frag_sz(32, 64, 3); c.umap = umaps; c.out = a5; c.Din = d3; c.Deff = 10; c.Dout = 10; c.cout = 32;
+    if ((rc = launch_conv<64, 2, 3, 1, 0>(c, st))) return rc;
+    c.in = a5; c.wfrag = packed + P_D3; c.bias = c.wfrag + frag_sz(16, 32, 5); c.umap = umaps + 10; c.out = a6; c.Din = 10; c.Deff = 20; c.Dout = 20; c.cout = 16;
+    if ((rc = launch_conv<32, 1, 5, 1, 0>(c, st))) return rc;
+    c.in = a6; c.wfrag = packed + P_HD; c.bias = c.wfrag + frag_sz(16, 16, 5); c.umap = umaps + 30; c.out = nullptr; c.Din = 20; c.Deff = 40; c.Dout = 40; c.cout = 6;
+    c.qual = qual; c.rot = rot; c.width = width;
+    return launch_conv<16, 1, 5, 1, 1>(c, st);
+}

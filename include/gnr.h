@@ -131,6 +131,18 @@ int gnr_debug_volume_chain(const GnrScene* scene, const float* bbox_min, int vol
                            const float* packed_coarse, float* dbg, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* ---- grasp head: gd.networks.ConvNet.forward (src/gd/networks.py:48-54) --------
+ * canonical blob = ConvNet state dict flattened in order: encoder.conv{1,2,3}, decoder.conv{1,2,3}, conv_qual,
+ * conv_rot, conv_width (each .weight [Cout,Cin,k,k,k] then .bias).  volume [B,1,R,R,R] -> qual [B,1,40,40,40],
+ * rot [B,4,40,40,40] (unit quaternions), width [B,1,40,40,40]. */
+int gnr_head_canonical_floats(void);
+int gnr_head_packed_floats(void);
+int gnr_pack_grasp_head(const float* canonical_host, float* packed_host);
+size_t gnr_grasp_head_workspace_bytes(int B, int volume_res);
+int gnr_grasp_head_fwd(int B, int volume_res, const float* volume, const float* packed_head, float* qual, float* rot,
+                       float* width, void* workspace, size_t workspace_bytes, void* stream);
+const char* gnr_head_last_error(void);
+
 /* ---- introspection / measurement -------------------------------------------------------*/
 /* name of the dominant kernel as it appears in rocprofv3 traces, and the last HIP error text */
 const char* gnr_dominant_kernel_name(void);

@@ -61,3 +61,8 @@ with torch.no_grad():
 print(f'single scene (B=1) ms: backbones {tb:.2f} | sample_volume {tv:.3f} | render 512 rays {tr:.3f} | depth-mean {td:.3f} | '
       f'grasp head {th:.3f} | full forward {tf:.2f}')
 print(f'grasp head (PyTorch/MIOpen) on 32 volumes: {th32:.2f} ms')
+from graspnerf_amd.grasp_head import GraspHead
+hh = GraspHead(net.vgn_net.state_dict())
+t1, _ = timed(lambda: hh(vol))
+t32, _ = timed(lambda: hh(vol32))
+print(f'grasp head (HIP MFMA) : {t1:.3f} ms single, {t32:.3f} ms on 32 volumes')
