@@ -95,18 +95,60 @@ struct ConvArgs {
 };
 
 // EPI 0: bias + ReLU -> out ; EPI 1: heads (packed channel order rot0..3, qual, width)
-template <int CIN, int NB, int KS, int STRIDE, int EPI>
+// STAGE = false: B operand gathered from global memory (strided encoder layers: large input footprint, tiny FLOPs)
+// STAGE = true : the workgroup (4 wavefronts = one 8x8x4 output brick) first copies the brick's input halo
+//                (<= 7x7x5 source cells per channel thanks to the folded x2 upsampling) into LDS and gathers from
+//                there: the 4x4 voxel patch of a tile touches 16 different cache lines per global load, which
+//                made the first version L1-bound at 20 % MFMA utilisation.
+constexpr int HALO_MAX = 256;        // floats per channel in LDS (>= 7*7*5)
+
+template <int CIN, int NB, int KS, int STRIDE, int EPI, bool STAGE>
 __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
     constexpr int PAD = KS / 2, C4 = CIN / 4;
-    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    const int nbr = (a.Dout + 3) >> 2;                         // bricks per axis
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= a.B * nbr * nbr * nbr) return;
-    const int b = task / (nbr * nbr * nbr), br = task - b * nbr * nbr * nbr;
-    const int bz = br / (nbr * nbr), by = (br / nbr) % nbr, bx = br % nbr;
-    const int ox = bx * 4 + (r & 3), oy = by * 4 + (r >> 2);
+    extern __shared__ __attribute__((aligned(16))) float halo[];           // [CIN][HALO_MAX] + 64 ints of umap (STAGE)
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int Din = a.Din, Din3 = Din * Din * Din;
-    const float* in = a.in + (size_t)b * CIN * Din3 + (size_t)g * Din3;     // lane group g = input channel 4c+g
+    int b, bz, oy0, ox0;                                                    // this wave's 4x4x4 sub-brick origin
+    if constexpr (STAGE) {
+        const int nbx = (a.Dout + 7) >> 3, nbz = (a.Dout + 3) >> 2;
+        const int blk = blockIdx.x;
+        b = blk / (nbx * nbx * nbz);
+        const int br = blk - b * nbx * nbx * nbz;
+        bz = br / (nbx * nbx);
+        oy0 = ((br / nbx) % nbx) * 8 + (wave >> 1) * 4;
+        ox0 = (br % nbx) * 8 + (wave & 1) * 4;
+    } else {
+        const int nbr = (a.Dout + 3) >> 2;
+        const int task = blockIdx.x * 4 + wave;
+        if (task >= a.B * nbr * nbr * nbr) return;
+        b = task / (nbr * nbr * nbr);
+        const int br = task - b * nbr * nbr * nbr;
+        bz = br / (nbr * nbr); oy0 = ((br / nbr) % nbr) * 4; ox0 = (br % nbr) * 4;
+    }
+    const int ox = ox0 + (r & 3), oy = oy0 + (r >> 2);
+    const float* in = a.in + (size_t)b * CIN * Din3;
+
+    // ---- STAGE: source-cell extent of the brick's receptive field, then cooperative copy into LDS
+    int sx0 = 0, sy0 = 0, sz0 = 0, hx = 0, hy = 0;
+    int* um = reinterpret_cast<int*>(halo + CIN * HALO_MAX);
+    if constexpr (STAGE) {
+        const int nbx = (a.Dout + 7) >> 3;
+        const int br = blockIdx.x % (nbx * nbx * ((a.Dout + 3) >> 2));
+        const int bx8 = (br % nbx) * 8, by8 = ((br / nbx) % nbx) * 8;
+        if ((int)threadIdx.x < a.Deff) um[threadIdx.x] = a.umap ? a.umap[threadIdx.x] : (int)threadIdx.x;
+        auto src = [&](int e) { e = min(max(e, 0), a.Deff - 1); return a.umap ? a.umap[e] : e; };
+        sx0 = src(bx8 * STRIDE - PAD); sy0 = src(by8 * STRIDE - PAD); sz0 = src(bz * 4 * STRIDE - PAD);
+        const int sx1 = src((bx8 + 7) * STRIDE + KS - 1 - PAD), sy1 = src((by8 + 7) * STRIDE + KS - 1 - PAD);
+        const int sz1 = src((bz * 4 + 3) * STRIDE + KS - 1 - PAD);
+        hx = sx1 - sx0 + 1; hy = sy1 - sy0 + 1;
+        const int hz = sz1 - sz0 + 1, hv = hx * hy * hz;                    // host guarantees hv <= HALO_MAX
+        for (int i = threadIdx.x; i < CIN * hv; i += 256) {
+            const int c = i / hv, rem = i - c * hv;
+            const int z = rem / (hx * hy), y = (rem / hx) % hy, x = rem % hx;
+            halo[c * HALO_MAX + rem] = in[(size_t)c * Din3 + ((sz0 + z) * Din + sy0 + y) * Din + sx0 + x];
+        }
+        __syncthreads();
+    }
 
     f4 acc[4][NB];
 #pragma unroll
@@ -115,6 +157,8 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[nb * 4 + g];
 
     const float* wf = a.wfrag + lane;
+    const float* ing = in + (size_t)g * Din3;                              // lane group g = input channel 4c+g
+    const float* hg = halo + g * HALO_MAX;
     for (int tz = 0; tz < KS; ++tz) {
         int zoff[4];
         bool zok[4];
@@ -123,19 +167,25 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
             const int iz = (bz * 4 + t) * STRIDE + tz - PAD;
             zok[t] = (unsigned)iz < (unsigned)a.Deff;
             const int izc = zok[t] ? iz : 0;
-            zoff[t] = (a.umap ? a.umap[izc] : izc) * Din * Din;
+            if constexpr (STAGE) zoff[t] = (um[izc] - sz0) * hx * hy;
+            else zoff[t] = (a.umap ? a.umap[izc] : izc) * Din * Din;
         }
         for (int ty = 0; ty < KS; ++ty) {
             const int iy = oy * STRIDE + ty - PAD;
             const bool yok = (unsigned)iy < (unsigned)a.Deff;
             const int iyc = yok ? iy : 0;
-            const int yoff = (a.umap ? a.umap[iyc] : iyc) * Din;
+            int yoff;
+            if constexpr (STAGE) yoff = (um[iyc] - sy0) * hx;
+            else yoff = (a.umap ? a.umap[iyc] : iyc) * Din;
 #pragma unroll 1
             for (int tx = 0; tx < KS; ++tx) {
                 const int ix = ox * STRIDE + tx - PAD;
-                const bool xok = yok && (unsigned)ix < (unsigned)a.Deff;
-                const int ixc = (unsigned)ix < (unsigned)a.Deff ? ix : 0;
-                const int xyoff = yoff + (a.umap ? a.umap[ixc] : ixc);
+                const bool xin = (unsigned)ix < (unsigned)a.Deff;
+                const bool xok = yok && xin;
+                const int ixc = xin ? ix : 0;
+                int xyoff;
+                if constexpr (STAGE) xyoff = yoff + um[ixc] - sx0;
+                else xyoff = yoff + (a.umap ? a.umap[ixc] : ixc);
                 const float* wt = wf + (size_t)((tz * KS + ty) * KS + tx) * C4 * NB * 64;
 #pragma unroll
                 for (int c = 0; c < C4; ++c) {
@@ -144,7 +194,9 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
                     for (int nb = 0; nb < NB; ++nb) av[nb] = wt[(c * NB + nb) * 64];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float v = in[(size_t)(4 * c) * Din3 + zoff[t] + xyoff];
+                        float v;
+                        if constexpr (STAGE) v = hg[4 * c * HALO_MAX + max(zoff[t] + xyoff, 0)];
+                        else v = ing[(size_t)(4 * c) * Din3 + zoff[t] + xyoff];
                         const float bv = (xok && zok[t]) ? v : 0.f;
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(av[nb], bv, acc[t][nb]);
@@ -155,7 +207,7 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
     }
     // ---- epilogue: lane (voxel r of tile t, group g) holds output channels 16*nb + 4*g + {0..3}
     const int D = a.Dout, n = D * D * D;
-    const bool xyok = ox < D && oy < D;
+    const bool xyok = ox < D && oy < D && b < a.B;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int oz = bz * 4 + t;
@@ -185,6 +237,9 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
 }  // namespace gnrh
 
 using namespace gnrh;
+
+static thread_local char h_err[256] = "";
+extern "C" const char* gnr_head_last_error(void) { return h_err; }
 
 extern "C" int gnr_head_canonical_floats(void) { return C_TOTAL; }
 extern "C" int gnr_head_packed_floats(void) { return P_TOTAL; }
@@ -222,8 +277,6 @@ extern "C" int gnr_pack_grasp_head(const float* c, float* p) {
     return GNR_OK;
 }
 
-static thread_local char h_err[256] = "";
-extern "C" const char* gnr_head_last_error(void) { return h_err; }
 #define HCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(h_err, sizeof(h_err), "%s: %s", #call, hipGetErrorString(e_)); return GNR_ERR_HIP; } } while (0)
 
 extern "C" size_t gnr_grasp_head_workspace_bytes(int B, int R) {
@@ -232,11 +285,26 @@ extern "C" size_t gnr_grasp_head_workspace_bytes(int B, int R) {
     return (size_t)B * fl * sizeof(float) + 4096;
 }
 
-template <int CIN, int NB, int KS, int STRIDE, int EPI>
+template <int CIN, int NB, int KS, int STRIDE, int EPI, bool STAGE>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    const int nbr = (a.Dout + 3) / 4;
-    const long tasks = (long)a.B * nbr * nbr * nbr;
-    hipLaunchKernelGGL((k_conv3d<CIN, NB, KS, STRIDE, EPI>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, a);
+    long blocks;
+    size_t lds = 0;
+    if (STAGE) {
+        const int nbx = (a.Dout + 7) / 8, nbz = (a.Dout + 3) / 4;
+        blocks = (long)a.B * nbx * nbx * nbz;
+        lds = ((size_t)CIN * HALO_MAX + 64) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv3d<CIN, NB, KS, STRIDE, EPI, STAGE>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
+            attr = true;
+        }
+    } else {
+        const int nbr = (a.Dout + 3) / 4;
+        blocks = ((long)a.B * nbr * nbr * nbr + 3) / 4;
+    }
+    hipLaunchKernelGGL((k_conv3d<CIN, NB, KS, STRIDE, EPI, STAGE>), dim3((unsigned)blocks), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
     return GNR_OK;
@@ -269,16 +337,19 @@ extern "C" int gnr_grasp_head_fwd(int B, int R, const float* volume, const float
     c.B = B;
     int rc;
     c.in = a1; c.wfrag = packed + P_E2; c.bias = c.wfrag + frag_sz(32, 16, 3); c.umap = nullptr; c.out = a2; c.Din = d1; c.Deff = d1; c.Dout = d2; c.cout = 32;
-    if ((rc = launch_conv<16, 2, 3, 2, 0>(c, st))) return rc;
+    if ((rc = launch_conv<16, 2, 3, 2, 0, false>(c, st))) return rc;
     c.in = a2; c.wfrag = packed + P_E3; c.bias = c.wfrag + frag_sz(64, 32, 3); c.out = a3; c.Din = d2; c.Deff = d2; c.Dout = d3; c.cout = 64;
-    if ((rc = launch_conv<32, 4, 3, 2, 0>(c, st))) return rc;
+    if ((rc = launch_conv<32, 4, 3, 2, 0, false>(c, st))) return rc;
     c.in = a3; c.wfrag = packed + P_D1; c.bias = c.wfrag + frag_sz(64, 64, 3); c.out = a4; c.Din = d3; c.Deff = d3; c.Dout = d3; c.cout = 64;
-    if ((rc = launch_conv<64, 4, 3, 1, 0>(c, st))) return rc;
+    // LDS staging needs the brick's source halo to fit HALO_MAX floats per channel: always true for the fixed
+    // 10^3 / 20^3 decoder grids, and for the 64-channel layers when the bottleneck grid is <= 6^3 (R <= 48)
+    const bool small = d3 <= 6;
+    if ((rc = small ? launch_conv<64, 4, 3, 1, 0, true>(c, st) : launch_conv<64, 4, 3, 1, 0, false>(c, st))) return rc;
     c.in = a4; c.wfrag = packed + P_D2; c.bias = c.wfrag + frag_sz(32, 64, 3); c.umap = umaps; c.out = a5; c.Din = d3; c.Deff = 10; c.Dout = 10; c.cout = 32;
-    if ((rc = launch_conv<64, 2, 3, 1, 0>(c, st))) return rc;
+    if ((rc = small ? launch_conv<64, 2, 3, 1, 0, true>(c, st) : launch_conv<64, 2, 3, 1, 0, false>(c, st))) return rc;
     c.in = a5; c.wfrag = packed + P_D3; c.bias = c.wfrag + frag_sz(16, 32, 5); c.umap = umaps + 10; c.out = a6; c.Din = 10; c.Deff = 20; c.Dout = 20; c.cout = 16;
-    if ((rc = launch_conv<32, 1, 5, 1, 0>(c, st))) return rc;
+    if ((rc = launch_conv<32, 1, 5, 1, 0, true>(c, st))) return rc;
     c.in = a6; c.wfrag = packed + P_HD; c.bias = c.wfrag + frag_sz(16, 16, 5); c.umap = umaps + 30; c.out = nullptr; c.Din = 20; c.Deff = 40; c.Dout = 40; c.cout = 6;
     c.qual = qual; c.rot = rot; c.width = width;
-    return launch_conv<16, 1, 5, 1, 1>(c, st);
+    return launch_conv<16, 1, 5, 1, 1, true>(c, st);
 }
