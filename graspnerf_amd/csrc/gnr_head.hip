@@ -94,118 +94,9 @@ struct ConvArgs {
     int B, Din, Deff, Dout, cout;
 };
 
-// EPI 0: bias + ReLU -> out ; EPI 1: heads (packed channel order rot0..3, qual, width)
-// STAGE = false: B operand gathered from global memory (strided encoder layers: large input footprint, tiny FLOPs)
-// STAGE = true : the workgroup (4 wavefronts = one 8x8x4 output brick) first copies the brick's input halo
-//                (<= 7x7x5 source cells per channel thanks to the folded x2 upsampling) into LDS and gathers from
-//                there: the 4x4 voxel patch of a tile touches 16 different cache lines per global load, which
-//                made the first version L1-bound at 20 % MFMA utilisation.
-constexpr int HALO_MAX = 256;        // floats per channel in LDS (>= 7*7*5)
-
-template <int CIN, int NB, int KS, int STRIDE, int EPI, bool STAGE>
-__global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
-    constexpr int PAD = KS / 2, C4 = CIN / 4;
-    extern __shared__ __attribute__((aligned(16))) float halo[];           // [CIN][HALO_MAX] + 64 ints of umap (STAGE)
-    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
-    const int Din = a.Din, Din3 = Din * Din * Din;
-    int b, bz, oy0, ox0;                                                    // this wave's 4x4x4 sub-brick origin
-    if constexpr (STAGE) {
-        const int nbx = (a.Dout + 7) >> 3, nbz = (a.Dout + 3) >> 2;
-        const int blk = blockIdx.x;
-        b = blk / (nbx * nbx * nbz);
-        const int br = blk - b * nbx * nbx * nbz;
-        bz = br / (nbx * nbx);
-        oy0 = ((br / nbx) % nbx) * 8 + (wave >> 1) * 4;
-        ox0 = (br % nbx) * 8 + (wave & 1) * 4;
-    } else {
-        const int nbr = (a.Dout + 3) >> 2;
-        const int task = blockIdx.x * 4 + wave;
-        if (task >= a.B * nbr * nbr * nbr) return;
-        b = task / (nbr * nbr * nbr);
-        const int br = task - b * nbr * nbr * nbr;
-        bz = br / (nbr * nbr); oy0 = ((br / nbr) % nbr) * 4; ox0 = (br % nbr) * 4;
-    }
-    const int ox = ox0 + (r & 3), oy = oy0 + (r >> 2);
-    const float* in = a.in + (size_t)b * CIN * Din3;
-
-    // ---- STAGE: source-cell extent of the brick's receptive field, then cooperative copy into LDS
-    int sx0 = 0, sy0 = 0, sz0 = 0, hx = 0, hy = 0;
-    int* um = reinterpret_cast<int*>(halo + CIN * HALO_MAX);
-    if constexpr (STAGE) {
-        const int nbx = (a.Dout + 7) >> 3;
-        const int br = blockIdx.x % (nbx * nbx * ((a.Dout + 3) >> 2));
-        const int bx8 = (br % nbx) * 8, by8 = ((br / nbx) % nbx) * 8;
-        if ((int)threadIdx.x < a.Deff) um[threadIdx.x] = a.umap ? a.umap[threadIdx.x] : (int)threadIdx.x;
-        auto src = [&](int e) { e = min(max(e, 0), a.Deff - 1); return a.umap ? a.umap[e] : e; };
-        sx0 = src(bx8 * STRIDE - PAD); sy0 = src(by8 * STRIDE - PAD); sz0 = src(bz * 4 * STRIDE - PAD);
-        const int sx1 = src((bx8 + 7) * STRIDE + KS - 1 - PAD), sy1 = src((by8 + 7) * STRIDE + KS - 1 - PAD);
-        const int sz1 = src((bz * 4 + 3) * STRIDE + KS - 1 - PAD);
-        hx = sx1 - sx0 + 1; hy = sy1 - sy0 + 1;
-        const int hz = sz1 - sz0 + 1, hv = hx * hy * hz;                    // host guarantees hv <= HALO_MAX
-        for (int i = threadIdx.x; i < CIN * hv; i += 256) {
-            const int c = i / hv, rem = i - c * hv;
-            const int z = rem / (hx * hy), y = (rem / hx) % hy, x = rem % hx;
-            halo[c * HALO_MAX + rem] = in[(size_t)c * Din3 + ((sz0 + z) * Din + sy0 + y) * Din + sx0 + x];
-        }
-        __syncthreads();
-    }
-
-    f4 acc[4][NB];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[nb * 4 + g];
-
-    const float* wf = a.wfrag + lane;
-    const float* ing = in + (size_t)g * Din3;                              // lane group g = input channel 4c+g
-    const float* hg = halo + g * HALO_MAX;
-    for (int tz = 0; tz < KS; ++tz) {
-        int zoff[4];
-        bool zok[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int iz = (bz * 4 + t) * STRIDE + tz - PAD;
-            zok[t] = (unsigned)iz < (unsigned)a.Deff;
-            const int izc = zok[t] ? iz : 0;
-            if constexpr (STAGE) zoff[t] = (um[izc] - sz0) * hx * hy;
-            else zoff[t] = (a.umap ? a.umap[izc] : izc) * Din * Din;
-        }
-        for (int ty = 0; ty < KS; ++ty) {
-            const int iy = oy * STRIDE + ty - PAD;
-            const bool yok = (unsigned)iy < (unsigned)a.Deff;
-            const int iyc = yok ? iy : 0;
-            int yoff;
-            if constexpr (STAGE) yoff = (um[iyc] - sy0) * hx;
-            else yoff = (a.umap ? a.umap[iyc] : iyc) * Din;
-#pragma unroll 1
-            for (int tx = 0; tx < KS; ++tx) {
-                const int ix = ox * STRIDE + tx - PAD;
-                const bool xin = (unsigned)ix < (unsigned)a.Deff;
-                const bool xok = yok && xin;
-                const int ixc = xin ? ix : 0;
-                int xyoff;
-                if constexpr (STAGE) xyoff = yoff + um[ixc] - sx0;
-                else xyoff = yoff + (a.umap ? a.umap[ixc] : ixc);
-                const float* wt = wf + (size_t)((tz * KS + ty) * KS + tx) * C4 * NB * 64;
-#pragma unroll
-                for (int c = 0; c < C4; ++c) {
-                    float av[NB];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) av[nb] = wt[(c * NB + nb) * 64];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float v;
-                        if constexpr (STAGE) v = hg[4 * c * HALO_MAX + max(zoff[t] + xyoff, 0)];
-                        else v = ing[(size_t)(4 * c) * Din3 + zoff[t] + xyoff];
-                        const float bv = (xok && zok[t]) ? v : 0.f;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(av[nb], bv, acc[t][nb]);
-                    }
-                }
-            }
-        }
-    }
-    // ---- epilogue: lane (voxel r of tile t, group g) holds output channels 16*nb + 4*g + {0..3}
+// epilogue shared by both kernels: lane (voxel r of tile t, group g) holds output channels 16*nb + 4*g + {0..3}
+template <int NB, int EPI>
+DEV void conv_epilogue(const ConvArgs& a, const f4 (&acc)[4][NB], int b, int bz, int oy, int ox, int g) {
     const int D = a.Dout, n = D * D * D;
     const bool xyok = ox < D && oy < D && b < a.B;
 #pragma unroll
@@ -220,7 +111,7 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
                 o[0] = fmaxf(acc[t][nb].x, 0.f); o[(size_t)n] = fmaxf(acc[t][nb].y, 0.f);
                 o[(size_t)2 * n] = fmaxf(acc[t][nb].z, 0.f); o[(size_t)3 * n] = fmaxf(acc[t][nb].w, 0.f);
             }
-        } else {
+        } else {                                              // heads, packed channel order rot0..3, qual, width
             const f4 x = acc[t][0];
             if (g == 0) {                                     // rot: F.normalize(dim=1), eps 1e-12 (networks.py:52)
                 const float nr = fmaxf(sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w), 1e-12f);
@@ -232,6 +123,180 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvArgs a) {
             }
         }
     }
+}
+
+// ---- strided encoder layers (large input footprint per brick, ~2 % of the FLOPs): one wavefront per 4x4x4
+// output brick, B operand gathered straight from global memory, A fragments read coalesced from global.
+template <int CIN, int NB, int KS, int STRIDE, int EPI>
+__global__ __launch_bounds__(256) void k_conv3d_direct(ConvArgs a) {
+    constexpr int PAD = KS / 2, C4 = CIN / 4;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int Din = a.Din, Din3 = Din * Din * Din;
+    const int nbr = (a.Dout + 3) >> 2;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= a.B * nbr * nbr * nbr) return;
+    const int b = task / (nbr * nbr * nbr), br = task - b * nbr * nbr * nbr;
+    const int bz = br / (nbr * nbr);
+    const int ox = (br % nbr) * 4 + (r & 3), oy = ((br / nbr) % nbr) * 4 + (r >> 2);
+    const float* ing = a.in + (size_t)b * CIN * Din3 + (size_t)g * Din3;   // lane group g = input channel 4c+g
+    f4 acc[4][NB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[nb * 4 + g];
+    const float* wf = a.wfrag + lane;
+    for (int tz = 0; tz < KS; ++tz) {
+        int zoff[4];
+        bool zok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int iz = (bz * 4 + t) * STRIDE + tz - PAD;
+            zok[t] = (unsigned)iz < (unsigned)a.Deff;
+            const int izc = zok[t] ? iz : 0;
+            zoff[t] = (a.umap ? a.umap[izc] : izc) * Din * Din;
+        }
+        for (int ty = 0; ty < KS; ++ty) {
+            const int iy = oy * STRIDE + ty - PAD;
+            const bool yok = (unsigned)iy < (unsigned)a.Deff;
+            const int iyc = yok ? iy : 0;
+            const int yoff = (a.umap ? a.umap[iyc] : iyc) * Din;
+#pragma unroll 1
+            for (int tx = 0; tx < KS; ++tx) {
+                const int ix = ox * STRIDE + tx - PAD;
+                const bool xin = (unsigned)ix < (unsigned)a.Deff;
+                const bool xok = yok && xin;
+                const int ixc = xin ? ix : 0;
+                const int xyoff = yoff + (a.umap ? a.umap[ixc] : ixc);
+                const float* wt = wf + (size_t)((tz * KS + ty) * KS + tx) * C4 * NB * 64;
+#pragma unroll
+                for (int c = 0; c < C4; ++c) {
+                    float av[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) av[nb] = wt[(c * NB + nb) * 64];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float v = ing[(size_t)(4 * c) * Din3 + zoff[t] + xyoff];
+                        const float bv = (xok && zok[t]) ? v : 0.f;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(av[nb], bv, acc[t][nb]);
+                    }
+                }
+            }
+        }
+    }
+    conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g);
+}
+
+// ---- stride-1 decoder / head layers (98 % of the FLOPs): one workgroup (4 wavefronts) per 8x8x4 output brick.
+//   * the brick's input halo, INCLUDING an explicit zero border, is copied once into LDS ([CIN][HALO_MAX]); the
+//     nearest-neighbour upsampling is folded into the source index, so the halo is at most 6x6x4 cells + border;
+//     the inner loop then needs no bounds tests: B operand = one ds_read at base + constant offset
+//   * the A fragments of TS consecutive taps are staged in LDS per step (read from HBM/L2 once per workgroup
+//     instead of once per wavefront, and off the latency-critical path)
+//   The first version (4x4 voxel patch gathered from global: 16 cache lines per load) was L1-bound at 20 % MFMA
+//   utilisation.
+constexpr int HALO_MAX = 320;        // floats per channel in LDS (worst case 7x7x6 = 294: 5^3 grid + zero border)
+
+template <int CIN, int NB, int KS, int TS, int EPI>
+__global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
+    constexpr int PAD = KS / 2, C4 = CIN / 4, TAPS = KS * KS * KS, AFL = C4 * NB * 64;   // A floats per tap
+    static_assert(TAPS % TS == 0, "tap staging step must divide the tap count");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                                   // [CIN][HALO_MAX]
+    float* asl = smem + CIN * HALO_MAX;                   // [TS][C4][NB][64]
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int Din = a.Din, Din3 = Din * Din * Din, Deff = a.Deff;
+    const int nbx = (a.Dout + 7) >> 3, nbz = (a.Dout + 3) >> 2;
+    const int b = blockIdx.x / (nbx * nbx * nbz), br = blockIdx.x - b * nbx * nbx * nbz;
+    const int bz = br / (nbx * nbx), by8 = ((br / nbx) % nbx) * 8, bx8 = (br % nbx) * 8;
+    const int ox = bx8 + (wave & 1) * 4 + (r & 3), oy = by8 + (wave >> 1) * 4 + (r >> 2);
+    const float* in = a.in + (size_t)b * CIN * Din3;
+    // source cell of an effective (virtually upsampled) coordinate; -1 / Din are the zero border
+    auto src = [&](int e) { return e < 0 ? -1 : (e >= Deff ? Din : (a.umap ? a.umap[e] : e)); };
+    const int sx0 = src(bx8 - PAD), sy0 = src(by8 - PAD), sz0 = src(bz * 4 - PAD);
+    const int hx = src(bx8 + 7 + KS - 1 - PAD) - sx0 + 1, hy = src(by8 + 7 + KS - 1 - PAD) - sy0 + 1;
+    const int hz = src(bz * 4 + 3 + KS - 1 - PAD) - sz0 + 1, hv = hx * hy * hz;          // host guarantees hv <= HALO_MAX
+    for (int i = threadIdx.x; i < CIN * hv; i += 256) {
+        const int c = i / hv, rem = i - c * hv;
+        const int z = sz0 + rem / (hx * hy), y = sy0 + (rem / hx) % hy, x = sx0 + rem % hx;
+        const bool ok = (unsigned)z < (unsigned)Din && (unsigned)y < (unsigned)Din && (unsigned)x < (unsigned)Din;
+        halo[c * HALO_MAX + rem] = ok ? in[(size_t)c * Din3 + (z * Din + y) * Din + x] : 0.f;
+    }
+    // per-lane halo offsets of the KS taps along each axis (stride 1)
+    int xo[KS], yo[KS], zo[4][KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        xo[k] = src(ox + k - PAD) - sx0;
+        yo[k] = (src(oy + k - PAD) - sy0) * hx;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) zo[t][k] = (src(bz * 4 + t + k - PAD) - sz0) * hx * hy;
+    }
+    f4 acc[4][NB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[nb * 4 + g];
+
+    const float* hg = halo + g * HALO_MAX;                // lane group g = input channel 4c+g
+    static_assert(TS % KS == 0 && C4 % 4 == 0, "a staging step is a whole number of x-rows; cin multiple of 16");
+    // A-fragment slices are prefetched into registers one step ahead (global latency hides under the MFMAs of
+    // the current slice) and written to LDS between two barriers once everybody has finished reading.
+    constexpr int PF = TS * AFL / 256;                    // floats per thread per slice
+    static_assert((TS * AFL) % 256 == 0, "slice must split evenly over the workgroup");
+    float pf[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) pf[k] = a.wfrag[threadIdx.x + 256 * k];
+    for (int s0 = 0; s0 < TAPS; s0 += TS) {
+        __syncthreads();                                  // previous slice consumed (and halo written, first trip)
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {                    // global [tap][c][nb][lane] -> LDS [tap][nb][lane][c]:
+            const int i = threadIdx.x + 256 * k;          // one ds_read_b128 then feeds 4 k-steps
+            const int ln = i & 63, q = i >> 6, nb = q % NB, c = (q / NB) % C4, tp = q / (NB * C4);
+            asl[((tp * NB + nb) * 64 + ln) * C4 + c] = pf[k];
+        }
+        __syncthreads();
+        if (s0 + TS < TAPS) {
+            const float* srcp = a.wfrag + (size_t)(s0 + TS) * AFL;
+#pragma unroll
+            for (int k = 0; k < PF; ++k) pf[k] = srcp[threadIdx.x + 256 * k];
+        }
+#pragma unroll 1
+        for (int row = 0; row < TS / KS; ++row) {         // one (tz, ty) row of KS taps, x-taps unrolled
+            const int rowi = s0 / KS + row, tz = rowi / KS, ty = rowi % KS;
+            int yz[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {                // static-index selects keep yo/zo in registers
+                if (ty == k) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) yz[t] += yo[k];
+                }
+                if (tz == k) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) yz[t] += zo[t][k];
+                }
+            }
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) {
+                const f4* ap = reinterpret_cast<const f4*>(asl + ((row * KS + tx) * NB * 64 + lane) * C4);
+#pragma unroll
+                for (int c4 = 0; c4 < C4 / 4; ++c4) {
+                    f4 av[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) av[nb] = ap[nb * 64 * (C4 / 4) + c4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float bv = hg[4 * (4 * c4 + cc) * HALO_MAX + yz[t] + xo[tx]];
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(av[nb][cc], bv, acc[t][nb]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g);
 }
 
 }  // namespace gnrh
@@ -285,28 +350,31 @@ extern "C" size_t gnr_grasp_head_workspace_bytes(int B, int R) {
     return (size_t)B * fl * sizeof(float) + 4096;
 }
 
-template <int CIN, int NB, int KS, int STRIDE, int EPI, bool STAGE>
-static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    long blocks;
-    size_t lds = 0;
-    if (STAGE) {
-        const int nbx = (a.Dout + 7) / 8, nbz = (a.Dout + 3) / 4;
-        blocks = (long)a.B * nbx * nbx * nbz;
-        lds = ((size_t)CIN * HALO_MAX + 64) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv3d<CIN, NB, KS, STRIDE, EPI, STAGE>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
-            attr = true;
-        }
-    } else {
-        const int nbr = (a.Dout + 3) / 4;
-        blocks = ((long)a.B * nbr * nbr * nbr + 3) / 4;
-    }
-    hipLaunchKernelGGL((k_conv3d<CIN, NB, KS, STRIDE, EPI, STAGE>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+template <int CIN, int NB, int KS, int STRIDE, int EPI>
+static int launch_direct(const ConvArgs& a, hipStream_t st) {
+    const int nbr = (a.Dout + 3) / 4;
+    const long blocks = ((long)a.B * nbr * nbr * nbr + 3) / 4;
+    hipLaunchKernelGGL((k_conv3d_direct<CIN, NB, KS, STRIDE, EPI>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
+    if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d_direct launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
+    return GNR_OK;
+}
+
+template <int CIN, int NB, int KS, int TS, int EPI>
+static int launch_staged(const ConvArgs& a, hipStream_t st) {
+    const int nbx = (a.Dout + 7) / 8, nbz = (a.Dout + 3) / 4;
+    const long blocks = (long)a.B * nbx * nbx * nbz;
+    const size_t lds = ((size_t)CIN * HALO_MAX + (size_t)TS * (CIN / 4) * NB * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv3d_staged<CIN, NB, KS, TS, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv3d_staged<CIN, NB, KS, TS, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d_staged launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
     return GNR_OK;
 }
 
@@ -337,19 +405,20 @@ extern "C" int gnr_grasp_head_fwd(int B, int R, const float* volume, const float
     c.B = B;
     int rc;
     c.in = a1; c.wfrag = packed + P_E2; c.bias = c.wfrag + frag_sz(32, 16, 3); c.umap = nullptr; c.out = a2; c.Din = d1; c.Deff = d1; c.Dout = d2; c.cout = 32;
-    if ((rc = launch_conv<16, 2, 3, 2, 0, false>(c, st))) return rc;
+    if ((rc = launch_direct<16, 2, 3, 2, 0>(c, st))) return rc;
     c.in = a2; c.wfrag = packed + P_E3; c.bias = c.wfrag + frag_sz(64, 32, 3); c.out = a3; c.Din = d2; c.Deff = d2; c.Dout = d3; c.cout = 64;
-    if ((rc = launch_conv<32, 4, 3, 2, 0, false>(c, st))) return rc;
+    if ((rc = launch_direct<32, 4, 3, 2, 0>(c, st))) return rc;
     c.in = a3; c.wfrag = packed + P_D1; c.bias = c.wfrag + frag_sz(64, 64, 3); c.out = a4; c.Din = d3; c.Deff = d3; c.Dout = d3; c.cout = 64;
-    // LDS staging needs the brick's source halo to fit HALO_MAX floats per channel: always true for the fixed
-    // 10^3 / 20^3 decoder grids, and for the 64-channel layers when the bottleneck grid is <= 6^3 (R <= 48)
-    const bool small = d3 <= 6;
-    if ((rc = small ? launch_conv<64, 4, 3, 1, 0, true>(c, st) : launch_conv<64, 4, 3, 1, 0, false>(c, st))) return rc;
+    // LDS staging needs the brick's source halo (+ zero border) to fit HALO_MAX floats per channel: always true for
+    // the fixed 10^3 / 20^3 decoder grids (<= 6x6x4), and for the 64-channel layers when the bottleneck grid is
+    // <= 5^3 (R <= 40: at most 7x7x6 = 294 cells with border)
+    const bool small = d3 <= 5;
+    if ((rc = small ? launch_staged<64, 4, 3, 3, 0>(c, st) : launch_direct<64, 4, 3, 1, 0>(c, st))) return rc;
     c.in = a4; c.wfrag = packed + P_D2; c.bias = c.wfrag + frag_sz(32, 64, 3); c.umap = umaps; c.out = a5; c.Din = d3; c.Deff = 10; c.Dout = 10; c.cout = 32;
-    if ((rc = small ? launch_conv<64, 2, 3, 1, 0, true>(c, st) : launch_conv<64, 2, 3, 1, 0, false>(c, st))) return rc;
+    if ((rc = small ? launch_staged<64, 2, 3, 9, 0>(c, st) : launch_direct<64, 2, 3, 1, 0>(c, st))) return rc;
     c.in = a5; c.wfrag = packed + P_D3; c.bias = c.wfrag + frag_sz(16, 32, 5); c.umap = umaps + 10; c.out = a6; c.Din = 10; c.Deff = 20; c.Dout = 20; c.cout = 16;
-    if ((rc = launch_conv<32, 1, 5, 1, 0, true>(c, st))) return rc;
+    if ((rc = launch_staged<32, 1, 5, 25, 0>(c, st))) return rc;
     c.in = a6; c.wfrag = packed + P_HD; c.bias = c.wfrag + frag_sz(16, 16, 5); c.umap = umaps + 30; c.out = nullptr; c.Din = 20; c.Deff = 40; c.Dout = 40; c.cout = 6;
     c.qual = qual; c.rot = rot; c.width = width;
-    return launch_conv<16, 1, 5, 1, 1, true>(c, st);
+    return launch_staged<16, 1, 5, 25, 1>(c, st);
 }
