@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <vector>
 
 #include "../../include/gnr.h"
 
@@ -41,8 +42,13 @@ constexpr int C_WW = C_RB + 4, C_WB = C_WW + w_sz(1, 16, 5), C_TOTAL = C_WB + 1;
 constexpr int frag_sz(int co, int ci, int k) { return k * k * k * (ci / 4) * ((co + 15) / 16) * 64; }
 constexpr int P_E1 = 0, P_E2 = P_E1 + w_sz(16, 1, 5) + 16, P_E3 = P_E2 + frag_sz(32, 16, 3) + 32;
 constexpr int P_D1 = P_E3 + frag_sz(64, 32, 3) + 64, P_D2 = P_D1 + frag_sz(64, 64, 3) + 64;
-constexpr int P_D3 = P_D2 + frag_sz(32, 64, 3) + 32, P_HD = P_D3 + frag_sz(16, 32, 5) + 16;
-constexpr int P_TOTAL = P_HD + frag_sz(16, 16, 5) + 16;
+// decoder.conv3 and the heads always see an input that was nearest-upsampled by exactly 2 (10->20, 20->40:
+// networks.py:91-96).  A k5 conv on a x2-replicated grid is, per output parity (pz,py,px), a k3 conv on the
+// un-replicated grid whose weights are sums of the original taps (per axis, parity 0: {-2,-1}|{0,1}|{2},
+// parity 1: {-2}|{-1,0}|{1,2}).  Folding is exact algebra (weights summed in fp64 on the host) and cuts the
+// MACs of these two layers (92 % of the head) by 125/27 = 4.6x.  Layout: 8 parity classes x [27 taps] fragments.
+constexpr int P_D3 = P_D2 + frag_sz(32, 64, 3) + 32, P_HD = P_D3 + 8 * frag_sz(16, 32, 3) + 16;
+constexpr int P_TOTAL = P_HD + 8 * frag_sz(16, 16, 3) + 16;
 
 // ---- layer 0: 1 -> 16 channels, k5, stride 2, ReLU; one thread per output voxel (16 MMAC per scene) -------
 __global__ __launch_bounds__(256) void k_conv_first(const float* __restrict__ vol, const float* __restrict__ wb,
@@ -96,14 +102,17 @@ struct ConvArgs {
 
 // epilogue shared by both kernels: lane (voxel r of tile t, group g) holds output channels 16*nb + 4*g + {0..3}
 template <int NB, int EPI>
-DEV void conv_epilogue(const ConvArgs& a, const f4 (&acc)[4][NB], int b, int bz, int oy, int ox, int g) {
-    const int D = a.Dout, n = D * D * D;
-    const bool xyok = ox < D && oy < D && b < a.B;
+DEV void conv_epilogue(const ConvArgs& a, const f4 (&acc)[4][NB], int b, int bz, int oy, int ox, int g, int parity = -1) {
+    // parity >= 0 (folded x2 upsampling): source-grid voxel (z,y,x) of class (pz,py,px) is output voxel (2z+pz, ...)
+    const int Ds = a.Dout, D = parity >= 0 ? 2 * Ds : Ds, n = D * D * D;
+    const int pz = parity >= 0 ? (parity >> 2) & 1 : 0, py = parity >= 0 ? (parity >> 1) & 1 : 0, px = parity >= 0 ? parity & 1 : 0;
+    const int sc = parity >= 0 ? 2 : 1;
+    const bool xyok = ox < Ds && oy < Ds && b < a.B;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int oz = bz * 4 + t;
-        if (!xyok || oz >= D) continue;
-        const int v = (oz * D + oy) * D + ox;
+        if (!xyok || oz >= Ds) continue;
+        const int v = ((oz * sc + pz) * D + oy * sc + py) * D + ox * sc + px;
         if constexpr (EPI == 0) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -195,11 +204,14 @@ __global__ __launch_bounds__(256) void k_conv3d_direct(ConvArgs a) {
 //     instead of once per wavefront, and off the latency-critical path)
 //   The first version (4x4 voxel patch gathered from global: 16 cache lines per load) was L1-bound at 20 % MFMA
 //   utilisation.
-constexpr int HALO_MAX = 320;        // floats per channel in LDS (worst case 7x7x6 = 294: 5^3 grid + zero border)
+// floats per channel in LDS: upsampled-input layers on a <=5^3 source grid need 7x7x6 = 294 (grid + zero border);
+// the folded k3 layers read the full (8+2)x(8+2)x(4+2) = 600-cell neighbourhood of their 8x8x4 brick
+constexpr int halo_max(bool fold) { return fold ? 608 : 320; }
 
-template <int CIN, int NB, int KS, int TS, int EPI>
+template <int CIN, int NB, int KS, int TS, int EPI, bool FOLD>
 __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
     constexpr int PAD = KS / 2, C4 = CIN / 4, TAPS = KS * KS * KS, AFL = C4 * NB * 64;   // A floats per tap
+    constexpr int HALO_MAX = halo_max(FOLD);
     static_assert(TAPS % TS == 0, "tap staging step must divide the tap count");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                                   // [CIN][HALO_MAX]
@@ -207,10 +219,13 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int Din = a.Din, Din3 = Din * Din * Din, Deff = a.Deff;
     const int nbx = (a.Dout + 7) >> 3, nbz = (a.Dout + 3) >> 2;
-    const int b = blockIdx.x / (nbx * nbx * nbz), br = blockIdx.x - b * nbx * nbx * nbz;
+    const int parity = FOLD ? (int)(blockIdx.x & 7) : -1;                 // 8 parity classes share a brick's halo shape
+    const int blk = FOLD ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int b = blk / (nbx * nbx * nbz), br = blk - b * nbx * nbx * nbz;
     const int bz = br / (nbx * nbx), by8 = ((br / nbx) % nbx) * 8, bx8 = (br % nbx) * 8;
     const int ox = bx8 + (wave & 1) * 4 + (r & 3), oy = by8 + (wave >> 1) * 4 + (r >> 2);
     const float* in = a.in + (size_t)b * CIN * Din3;
+    const float* wfrag = a.wfrag + (FOLD ? (size_t)parity * TAPS * AFL : 0);
     // source cell of an effective (virtually upsampled) coordinate; -1 / Din are the zero border
     auto src = [&](int e) { return e < 0 ? -1 : (e >= Deff ? Din : (a.umap ? a.umap[e] : e)); };
     const int sx0 = src(bx8 - PAD), sy0 = src(by8 - PAD), sz0 = src(bz * 4 - PAD);
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
     static_assert((TS * AFL) % 256 == 0, "slice must split evenly over the workgroup");
     float pf[PF];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) pf[k] = a.wfrag[threadIdx.x + 256 * k];
+    for (int k = 0; k < PF; ++k) pf[k] = wfrag[threadIdx.x + 256 * k];
     for (int s0 = 0; s0 < TAPS; s0 += TS) {
         __syncthreads();                                  // previous slice consumed (and halo written, first trip)
 #pragma unroll
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
         }
         __syncthreads();
         if (s0 + TS < TAPS) {
-            const float* srcp = a.wfrag + (size_t)(s0 + TS) * AFL;
+            const float* srcp = wfrag + (size_t)(s0 + TS) * AFL;
 #pragma unroll
             for (int k = 0; k < PF; ++k) pf[k] = srcp[threadIdx.x + 256 * k];
         }
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
             }
         }
     }
-    conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g);
+    conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g, parity);
 }
 
 }  // namespace gnrh
@@ -322,6 +337,30 @@ static void pack_conv(float* dst, const float* W, const float* bias, int cout, i
     for (int i = 0; i < NB * 16; ++i) { const int o = cout_pad_map(i); bd[i] = (o >= 0 && o < cout) ? bias[o] : 0.f; }
 }
 
+// fold a k5 conv that follows a x2 nearest upsampling into 8 parity-class k3 convs (see the layout comment)
+static void pack_folded(float* dst, const float* W, const float* bias, int cout, int cin) {
+    static const int cell[2][5] = {{-1, -1, 0, 0, 1}, {-1, 0, 0, 1, 1}};      // source cell of tap d-2 for parity 0 / 1
+    std::vector<float> wf((size_t)cout * cin * 27);
+    const int fs = 27 * (cin / 4) * ((cout + 15) / 16) * 64;
+    std::vector<float> tmp((size_t)fs + 64);
+    for (int par = 0; par < 8; ++par) {
+        const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+        for (int o = 0; o < cout; ++o)
+            for (int ci = 0; ci < cin; ++ci) {
+                double acc[27] = {0};
+                for (int dz = 0; dz < 5; ++dz)
+                    for (int dy = 0; dy < 5; ++dy)
+                        for (int dx = 0; dx < 5; ++dx)
+                            acc[((cell[pz][dz] + 1) * 3 + cell[py][dy] + 1) * 3 + cell[px][dx] + 1] +=
+                                (double)W[((size_t)o * cin + ci) * 125 + (dz * 5 + dy) * 5 + dx];
+                for (int t = 0; t < 27; ++t) wf[((size_t)o * cin + ci) * 27 + t] = (float)acc[t];
+            }
+        pack_conv(tmp.data(), wf.data(), bias, cout, cin, 3, [](int o) { return o; });
+        for (int i = 0; i < fs; ++i) dst[(size_t)par * fs + i] = tmp[i];
+        if (par == 7) for (int i = 0; i < ((cout + 15) / 16) * 16; ++i) dst[(size_t)8 * fs + i] = tmp[fs + i];
+    }
+}
+
 extern "C" int gnr_pack_grasp_head(const float* c, float* p) {
     if (!c || !p) return GNR_ERR_ARG;
     for (int i = 0; i < P_TOTAL; ++i) p[i] = 0.f;
@@ -332,13 +371,13 @@ extern "C" int gnr_pack_grasp_head(const float* c, float* p) {
     pack_conv(p + P_E3, c + C_E3W, c + C_E3B, 64, 32, 3, ident);
     pack_conv(p + P_D1, c + C_D1W, c + C_D1B, 64, 64, 3, ident);
     pack_conv(p + P_D2, c + C_D2W, c + C_D2B, 32, 64, 3, ident);
-    pack_conv(p + P_D3, c + C_D3W, c + C_D3B, 16, 32, 5, ident);
+    pack_folded(p + P_D3, c + C_D3W, c + C_D3B, 16, 32);
     // heads fused into one 16->6 conv; packed channel order: rot0..3, qual, width
     static float hw[6 * 16 * 125], hb[6];
     for (int o = 0; o < 4; ++o) { for (int i = 0; i < 2000; ++i) hw[o * 2000 + i] = c[C_RW + o * 2000 + i]; hb[o] = c[C_RB + o]; }
     for (int i = 0; i < 2000; ++i) { hw[4 * 2000 + i] = c[C_QW + i]; hw[5 * 2000 + i] = c[C_WW + i]; }
     hb[4] = c[C_QB]; hb[5] = c[C_WB];
-    pack_conv(p + P_HD, hw, hb, 6, 16, 5, ident);
+    pack_folded(p + P_HD, hw, hb, 6, 16);
     return GNR_OK;
 }
 
@@ -360,19 +399,19 @@ static int launch_direct(const ConvArgs& a, hipStream_t st) {
     return GNR_OK;
 }
 
-template <int CIN, int NB, int KS, int TS, int EPI>
+template <int CIN, int NB, int KS, int TS, int EPI, bool FOLD>
 static int launch_staged(const ConvArgs& a, hipStream_t st) {
     const int nbx = (a.Dout + 7) / 8, nbz = (a.Dout + 3) / 4;
-    const long blocks = (long)a.B * nbx * nbx * nbz;
-    const size_t lds = ((size_t)CIN * HALO_MAX + (size_t)TS * (CIN / 4) * NB * 64) * sizeof(float);
+    const long blocks = (long)a.B * nbx * nbx * nbz * (FOLD ? 8 : 1);
+    const size_t lds = ((size_t)CIN * halo_max(FOLD) + (size_t)TS * (CIN / 4) * NB * 64) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv3d_staged<CIN, NB, KS, TS, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv3d_staged<CIN, NB, KS, TS, EPI, FOLD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv3d_staged<CIN, NB, KS, TS, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_conv3d_staged<CIN, NB, KS, TS, EPI, FOLD>), dim3((unsigned)blocks), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d_staged launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
     return GNR_OK;
@@ -413,12 +452,13 @@ extern "C" int gnr_grasp_head_fwd(int B, int R, const float* volume, const float
     // the fixed 10^3 / 20^3 decoder grids (<= 6x6x4), and for the 64-channel layers when the bottleneck grid is
     // <= 5^3 (R <= 40: at most 7x7x6 = 294 cells with border)
     const bool small = d3 <= 5;
-    if ((rc = small ? launch_staged<64, 4, 3, 3, 0>(c, st) : launch_direct<64, 4, 3, 1, 0>(c, st))) return rc;
+    if ((rc = small ? launch_staged<64, 4, 3, 3, 0, false>(c, st) : launch_direct<64, 4, 3, 1, 0>(c, st))) return rc;
     c.in = a4; c.wfrag = packed + P_D2; c.bias = c.wfrag + frag_sz(32, 64, 3); c.umap = umaps; c.out = a5; c.Din = d3; c.Deff = 10; c.Dout = 10; c.cout = 32;
-    if ((rc = small ? launch_staged<64, 2, 3, 9, 0>(c, st) : launch_direct<64, 2, 3, 1, 0>(c, st))) return rc;
-    c.in = a5; c.wfrag = packed + P_D3; c.bias = c.wfrag + frag_sz(16, 32, 5); c.umap = umaps + 10; c.out = a6; c.Din = 10; c.Deff = 20; c.Dout = 20; c.cout = 16;
-    if ((rc = launch_staged<32, 1, 5, 25, 0>(c, st))) return rc;
-    c.in = a6; c.wfrag = packed + P_HD; c.bias = c.wfrag + frag_sz(16, 16, 5); c.umap = umaps + 30; c.out = nullptr; c.Din = 20; c.Deff = 40; c.Dout = 40; c.cout = 6;
+    if ((rc = small ? launch_staged<64, 2, 3, 9, 0, false>(c, st) : launch_direct<64, 2, 3, 1, 0>(c, st))) return rc;
+    // decoder.conv3 and the heads: folded x2 upsampling -> k3 convs on the 10^3 / 20^3 source grids, 8 parity classes
+    c.in = a5; c.wfrag = packed + P_D3; c.bias = c.wfrag + 8 * frag_sz(16, 32, 3); c.umap = nullptr; c.out = a6; c.Din = 10; c.Deff = 10; c.Dout = 10; c.cout = 16;
+    if ((rc = launch_staged<32, 1, 3, 9, 0, true>(c, st))) return rc;
+    c.in = a6; c.wfrag = packed + P_HD; c.bias = c.wfrag + 8 * frag_sz(16, 16, 3); c.out = nullptr; c.Din = 20; c.Deff = 20; c.Dout = 20; c.cout = 6;
     c.qual = qual; c.rot = rot; c.width = width;
-    return launch_staged<16, 1, 5, 25, 1>(c, st);
+    return launch_staged<16, 1, 3, 9, 1, true>(c, st);
 }
