@@ -12,8 +12,22 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _InstanceNorm(nn.InstanceNorm2d):
+    """nn.InstanceNorm2d(affine=True, track_running_stats=False) with the same parameters/keys.  On ROCm
+    `torch.instance_norm` goes through a batch-norm path that blocks the host for ~0.23 ms per call (62 calls =
+    14 ms of a 34 ms single-scene forward, tools/time_full_forward.py --profile); on the GPU the statistics are
+    computed with plain reductions instead (same formula: biased variance, eps inside the rsqrt)."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
+        var, mean = torch.var_mean(x, dim=(2, 3), unbiased=False, keepdim=True)
+        scale = torch.rsqrt(var + self.eps) * self.weight[None, :, None, None]
+        return torch.addcmul(self.bias[None, :, None, None] - mean * scale, x, scale)
+
+
 def _inorm(ch):
-    return nn.InstanceNorm2d(ch, track_running_stats=False, affine=True)
+    return _InstanceNorm(ch, track_running_stats=False, affine=True)
 
 
 def _c3(cin, cout, stride=1):

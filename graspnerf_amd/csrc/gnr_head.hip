@@ -98,11 +98,13 @@ struct ConvArgs {
     float* out;           // [B][COUT][Dout^3]           (EPI 0)
     float *qual, *rot, *width;   // heads               (EPI 1)
     int B, Din, Deff, Dout, cout;
+    int nb_total;         // output-channel blocks of the layer; blockIdx.y selects NB of them (small layers: more waves)
 };
 
 // epilogue shared by both kernels: lane (voxel r of tile t, group g) holds output channels 16*nb + 4*g + {0..3}
 template <int NB, int EPI>
-DEV void conv_epilogue(const ConvArgs& a, const f4 (&acc)[4][NB], int b, int bz, int oy, int ox, int g, int parity = -1) {
+DEV void conv_epilogue(const ConvArgs& a, const f4 (&acc)[4][NB], int b, int bz, int oy, int ox, int g, int parity = -1,
+                       int nb0 = 0) {
     // parity >= 0 (folded x2 upsampling): source-grid voxel (z,y,x) of class (pz,py,px) is output voxel (2z+pz, ...)
     const int Ds = a.Dout, D = parity >= 0 ? 2 * Ds : Ds, n = D * D * D;
     const int pz = parity >= 0 ? (parity >> 2) & 1 : 0, py = parity >= 0 ? (parity >> 1) & 1 : 0, px = parity >= 0 ? parity & 1 : 0;
@@ -116,7 +118,7 @@ DEV void conv_epilogue(const ConvArgs& a, const f4 (&acc)[4][NB], int b, int bz,
         if constexpr (EPI == 0) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                float* o = a.out + ((size_t)b * a.cout + 16 * nb + 4 * g) * n + v;
+                float* o = a.out + ((size_t)b * a.cout + 16 * (nb0 + nb) + 4 * g) * n + v;
                 o[0] = fmaxf(acc[t][nb].x, 0.f); o[(size_t)n] = fmaxf(acc[t][nb].y, 0.f);
                 o[(size_t)2 * n] = fmaxf(acc[t][nb].z, 0.f); o[(size_t)3 * n] = fmaxf(acc[t][nb].w, 0.f);
             }
@@ -148,12 +150,13 @@ __global__ __launch_bounds__(256) void k_conv3d_direct(ConvArgs a) {
     const int bz = br / (nbr * nbr);
     const int ox = (br % nbr) * 4 + (r & 3), oy = ((br / nbr) % nbr) * 4 + (r >> 2);
     const float* ing = a.in + (size_t)b * CIN * Din3 + (size_t)g * Din3;   // lane group g = input channel 4c+g
+    const int nb0 = blockIdx.y * NB, NBT = a.nb_total;
     f4 acc[4][NB];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[nb * 4 + g];
-    const float* wf = a.wfrag + lane;
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[(nb0 + nb) * 4 + g];
+    const float* wf = a.wfrag + nb0 * 64 + lane;
     for (int tz = 0; tz < KS; ++tz) {
         int zoff[4];
         bool zok[4];
@@ -176,12 +179,12 @@ __global__ __launch_bounds__(256) void k_conv3d_direct(ConvArgs a) {
                 const bool xok = yok && xin;
                 const int ixc = xin ? ix : 0;
                 const int xyoff = yoff + (a.umap ? a.umap[ixc] : ixc);
-                const float* wt = wf + (size_t)((tz * KS + ty) * KS + tx) * C4 * NB * 64;
+                const float* wt = wf + (size_t)((tz * KS + ty) * KS + tx) * C4 * NBT * 64;
 #pragma unroll
                 for (int c = 0; c < C4; ++c) {
                     float av[NB];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) av[nb] = wt[(c * NB + nb) * 64];
+                    for (int nb = 0; nb < NB; ++nb) av[nb] = wt[(c * NBT + nb) * 64];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const float v = ing[(size_t)(4 * c) * Din3 + zoff[t] + xyoff];
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void k_conv3d_direct(ConvArgs a) {
             }
         }
     }
-    conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g);
+    conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g, -1, nb0);
 }
 
 // ---- stride-1 decoder / head layers (98 % of the FLOPs): one workgroup (4 wavefronts) per 8x8x4 output brick.
@@ -219,13 +222,14 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int Din = a.Din, Din3 = Din * Din * Din, Deff = a.Deff;
     const int nbx = (a.Dout + 7) >> 3, nbz = (a.Dout + 3) >> 2;
-    const int parity = FOLD ? (int)(blockIdx.x & 7) : -1;                 // 8 parity classes share a brick's halo shape
-    const int blk = FOLD ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int blk = blockIdx.x;
     const int b = blk / (nbx * nbx * nbz), br = blk - b * nbx * nbx * nbz;
     const int bz = br / (nbx * nbx), by8 = ((br / nbx) % nbx) * 8, bx8 = (br % nbx) * 8;
     const int ox = bx8 + (wave & 1) * 4 + (r & 3), oy = by8 + (wave >> 1) * 4 + (r >> 2);
     const float* in = a.in + (size_t)b * CIN * Din3;
-    const float* wfrag = a.wfrag + (FOLD ? (size_t)parity * TAPS * AFL : 0);
+    const int nb0 = blockIdx.y * NB, NBT = a.nb_total;                    // this block's output-channel blocks
+    constexpr int NPAR = FOLD ? 8 : 1;                                    // parity classes share the halo (loaded once)
+    const float* wfrag = a.wfrag;
     // source cell of an effective (virtually upsampled) coordinate; -1 / Din are the zero border
     auto src = [&](int e) { return e < 0 ? -1 : (e >= Deff ? Din : (a.umap ? a.umap[e] : e)); };
     const int sx0 = src(bx8 - PAD), sy0 = src(by8 - PAD), sz0 = src(bz * 4 - PAD);
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[nb * 4 + g];
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[(nb0 + nb) * 4 + g];
 
     const float* hg = halo + g * HALO_MAX;                // lane group g = input channel 4c+g
     static_assert(TS % KS == 0 && C4 % 4 == 0, "a staging step is a whole number of x-rows; cin multiple of 16");
@@ -259,9 +263,12 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
     constexpr int PF = TS * AFL / 256;                    // floats per thread per slice
     static_assert((TS * AFL) % 256 == 0, "slice must split evenly over the workgroup");
     float pf[PF];
+    // element i of a slice = (tap tp, c, nb, lane); in global memory the nb axis has NBT entries
+    auto gidx = [&](int i) { const int ln = i & 63, q = i >> 6, nb = q % NB, c = (q / NB) % C4, tp = q / (NB * C4);
+                             return ((size_t)(tp * C4 + c) * NBT + nb0 + nb) * 64 + ln; };
 #pragma unroll
-    for (int k = 0; k < PF; ++k) pf[k] = wfrag[threadIdx.x + 256 * k];
-    for (int s0 = 0; s0 < TAPS; s0 += TS) {
+    for (int k = 0; k < PF; ++k) pf[k] = wfrag[gidx(threadIdx.x + 256 * k)];
+    for (int s0 = 0; s0 < TAPS * NPAR; s0 += TS) {
         __syncthreads();                                  // previous slice consumed (and halo written, first trip)
 #pragma unroll
         for (int k = 0; k < PF; ++k) {                    // global [tap][c][nb][lane] -> LDS [tap][nb][lane][c]:
@@ -270,14 +277,14 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
             asl[((tp * NB + nb) * 64 + ln) * C4 + c] = pf[k];
         }
         __syncthreads();
-        if (s0 + TS < TAPS) {
-            const float* srcp = wfrag + (size_t)(s0 + TS) * AFL;
+        if (s0 + TS < TAPS * NPAR) {
+            const float* srcp = wfrag + (size_t)(s0 + TS) * C4 * NBT * 64;
 #pragma unroll
-            for (int k = 0; k < PF; ++k) pf[k] = srcp[threadIdx.x + 256 * k];
+            for (int k = 0; k < PF; ++k) pf[k] = srcp[gidx(threadIdx.x + 256 * k)];
         }
 #pragma unroll 1
         for (int row = 0; row < TS / KS; ++row) {         // one (tz, ty) row of KS taps, x-taps unrolled
-            const int rowi = s0 / KS + row, tz = rowi / KS, ty = rowi % KS;
+            const int rowi = (s0 % TAPS) / KS + row, tz = rowi / KS, ty = rowi % KS;
             int yz[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < KS; ++k) {                // static-index selects keep yo/zo in registers
@@ -310,8 +317,14 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
                 }
             }
         }
+        if ((s0 + TS) % TAPS == 0) {                      // a parity class (or the whole layer) is complete
+            conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g, FOLD ? s0 / TAPS : -1, nb0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[t][nb] = reinterpret_cast<const f4*>(a.bias)[(nb0 + nb) * 4 + g];
+        }
     }
-    conv_epilogue<NB, EPI>(a, acc, b, bz, oy, ox, g, parity);
 }
 
 }  // namespace gnrh
@@ -393,7 +406,7 @@ template <int CIN, int NB, int KS, int STRIDE, int EPI>
 static int launch_direct(const ConvArgs& a, hipStream_t st) {
     const int nbr = (a.Dout + 3) / 4;
     const long blocks = ((long)a.B * nbr * nbr * nbr + 3) / 4;
-    hipLaunchKernelGGL((k_conv3d_direct<CIN, NB, KS, STRIDE, EPI>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv3d_direct<CIN, NB, KS, STRIDE, EPI>), dim3((unsigned)blocks, a.nb_total / NB), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d_direct launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
     return GNR_OK;
@@ -402,7 +415,7 @@ static int launch_direct(const ConvArgs& a, hipStream_t st) {
 template <int CIN, int NB, int KS, int TS, int EPI, bool FOLD>
 static int launch_staged(const ConvArgs& a, hipStream_t st) {
     const int nbx = (a.Dout + 7) / 8, nbz = (a.Dout + 3) / 4;
-    const long blocks = (long)a.B * nbx * nbx * nbz * (FOLD ? 8 : 1);
+    const long blocks = (long)a.B * nbx * nbx * nbz;
     const size_t lds = ((size_t)CIN * halo_max(FOLD) + (size_t)TS * (CIN / 4) * NB * 64) * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -411,7 +424,7 @@ static int launch_staged(const ConvArgs& a, hipStream_t st) {
         if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv3d_staged<CIN, NB, KS, TS, EPI, FOLD>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_conv3d_staged<CIN, NB, KS, TS, EPI, FOLD>), dim3((unsigned)blocks, a.nb_total / NB), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "k_conv3d_staged launch: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
     return GNR_OK;
@@ -443,22 +456,22 @@ extern "C" int gnr_grasp_head_fwd(int B, int R, const float* volume, const float
     ConvArgs c{};
     c.B = B;
     int rc;
-    c.in = a1; c.wfrag = packed + P_E2; c.bias = c.wfrag + frag_sz(32, 16, 3); c.umap = nullptr; c.out = a2; c.Din = d1; c.Deff = d1; c.Dout = d2; c.cout = 32;
-    if ((rc = launch_direct<16, 2, 3, 2, 0>(c, st))) return rc;
-    c.in = a2; c.wfrag = packed + P_E3; c.bias = c.wfrag + frag_sz(64, 32, 3); c.out = a3; c.Din = d2; c.Deff = d2; c.Dout = d3; c.cout = 64;
-    if ((rc = launch_direct<32, 4, 3, 2, 0>(c, st))) return rc;
-    c.in = a3; c.wfrag = packed + P_D1; c.bias = c.wfrag + frag_sz(64, 64, 3); c.out = a4; c.Din = d3; c.Deff = d3; c.Dout = d3; c.cout = 64;
+    c.in = a1; c.wfrag = packed + P_E2; c.bias = c.wfrag + frag_sz(32, 16, 3); c.umap = nullptr; c.out = a2; c.Din = d1; c.Deff = d1; c.Dout = d2; c.cout = 32; c.nb_total = 2;
+    if ((rc = launch_direct<16, 1, 3, 2, 0>(c, st))) return rc;
+    c.in = a2; c.wfrag = packed + P_E3; c.bias = c.wfrag + frag_sz(64, 32, 3); c.out = a3; c.Din = d2; c.Deff = d2; c.Dout = d3; c.cout = 64; c.nb_total = 4;
+    if ((rc = launch_direct<32, 1, 3, 2, 0>(c, st))) return rc;
+    c.in = a3; c.wfrag = packed + P_D1; c.bias = c.wfrag + frag_sz(64, 64, 3); c.out = a4; c.Din = d3; c.Deff = d3; c.Dout = d3; c.cout = 64; c.nb_total = 4;
     // LDS staging needs the brick's source halo (+ zero border) to fit HALO_MAX floats per channel: always true for
     // the fixed 10^3 / 20^3 decoder grids (<= 6x6x4), and for the 64-channel layers when the bottleneck grid is
     // <= 5^3 (R <= 40: at most 7x7x6 = 294 cells with border)
     const bool small = d3 <= 5;
-    if ((rc = small ? launch_staged<64, 4, 3, 3, 0, false>(c, st) : launch_direct<64, 4, 3, 1, 0>(c, st))) return rc;
-    c.in = a4; c.wfrag = packed + P_D2; c.bias = c.wfrag + frag_sz(32, 64, 3); c.umap = umaps; c.out = a5; c.Din = d3; c.Deff = 10; c.Dout = 10; c.cout = 32;
-    if ((rc = small ? launch_staged<64, 2, 3, 9, 0, false>(c, st) : launch_direct<64, 2, 3, 1, 0>(c, st))) return rc;
+    if ((rc = small ? launch_staged<64, 1, 3, 9, 0, false>(c, st) : launch_direct<64, 1, 3, 1, 0>(c, st))) return rc;
+    c.in = a4; c.wfrag = packed + P_D2; c.bias = c.wfrag + frag_sz(32, 64, 3); c.umap = umaps; c.out = a5; c.Din = d3; c.Deff = 10; c.Dout = 10; c.cout = 32; c.nb_total = 2;
+    if ((rc = small ? launch_staged<64, 1, 3, 9, 0, false>(c, st) : launch_direct<64, 1, 3, 1, 0>(c, st))) return rc;
     // decoder.conv3 and the heads: folded x2 upsampling -> k3 convs on the 10^3 / 20^3 source grids, 8 parity classes
-    c.in = a5; c.wfrag = packed + P_D3; c.bias = c.wfrag + 8 * frag_sz(16, 32, 3); c.umap = nullptr; c.out = a6; c.Din = 10; c.Deff = 10; c.Dout = 10; c.cout = 16;
+    c.in = a5; c.wfrag = packed + P_D3; c.bias = c.wfrag + 8 * frag_sz(16, 32, 3); c.umap = nullptr; c.out = a6; c.Din = 10; c.Deff = 10; c.Dout = 10; c.cout = 16; c.nb_total = 1;
     if ((rc = launch_staged<32, 1, 3, 9, 0, true>(c, st))) return rc;
-    c.in = a6; c.wfrag = packed + P_HD; c.bias = c.wfrag + 8 * frag_sz(16, 16, 3); c.out = nullptr; c.Din = 20; c.Deff = 20; c.Dout = 20; c.cout = 6;
+    c.in = a6; c.wfrag = packed + P_HD; c.bias = c.wfrag + 8 * frag_sz(16, 16, 3); c.out = nullptr; c.Din = 20; c.Deff = 20; c.Dout = 20; c.cout = 6; c.nb_total = 1;
     c.qual = qual; c.rot = rot; c.width = width;
     return launch_staged<16, 1, 3, 9, 1, true>(c, st);
 }

@@ -13,6 +13,7 @@ import torch.nn as nn
 from . import weights as _w
 from .backbone import ResUNetLight, CostVolumeInitNet, DefaultVisEncoder, ConvNet
 from .hotpath import HotPath
+from .grasp_head import GraspHead
 
 
 def _kaiming(mods):
@@ -187,7 +188,10 @@ class NeuralRayRenderer(nn.Module):
         return self._out_dict(o, '', self.fine_agg_net if is_fine else self.agg_net)
 
     def gen_depth_loss_coords(self, h, w, device):                          # renderer.py:222-228
-        idx = torch.randperm(h * w)[:self.cfg['depth_loss_coords_num']]     # CPU generator, like the reference
+        # default: CPU generator like the reference (same RNG stream -> identical coordinates for a given seed);
+        # cfg['depth_coords_rng'] = 'device' draws on the GPU instead (randperm of 147 456 costs ~15 ms on the host)
+        gen_dev = device if self.cfg.get('depth_coords_rng', 'cpu') == 'device' else 'cpu'
+        idx = torch.randperm(h * w, device=gen_dev)[:self.cfg['depth_loss_coords_num']]
         return torch.stack([idx // w, idx % w], -1).to(device)              # (row, col)
 
     def predict_mean_for_depth_loss(self, ref_imgs_info, _prep=None):       # renderer.py:230-266
@@ -228,7 +232,25 @@ class GraspNeRF(nn.Module):
         super().__init__()
         self.cfg = {**self.default_cfg_vgn, **cfg}
         self.nr_net = NeuralRayRenderer(self.cfg)
-        self.vgn_net = ConvNet()                                            # gd.networks.get_network("conv")
+        self.vgn_net = ConvNet()                                            # gd.networks.get_network("conv"): parameters
+        self._head = None                                                   # HIP kernels built from vgn_net's weights
+
+    def _apply(self, fn, *a, **k):
+        self._head = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._head = None
+        return super().load_state_dict(*a, **k)
+
+    def grasp_head(self, volume):
+        """gd.networks.ConvNet.forward: HIP implicit-GEMM kernels for inference on the GPU (csrc/gnr_head.hip);
+        the PyTorch module (same parameters) when autograd is needed."""
+        if volume.is_cuda and not torch.is_grad_enabled():
+            if self._head is None:
+                self._head = GraspHead(self.vgn_net.state_dict(), device=volume.device)
+            return self._head(volume)
+        return self.vgn_net(volume)
 
     @staticmethod
     def select(out, index):                                                 # renderer.py:305-311
@@ -239,7 +261,7 @@ class GraspNeRF(nn.Module):
 
     def forward(self, data):                                                # renderer.py:313-331
         render_outputs = self.nr_net(data)
-        vgn_pred = self.vgn_net(render_outputs['volume'])
+        vgn_pred = self.grasp_head(render_outputs['volume'])
         render_outputs['vgn_pred'] = vgn_pred if 'full_vol' in data else self.select(vgn_pred, data['grasp_info'][0])
         return render_outputs
 

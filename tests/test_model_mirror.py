@@ -114,3 +114,31 @@ def test_full_forward_matches_reference(model, G):
     np.testing.assert_allclose(q.cpu().numpy()[..., ::2, ::2, ::2], G['vgn_qual_sub'], **tol)
     np.testing.assert_allclose(r.cpu().numpy()[..., ::2, ::2, ::2], G['vgn_rot_sub'], rtol=1e-3, atol=2e-3)
     np.testing.assert_allclose(w.cpu().numpy()[..., ::2, ::2, ::2], G['vgn_width_sub'], **tol)
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_equals_eager(model):
+    """The whole forward (PyTorch backbones + libgnr kernels + HIP grasp head) is hipGraph-capturable."""
+    from graspnerf_amd.graph import GraphedForward
+    net = model.cuda()
+    net.nr_net.cfg['depth_coords_rng'] = 'device'
+    try:
+        ref, que = make_scene(1, 'cfg1')
+        t = lambda a: torch.from_numpy(a).cuda()
+        data = {'step': 0, 'eval': True, 'full_vol': True,
+                'ref_imgs_info': {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')},
+                'que_imgs_info': {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                                  'depth_range': t(que['depth_range'])[None]}}
+        with torch.no_grad():
+            eager = net(data)
+        gf = GraphedForward(net, data)
+        out = gf(data)
+        torch.cuda.synchronize()
+        for k in ('volume', 'sdf_values', 'alpha_values_fine', 'render_depth'):
+            assert torch.allclose(out[k], eager[k], rtol=1e-4, atol=1e-5), k
+        assert torch.allclose(out['vgn_pred'][0], eager['vgn_pred'][0], rtol=1e-4, atol=1e-5)
+        with pytest.raises(ValueError):
+            net.nr_net.cfg['depth_coords_rng'] = 'cpu'
+            GraphedForward(net, data)
+    finally:
+        net.nr_net.cfg['depth_coords_rng'] = 'cpu'

@@ -66,3 +66,24 @@ hh = GraspHead(net.vgn_net.state_dict())
 t1, _ = timed(lambda: hh(vol))
 t32, _ = timed(lambda: hh(vol32))
 print(f'grasp head (HIP MFMA) : {t1:.3f} ms single, {t32:.3f} ms on 32 volumes')
+
+if '--profile' in sys.argv:
+    import cProfile, pstats
+    with torch.no_grad():
+        for _ in range(3): net(data)
+        torch.cuda.synchronize()
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(5): net(data)
+        torch.cuda.synchronize()
+        pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+
+if '--graph' in sys.argv:
+    from graspnerf_amd.graph import GraphedForward
+    net.nr_net.cfg['depth_coords_rng'] = 'device'
+    with torch.no_grad():
+        te, oe = timed(lambda: net(data))
+    gf = GraphedForward(net, data)
+    tg, og = timed(lambda: gf(data))
+    print(f'full forward: eager {te:.2f} ms, hipGraph replay {tg:.2f} ms; volume max|diff| '
+          f'{(og["volume"] - oe["volume"]).abs().max().item():.2e}')
