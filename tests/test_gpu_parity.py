@@ -148,8 +148,27 @@ def test_error_codes(hot):
     from graspnerf_amd import _lib
     scenes, (bref, bque) = _batched('cfg1')
     scene, keep, ws = hot.prepare(bref, 16)
-    bad = _lib.GnrScene(scene.B, 7, scene.H, scene.W, scene.fh, scene.fw, scene.imgs, scene.img_feats, scene.ray_feats,
+    bad = _lib.GnrScene(scene.B, 9, scene.H, scene.W, scene.fh, scene.fw, scene.imgs, scene.img_feats, scene.ray_feats,
                         scene.poses, scene.Ks, scene.depth_range)
     assert hot.L.gnr_prepare(C.byref(bad), ws.data_ptr(), ws.numel(), None) == -2
     assert hot.L.gnr_prepare(C.byref(scene), ws.data_ptr(), 16, None) == -4
     assert hot.L.gnr_prepare(C.byref(scene), None, 0, None) == -1
+
+
+@pytest.mark.parametrize('V', [2, 4, 5, 8])
+def test_other_view_counts(V, hot, W):
+    """k_chain is instantiated for 2..8 views; masks include views that see nothing (ragged validity)."""
+    from graspnerf_amd.hotpath import batch_scenes
+    cfgV = dict(CONFIGS['cfg1'], V=V)
+    sc = make_scene(V, cfgV)
+    bref, bque = batch_scenes([sc])
+    res, dn = 16, 16
+    vol = hot.sample_volume(bref, res).cpu().numpy()
+    close(vol[0], O.sample_volume(W, O.to_torch(sc[0]), res).numpy()[0], f'V={V} volume vs oracle')
+    depth = O.sample_depth(torch.from_numpy(sc[1]['depth_range']), 64, dn)
+    o = hot.render_by_depth(bref, bque, depth[None], 'coarse', debug=False)
+    ref_o = O.render_by_depth(W, O.to_torch(sc[0]), O.to_torch(sc[1]), depth, 'dist_decoder.', 'agg_net.',
+                              O.DEFAULT_RENDER_CFG)
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'colors_nr'):
+        close(o[k].cpu().numpy(), ref_o[k].numpy(), f'V={V} {k}')
+    assert np.array_equal(o['ray_mask'].cpu().numpy(), ref_o['ray_mask'].numpy())

@@ -142,3 +142,20 @@ def test_hipgraph_replay_equals_eager(model):
             GraphedForward(net, data)
     finally:
         net.nr_net.cfg['depth_coords_rng'] = 'cpu'
+
+
+@pytest.mark.gpu
+def test_planner_core_matches_forward(model, G):
+    """Counterpart of GraspNeRFPlanner.core (main.py:211-253): numpy in, numpy volumes out."""
+    from graspnerf_amd import planner
+    net = model.cuda()
+    old = net.nr_net.cfg['render_rgb']
+    net.nr_net.cfg['render_rgb'] = False
+    try:
+        ref, _ = make_scene(0, 'cfg1')
+        vol, q, r, w, dt = planner.core(net, ref['imgs'], ref['poses'], ref['Ks'], ref['depth_range'], ref['bbox3d'])
+        assert vol.shape == (1, 1, 16, 16, 16) and q.shape == (1, 1, 40, 40, 40) and dt > 0
+        np.testing.assert_allclose(vol, G['volume'], rtol=1e-3, atol=3e-4)
+        np.testing.assert_allclose(q[..., ::2, ::2, ::2], G['vgn_qual_sub'], rtol=1e-3, atol=3e-4)
+    finally:
+        net.nr_net.cfg['render_rgb'] = old
