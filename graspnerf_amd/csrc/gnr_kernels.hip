@@ -470,13 +470,9 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
                     e1[nb * 4 + 0] = fmaxf(acc[nb].x, 0.f); e1[nb * 4 + 1] = fmaxf(acc[nb].y, 0.f);
                     e1[nb * 4 + 2] = fmaxf(acc[nb].z, 0.f); e1[nb * 4 + 3] = fmaxf(acc[nb].w, 0.f);
                 }
-                load_bias<2>(lds + pk::B_PE2, g, acc);
-                mm<8, 2>(lds + pk::PE2, lane, e1, acc);
+                // prob_embed.2 is folded into neuray_fc.0 / base_fc.0 on the host: the state kept per view is e1
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    Sv[9 + nb * 4 + 0] = acc[nb].x; Sv[9 + nb * 4 + 1] = acc[nb].y;
-                    Sv[9 + nb * 4 + 2] = acc[nb].z; Sv[9 + nb * 4 + 3] = acc[nb].w;
-                }
+                for (int j = 0; j < 8; ++j) Sv[9 + j] = e1[j];
             }
             // ---- x = [rgb, img_feats] + ray_dir_fc(dir_diff)  (ibrnet.py:457-459)
             {
@@ -872,14 +868,9 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     const float rstd = 1.f / sqrtf(var + 1e-6f);
 #pragma unroll
     for (int c = 0; c < 16; ++c) { xh[c] = (y[c] - mean) * rstd; nrm[c] = xh[c] * W[pk::R_LNW + c] + W[pk::R_LNB + c]; }
-    float sraw = W[pk::R_OUT1B];
+    float sraw = W[pk::R_OUTB];                       // out_geometry_fc.1(out_geometry_fc.0(n)), folded on the host
 #pragma unroll
-    for (int f = 0; f < 16; ++f) {
-        float rr = W[pk::R_OUT0B + f];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) rr = fmaf(W[pk::R_OUT0W + f * 16 + c], nrm[c], rr);
-        sraw = fmaf(W[pk::R_OUT1W + f], rr, sraw);
-    }
+    for (int c = 0; c < 16; ++c) sraw = fmaf(W[pk::R_OUTVJP + c], nrm[c], sraw);
     float sdf = fminf(fmaxf(sraw, -1.f), 1.f);
     if (nvalid < 1.f) sdf = 1.f;
 

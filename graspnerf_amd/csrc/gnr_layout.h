@@ -58,8 +58,9 @@ namespace pk {
 constexpr int DEC1 = 0;          //  8   2   x3 branches (mean, var, aw), 1024 floats each
 constexpr int DEC2 = DEC1 + 3 * frag_floats(8, 2);        //  8   2   x3
 constexpr int PE1 = DEC2 + 3 * frag_floats(8, 2);         //  9   2
-constexpr int PE2 = PE1 + frag_floats(9, 2);              //  8   2
-constexpr int RDF1 = PE2 + frag_floats(8, 2);             //  1   1
+// prob_embed.2 has no activation behind it and its output is only consumed linearly (neuray_fc.0, base_fc.0
+// columns 175..206), so it is multiplied into those consumers on the host: 16 MFMAs per (tile, view) less.
+constexpr int RDF1 = PE1 + frag_floats(9, 2);             //  1   1
 constexpr int RDF2 = RDF1 + frag_floats(1, 1);            //  4   3
 constexpr int NR1 = RDF2 + frag_floats(4, 3);             //  8   1
 constexpr int BASE1 = NR1 + frag_floats(8, 1);            // 17   4
@@ -77,8 +78,7 @@ constexpr int FRAG_END = GEO2 + frag_floats(16, 1);
 constexpr int B_DEC1 = FRAG_END;            // 3 x 32
 constexpr int B_DEC2 = B_DEC1 + 96;         // 3 x 32
 constexpr int B_PE1 = B_DEC2 + 96;
-constexpr int B_PE2 = B_PE1 + 32;
-constexpr int B_RDF1 = B_PE2 + 32;
+constexpr int B_RDF1 = B_PE1 + 32;
 constexpr int B_RDF2 = B_RDF1 + 16;         // 48 (3 blocks)
 constexpr int B_NR1 = B_RDF2 + 48;
 constexpr int B_HOIST = B_NR1 + 16;         // base_fc.0 bias, 64
@@ -114,8 +114,10 @@ constexpr int R_PE = R_VARIANCE + 4;        // sinusoid table [64 positions][16]
 // transposed copies / products for the VJP so that every inner loop reads contiguous scalars
 constexpr int R_WQT = R_PE + 64 * 16, R_WKT = R_WQT + 256, R_WVT = R_WKT + 256, R_WFCT = R_WVT + 256;   // [in][out]
 constexpr int R_GEO2WT = R_WFCT + 256;      // geometry_fc.2 weight transposed: [64][16]
-constexpr int R_OUTVJP = R_GEO2WT + 1024;   // out_geometry_fc.0^T @ out_geometry_fc.1 : d sdf / d LayerNorm output, [16]
-constexpr int TOTAL = R_OUTVJP + 16;
+constexpr int R_OUTVJP = R_GEO2WT + 1024;   // w = out_geometry_fc.0^T @ out_geometry_fc.1 [16]: both d sdf / d LayerNorm output
+                                            // and the folded forward (two linears without activation, ibrnet.py:410-412)
+constexpr int R_OUTB = R_OUTVJP + 16;       // folded bias: out_fc.1 . out_fc.0.bias + out_fc.1.bias
+constexpr int TOTAL = R_OUTB + 4;
 }  // namespace pk
 
 // per-point descriptor (k_points_* -> k_chain): 8 floats

@@ -64,10 +64,10 @@ extern "C" int gnr_layout_offset(const char* name) {
     using namespace gnr::pk;
     struct E { const char* n; int o; };
     static const E tab[] = {
-        {"DEC1", DEC1}, {"DEC2", DEC2}, {"PE1", PE1}, {"PE2", PE2}, {"RDF1", RDF1}, {"RDF2", RDF2}, {"NR1", NR1},
+        {"DEC1", DEC1}, {"DEC2", DEC2}, {"PE1", PE1}, {"RDF1", RDF1}, {"RDF2", RDF2}, {"NR1", NR1},
         {"BASE1", BASE1}, {"BASE2", BASE2}, {"VIS1", VIS1}, {"VIS2", VIS2}, {"VISB1", VISB1}, {"RGB1", RGB1},
         {"RGB2", RGB2}, {"HOIST", HOIST}, {"GEO1", GEO1}, {"GEO2", GEO2}, {"FRAG_END", FRAG_END},
-        {"B_DEC1", B_DEC1}, {"B_DEC2", B_DEC2}, {"B_PE1", B_PE1}, {"B_PE2", B_PE2}, {"B_RDF1", B_RDF1},
+        {"B_DEC1", B_DEC1}, {"B_DEC2", B_DEC2}, {"B_PE1", B_PE1}, {"B_RDF1", B_RDF1},
         {"B_RDF2", B_RDF2}, {"B_NR1", B_NR1}, {"B_HOIST", B_HOIST}, {"B_BASE2", B_BASE2}, {"B_VIS1", B_VIS1},
         {"B_VIS2", B_VIS2}, {"B_VISB1", B_VISB1}, {"B_RGB1", B_RGB1}, {"B_RGB2", B_RGB2}, {"B_GEO1", B_GEO1},
         {"B_GEO2", B_GEO2}, {"T_DEC3", T_DEC3}, {"T_DEC3_B", T_DEC3_B}, {"T_NR2", T_NR2}, {"T_VIS2R", T_VIS2R},
@@ -75,7 +75,7 @@ extern "C" int gnr_layout_offset(const char* name) {
         {"R_WQ", R_WQ}, {"R_WK", R_WK}, {"R_WV", R_WV}, {"R_WFC", R_WFC}, {"R_LNW", R_LNW}, {"R_LNB", R_LNB},
         {"R_OUT0W", R_OUT0W}, {"R_OUT0B", R_OUT0B}, {"R_OUT1W", R_OUT1W}, {"R_OUT1B", R_OUT1B},
         {"R_GEO2W", R_GEO2W}, {"R_GEO1E", R_GEO1E}, {"R_VARIANCE", R_VARIANCE}, {"R_PE", R_PE}, {"R_WQT", R_WQT},
-        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"TOTAL", TOTAL}};
+        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"R_OUTB", R_OUTB}, {"TOTAL", TOTAL}};
     for (const E& e : tab)
         if (!std::strcmp(e.n, name)) return e.o;
     return -1;
@@ -115,8 +115,10 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
     pack_frag(p + pk::PE1, c + can::PE0_W, 34, 9, 2,
               [](int j, int g) { return j < 8 ? 8 * g + j : (g == 0 ? 32 : (g == 1 ? 33 : -1)); }, natO);
     pack_bias(p + pk::B_PE1, c + can::PE0_B, 2, natO);
-    pack_frag(p + pk::PE2, c + can::PE2_W, 32, 8, 2, natI, natO);
-    pack_bias(p + pk::B_PE2, c + can::PE2_B, 2, natO);
+    // prob_embed.2 (32x32 + bias, no activation) is folded into its two linear consumers (see gnr_layout.h):
+    // products in double, then rounded once.
+    const float* Wp2 = c + can::PE2_W;      // [32][32]
+    const float* bp2 = c + can::PE2_B;
 
     // --- ray_dir_fc: 4 -> 16 -> 35, output laid out like x (see xfeat)
     pack_frag(p + pk::RDF1, c + can::RDF0_W, 4, 1, 1, [](int, int g) { return g; }, natO, LOG2E, kTrue);
@@ -131,8 +133,21 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
     pack_bias(p + pk::B_RDF2, c + can::RDF2_B, 3, xout, LOG2E);
 
     // --- neuray_fc: 32 -> 8 (MFMA) -> 1 (VALU)
-    pack_frag(p + pk::NR1, c + can::NR0_W, 32, 8, 1, natI, first8, LOG2E, kTrue);
-    pack_bias(p + pk::B_NR1, c + can::NR0_B, 1, first8, LOG2E);
+    {   // neuray_fc.0 o prob_embed.2 : [8][32], input = ReLU output of prob_embed.0
+        std::vector<float> Wc(8 * 32), bc(8);
+        for (int o = 0; o < 8; ++o) {
+            double bb = c[can::NR0_B + o];
+            for (int k = 0; k < 32; ++k) bb += (double)c[can::NR0_W + o * 32 + k] * bp2[k];
+            bc[o] = (float)bb;
+            for (int i = 0; i < 32; ++i) {
+                double a = 0;
+                for (int k = 0; k < 32; ++k) a += (double)c[can::NR0_W + o * 32 + k] * Wp2[k * 32 + i];
+                Wc[o * 32 + i] = (float)a;
+            }
+        }
+        pack_frag(p + pk::NR1, Wc.data(), 32, 8, 1, natI, first8, LOG2E, kTrue);
+        pack_bias(p + pk::B_NR1, bc.data(), 1, first8, LOG2E);
+    }
     for (int g = 0; g < 4; ++g)
         for (int r = 0; r < 4; ++r) p[pk::T_NR2 + g * 4 + r] = (4 * g + r < 8) ? (float)(c[can::NR2_W + 4 * g + r] / LOG2E) : 0.f;
     p[pk::T_SCAL + 0] = c[can::NR2_B];
@@ -140,12 +155,26 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
     // --- base_fc.0 split: view-invariant 140 columns (HOIST) + per-view 67 columns (BASE1)
     pack_frag(p + pk::HOIST, c + can::BASE0_W, 207, 36, 4,
               [](int j, int g) { const int x = xfeat(j % 9, g); return x < 0 ? -1 : 35 * (j / 9) + x; }, natO, LOG2E, kTrue);
-    pack_bias(p + pk::B_HOIST, c + can::BASE0_B, 4, natO, LOG2E);
-    pack_frag(p + pk::BASE1, c + can::BASE0_W, 207, 17, 4,
-              [](int j, int g) {
-                  if (j < 9) { const int x = xfeat(j, g); return x < 0 ? -1 : 140 + x; }
-                  return 175 + nat_in(j - 9, g);
-              }, natO, LOG2E, kTrue);
+    {   // base_fc.0 with its prob-embedding columns (175..206) multiplied by prob_embed.2
+        std::vector<float> Wc(64 * 207), bc(64);
+        for (int o = 0; o < 64; ++o) {
+            double bb = c[can::BASE0_B + o];
+            for (int k = 0; k < 32; ++k) bb += (double)c[can::BASE0_W + o * 207 + 175 + k] * bp2[k];
+            bc[o] = (float)bb;
+            for (int i = 0; i < 175; ++i) Wc[o * 207 + i] = c[can::BASE0_W + o * 207 + i];
+            for (int i = 0; i < 32; ++i) {
+                double a = 0;
+                for (int k = 0; k < 32; ++k) a += (double)c[can::BASE0_W + o * 207 + 175 + k] * Wp2[k * 32 + i];
+                Wc[o * 207 + 175 + i] = (float)a;
+            }
+        }
+        pack_bias(p + pk::B_HOIST, bc.data(), 4, natO, LOG2E);
+        pack_frag(p + pk::BASE1, Wc.data(), 207, 17, 4,
+                  [](int j, int g) {
+                      if (j < 9) { const int x = xfeat(j, g); return x < 0 ? -1 : 140 + x; }
+                      return 175 + nat_in(j - 9, g);
+                  }, natO, LOG2E, kTrue);
+    }
     pack_frag(p + pk::BASE2, c + can::BASE2_W, 64, 16, 2, natI, natO, LOG2E, kTilde);
     pack_bias(p + pk::B_BASE2, c + can::BASE2_B, 2, natO, LOG2E);
 
@@ -224,6 +253,11 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
         double acc = 0;
         for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT0_W + f * 16 + i] * (double)c[can::OUT1_W + f];
         p[pk::R_OUTVJP + i] = (float)acc;
+    }
+    {
+        double acc = c[can::OUT1_B];
+        for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT1_W + f] * (double)c[can::OUT0_B + f];
+        p[pk::R_OUTB] = (float)acc;
     }
     return GNR_OK;
 }

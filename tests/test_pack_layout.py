@@ -114,12 +114,10 @@ LAYERS = [
     ('dec2_aw', ('DEC2', 2048), ('B_DEC2', 64), 8, 2, 'dist_decoder.aw_decoder.2', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
     ('pe1', ('PE1', 0), ('B_PE1', 0), 9, 2, 'agg_net.prob_embed.0',
      lambda j, g: 8 * g + j if j < 8 else (32 if g == 0 else (33 if g == 1 else -1)), lambda nb, i: 16 * nb + i, TRUE, 1.0),
-    ('pe2', ('PE2', 0), ('B_PE2', 0), 8, 2, 'agg_net.prob_embed.2', nat, lambda nb, i: 16 * nb + i, TRUE, 1.0),
     ('rdf1', ('RDF1', 0), ('B_RDF1', 0), 1, 1, 'agg_net.agg_impl.ray_dir_fc.0', lambda j, g: g, lambda nb, i: i, TRUE, LOG2E),
     ('rdf2', ('RDF2', 0), ('B_RDF2', 0), 4, 3, 'agg_net.agg_impl.ray_dir_fc.2', nat,
      lambda nb, i: (3 + 8 * (i >> 2) + (i & 3)) if nb == 0 else ((3 + 8 * (i >> 2) + 4 + (i & 3)) if nb == 1 else
                                                                  ((i >> 2) if (i & 3) == 0 and (i >> 2) < 3 else -1)), TILDE, LOG2E),
-    ('nr1', ('NR1', 0), ('B_NR1', 0), 8, 1, 'agg_net.agg_impl.neuray_fc.0', nat, lambda nb, i: i if i < 8 else -1, TRUE, LOG2E),
     ('base2', ('BASE2', 0), ('B_BASE2', 0), 16, 2, 'agg_net.agg_impl.base_fc.2', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
     ('vis1', ('VIS1', 0), ('B_VIS1', 0), 8, 2, 'agg_net.agg_impl.vis_fc.0', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
     ('visb1', ('VISB1', 0), ('B_VISB1', 0), 8, 2, 'agg_net.agg_impl.vis_fc2.0', nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
@@ -149,10 +147,24 @@ def test_layer_fragments(spec, packed_and_sd):
     np.testing.assert_allclose(y, oscale * (x.astype(np.float64) @ W.T.astype(np.float64) + b), rtol=2e-5, atol=2e-5)
 
 
+def test_neuray_gate_with_folded_prob_embed2(packed_and_sd):
+    """NR1 fragments = neuray_fc.0 o prob_embed.2 applied to e1 = ReLU(prob_embed.0(...))."""
+    packed, sd = packed_and_sd
+    Wn, bn = sd['agg_net.agg_impl.neuray_fc.0.weight'], sd['agg_net.agg_impl.neuray_fc.0.bias']
+    Wp, bp = sd['agg_net.prob_embed.2.weight'], sd['agg_net.prob_embed.2.bias']
+    e1 = np.abs(np.random.default_rng(9).standard_normal((16, 32))).astype(np.float32)
+    acc = emulate(packed, off('NR1'), 8, 1, to_B(e1, 8, nat), bias_acc(packed, off('B_NR1'), 1))
+    y = from_D(acc, 1, lambda nb, i: i if i < 8 else -1, 8)
+    e = e1.astype(np.float64) @ Wp.T.astype(np.float64) + bp
+    np.testing.assert_allclose(y, LOG2E * (e @ Wn.T.astype(np.float64) + bn), rtol=2e-5, atol=2e-5)
+
+
 def test_base_fc0_split(packed_and_sd):
-    """HOIST (140 view-invariant columns + bias) + BASE1 (x 35, e 32) == base_fc.0 on the 207-wide concat."""
+    """HOIST (140 view-invariant columns + bias) + BASE1 (x 35, e1 32 with prob_embed.2 folded in) == base_fc.0 on the
+    207-wide concat [glob, x, prob_embed.2(e1)]."""
     packed, sd = packed_and_sd
     W, b = sd['agg_net.agg_impl.base_fc.0.weight'], sd['agg_net.agg_impl.base_fc.0.bias']
+    Wp, bp = sd['agg_net.prob_embed.2.weight'], sd['agg_net.prob_embed.2.bias']
     rng = np.random.default_rng(3)
     z = rng.standard_normal((16, 207)).astype(np.float32)
     B_h = to_B(z, 36, lambda j, g: (35 * (j // 9) + xfeat(j % 9, g)) if xfeat(j % 9, g) >= 0 else -1)
@@ -160,7 +172,9 @@ def test_base_fc0_split(packed_and_sd):
     B_v = to_B(z, 17, lambda j, g: ((140 + xfeat(j, g)) if xfeat(j, g) >= 0 else -1) if j < 9 else 175 + nat(j - 9, g))
     acc = emulate(packed, off('BASE1'), 17, 4, B_v, G)
     y = from_D(acc, 4, lambda nb, i: 16 * nb + i, 64)
-    np.testing.assert_allclose(y, LOG2E * (z.astype(np.float64) @ W.T.astype(np.float64) + b), rtol=2e-5, atol=2e-5)
+    zt = z.astype(np.float64).copy()
+    zt[:, 175:] = z[:, 175:].astype(np.float64) @ Wp.T.astype(np.float64) + bp      # what the reference concatenates
+    np.testing.assert_allclose(y, LOG2E * (zt @ W.T.astype(np.float64) + b), rtol=2e-5, atol=2e-5)
 
 
 def test_vis_fc2_rows_and_tables(packed_and_sd):
