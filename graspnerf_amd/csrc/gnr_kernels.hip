@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
     // it).  Each XCD sweeps its own contiguous eighth of the tile list, so consecutive tiles (= neighbouring
     // voxels / ray samples, i.e. neighbouring feature-map lines) share ONE L2 instead of being fetched into
     // all eight (measured before this: 7.7 GB fetched per launch against 0.8 GB of inputs).
-    constexpr int NXCD = 8;
+    const int NXCD = min(8, (int)gridDim.x);                               // tiny launches: fewer chunks than XCDs
     const int xcd = blockIdx.x % NXCD, lblk = blockIdx.x / NXCD;
     const int nlblk = ((int)gridDim.x - xcd + NXCD - 1) / NXCD;            // workgroups that share this XCD
     const int chunk = (ntiles + NXCD - 1) / NXCD;

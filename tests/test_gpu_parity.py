@@ -172,3 +172,62 @@ def test_other_view_counts(V, hot, W):
     for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'colors_nr'):
         close(o[k].cpu().numpy(), ref_o[k].numpy(), f'V={V} {k}')
     assert np.array_equal(o['ray_mask'].cpu().numpy(), ref_o['ray_mask'].numpy())
+
+
+def _shifted_scene(seed, V, bbox_shift, res_rn=(16, 64)):
+    """cfg1-sized scene whose workspace box is pushed partly out of the cameras' frusta: many points are seen by 0 or 1
+    views (n_valid < 1 -> sdf := 1, ibrnet.py:495; n_valid <= 1 -> uniform attention row)."""
+    cfgV = dict(CONFIGS['cfg1'], V=V)
+    ref, que = make_scene(seed, cfgV)
+    ref['bbox3d'] = (ref['bbox3d'] + np.asarray(bbox_shift, np.float32)).astype(np.float32)
+    return ref, que
+
+
+@pytest.mark.parametrize('shift', [(0.35, 0.0, 0.0), (0.0, 0.0, 0.9), (0.6, 0.6, 0.0)])
+def test_points_outside_most_views(shift, hot, W):
+    from graspnerf_amd.hotpath import batch_scenes
+    ref, que = _shifted_scene(11, 3, shift)
+    bref, bque = batch_scenes([(ref, que)])
+    dbg = {}
+    vol_o = O.sample_volume(W, O.to_torch(ref), 16, debug=dbg).numpy()
+    nv = dbg['mask'].sum(0).numpy()
+    assert (nv == 0).any() or (nv == 1).any(), 'test scene should contain unseen / singly-seen voxels'
+    vol, vm = hot.sample_volume(bref, 16, want_mask=True)
+    close(vol.cpu().numpy()[0], vol_o[0], f'shifted volume {shift}')
+    mine = vm.cpu().numpy()[0]
+    for v in range(3):                                             # masks bit-exact vs the oracle
+        mv = ((mine >> v) & 1).astype(bool).reshape(256, 16)[:, ::-1]
+        assert np.array_equal(mv, dbg['mask'][v].numpy().reshape(256, 16))
+    if (nv == 0).any():
+        assert np.all(vol.cpu().numpy()[0, 0].reshape(256, 16)[:, ::-1][nv.reshape(256, 16) == 0] == 1.0)
+
+
+@pytest.mark.parametrize('res,rn,dn', [(10, 3, 17), (12, 5, 3), (24, 2, 64)])
+def test_ragged_and_extreme_sizes(res, rn, dn, hot, W):
+    """Point counts that are not multiples of the 16-point MFMA tile, the smallest / largest samples-per-ray, and
+    grid sizes that disable (res % 8 != 0) or enable the brick-ordered traversal."""
+    from graspnerf_amd.hotpath import batch_scenes
+    cfgV = dict(CONFIGS['cfg1'], V=4, rn=rn)
+    scs = [make_scene(s, cfgV) for s in (21, 22)]
+    bref, bque = batch_scenes(scs)
+    vol = hot.sample_volume(bref, res).cpu().numpy()
+    depth = O.sample_depth(torch.from_numpy(scs[0][1]['depth_range']), rn, dn)
+    o = hot.render_by_depth(bref, bque, depth[None].repeat(2, 1, 1), 'fine')
+    for i, sc in enumerate(scs):
+        close(vol[i], O.sample_volume(W, O.to_torch(sc[0]), res).numpy()[0], f'res {res} scene {i}')
+        ref_o = O.render_by_depth(W, O.to_torch(sc[0]), O.to_torch(sc[1]), depth, 'fine_dist_decoder.', 'fine_agg_net.',
+                                  O.DEFAULT_RENDER_CFG)
+        for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth'):
+            close(o[k].cpu().numpy()[i], ref_o[k].numpy()[0], f'rn {rn} dn {dn} scene {i} {k}')
+        assert np.array_equal(o['ray_mask'].cpu().numpy()[i], ref_o['ray_mask'].numpy()[0])
+
+
+def test_bad_sizes_are_refused(hot):
+    from graspnerf_amd import _lib
+    scenes, (bref, bque) = _batched('cfg1')
+    with pytest.raises(_lib.GnrError):
+        hot.sample_volume(bref, 65)                                # volume_res > 64
+    with pytest.raises(_lib.GnrError):
+        hot.render(bref, bque, {'depth_sample_num': 2, 'fine_depth_sample_num': 16})
+    with pytest.raises(_lib.GnrError):
+        hot.render(bref, bque, {'depth_sample_num': 16, 'fine_depth_sample_num': 65})
