@@ -88,6 +88,9 @@ def lib():
     L.gnr_time_chain_kernel.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                         c_float_p, C.c_void_p]
     L.gnr_time_chain_kernel.restype = C.c_int
+    L.gnr_chain_timing_begin.restype = C.c_int
+    L.gnr_chain_timing_end.argtypes = [c_float_p, C.POINTER(C.c_int)]
+    L.gnr_chain_timing_end.restype = C.c_int
     L.gnr_last_error.restype = C.c_char_p
     L.gnr_dominant_kernel_name.restype = C.c_char_p
     _lib = L
@@ -98,7 +101,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
-            'gnr_head_last_error']
+            'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end']
 
 
 def check(rc, what):

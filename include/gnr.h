@@ -147,6 +147,10 @@ const char* gnr_head_last_error(void);
 /* name of the dominant kernel as it appears in rocprofv3 traces, and the last HIP error text */
 const char* gnr_dominant_kernel_name(void);
 const char* gnr_last_error(void);
+/* In-situ timing of the dominant kernel: between begin and end, every k_chain launch on volume points is
+ * bracketed by HIP events recorded on its launch stream (process-wide switch, measurement only). */
+int gnr_chain_timing_begin(void);
+int gnr_chain_timing_end(float* avg_ms_out, int* count_out);
 /* Time `iters` launches of the dominant kernel alone (volume points of `scene`) with HIP
  * events on `stream`; returns average milliseconds per launch in *ms_out. */
 int gnr_time_chain_kernel(const GnrScene* scene, int volume_res, const float* packed_coarse,
