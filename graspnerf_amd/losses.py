@@ -1,0 +1,103 @@
+"""Loss / metric terms of the reference evaluated on the forward outputs (first half): plain
+PyTorch reductions over the output dict, same keys and weights as `src/nr/network/loss.py` for the configured path
+(`loss: [render, depth, sdf, vgn]`, configs/nrvgn_sdf.yaml:36).  They run on whatever device the outputs live on.
+The training step itself (backward through the HIP path, RCCL gradient all-reduce) is not built in this round."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def render_loss(pr, use_ray_mask=True, weight=0.01, fine=True):
+    """ref: loss.py:50-85 (RenderLoss; use_nr_fine_loss per nrvgn_sdf.yaml:42)."""
+    gt = pr['pixel_colors_gt']
+
+    def one(rgb):
+        l = torch.sum((rgb - gt) ** 2, -1)
+        if use_ray_mask:
+            m = pr['ray_mask'].float()
+            l = torch.sum(l * m, 1) / (torch.sum(m, 1) + 1e-3)
+        else:
+            l = torch.mean(l, 1)
+        return l * weight
+    out = {'loss_rgb_nr': one(pr['pixel_colors_nr'])}
+    if fine and 'pixel_colors_nr_fine' in pr:
+        out['loss_rgb_nr_fine'] = one(pr['pixel_colors_nr_fine'])
+    return out
+
+
+def _bilinear_border_ac(maps, coords):
+    """maps [rfn,1,h,w], coords [rfn,pn,2] -> [rfn,pn]; interpolate_feats(..., 'border', align_corners=True) with
+    coords used as (x, y) (ref: ops.py:14-34; the reference passes (row, col) here, loss.py:104-110, kept)."""
+    rfn, _, h, w = maps.shape
+    c = coords.to(maps.dtype)
+    g = torch.stack([c[..., 0] / (w - 1) * 2 - 1, c[..., 1] / (h - 1) * 2 - 1], -1)[:, None]
+    return F.grid_sample(maps, g, mode='bilinear', padding_mode='border', align_corners=True)[:, 0, 0]
+
+
+def depth_loss(pr, true_depth, depth_range, weight=1.0):
+    """ref: loss.py:87-144 (DepthLoss, l2 in normalised inverse depth; non-'gso' scenes)."""
+    depth_gt = _bilinear_border_ac(true_depth, pr['depth_coords'])
+    near, far = -1 / depth_range[:, 0:1], -1 / depth_range[:, 1:2]
+
+    def norm(d):
+        d = -1 / torch.clamp(d, min=1e-5)
+        return torch.clamp((d - near) / (far - near), min=0, max=1.0)
+    gt = norm(depth_gt)
+    out = {'loss_depth': ((gt - pr['depth_mean']) ** 2).mean() * weight}
+    if 'depth_mean_fine' in pr:
+        out['loss_depth_fine'] = ((gt - pr['depth_mean_fine']) ** 2).mean() * weight
+    return out
+
+
+def sdf_loss(pr, sdf_gt, w_sdf=1.0, w_eik=0.1):
+    """ref: loss.py:149-178 (SDFLoss: SmoothL1 on valid = sdf_gt != -1, eikonal term, sdf_mae, variance)."""
+    valid = sdf_gt != -1.0
+    vol = pr['volume'][0, 0]
+    out = {'sdf_mae': (torch.abs(vol * valid - sdf_gt * valid).sum() / valid.sum().clamp(min=1))[None],
+           'loss_sdf': F.smooth_l1_loss(sdf_gt * valid, vol * valid)[None] * w_sdf,
+           'loss_eikonal': pr['sdf_gradient_error'].mean()[None] * w_eik,
+           'variance': pr['s'][None]}
+    return out
+
+
+def _quat_to_rot(q):
+    """xyzw -> rotation matrix (ref: base_utils.py:802-838)."""
+    q = q / torch.clamp(torch.sqrt((q ** 2).sum(1, keepdim=True)), min=1e-8)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    return torch.stack([1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w,
+                        2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w,
+                        2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y], 1).reshape(-1, 3, 3)
+
+
+def _geodesic_deg(m1, m2):
+    """ref: base_utils.py:791-800"""
+    m = torch.bmm(m1, m2.transpose(1, 2))
+    cos = ((m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1) / 2).clamp(-1, 1)
+    th = torch.acos(cos)
+    return torch.min(th, 2 * math.pi - th) * (180 / math.pi)
+
+
+def vgn_loss(vgn_pred, grasp_info, weight=1e-2):
+    """ref: loss.py:180-252 (VGNLoss).  vgn_pred = (label[N], rot[N,4], width[N]) gathered at the GT voxels
+    (GraspNeRF.select); grasp_info = (index, label[N], rotations[N,2,4], width[N])."""
+    label_pred, rot_pred, width_pred = vgn_pred
+    _, label, rots, width = grasp_info
+    l_qual = F.binary_cross_entropy(label_pred, label, reduction='none')
+    qloss = lambda t: 1.0 - torch.abs(torch.sum(rot_pred * t, dim=1))
+    l_rot = label * torch.min(qloss(rots[:, 0]), qloss(rots[:, 1]))
+    l_width = label * 0.01 * F.mse_loss(width_pred, width, reduction='none')
+    loss = l_qual + l_rot + l_width
+    out = {'loss_vgn': loss.mean()[None] * weight, 'vgn_total_loss': loss.mean()[None], 'vgn_qual_loss': l_qual.mean()[None],
+           'vgn_rot_loss': l_rot.mean()[None], 'vgn_width_loss': l_width.mean()[None],
+           'vgn_qual_acc': (100 * (torch.round(label_pred) == label).float().sum() / label.shape[0])[None]}
+    num = torch.count_nonzero(label)
+    pr_m = _quat_to_rot(rot_pred)
+    err = torch.min(_geodesic_deg(_quat_to_rot(rots[:, 0]), pr_m), _geodesic_deg(_quat_to_rot(rots[:, 1]), pr_m))
+    out['vgn_rot_err'] = ((label * err).sum() / num)[None] if num else torch.zeros(1, device=label.device)
+    return out
+
+
+def total_loss(terms):
+    """Sum of every entry whose key starts with 'loss' (ref: train/trainer.py:147-155)."""
+    return sum(v.mean() for k, v in terms.items() if k.startswith('loss'))

@@ -91,3 +91,25 @@ def synth_state_dict(shapes, seed=7):
             v = (0.05 * rng.standard_normal(shp)).astype(np.float32)
         out[k] = v
     return out
+
+
+def synth_loss_case(seed=5, rfn=3, h=96, w=128, rn=64, pn=256, R=16, N=12):
+    """Random (prediction, ground truth) tensors in the shapes the reference's losses consume (loss.py); the golden
+    stores the reference's loss values for exactly these tensors."""
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.random(s).astype(np.float32)
+    pr = {'pixel_colors_gt': f(1, rn, 3), 'pixel_colors_nr': f(1, rn, 3), 'pixel_colors_nr_fine': f(1, rn, 3),
+          'ray_mask': rng.random((1, rn)) > 0.3,
+          'depth_coords': np.repeat(np.stack([rng.integers(0, h, pn), rng.integers(0, w, pn)], -1)[None], rfn, 0).astype(np.int64),
+          'depth_mean': f(rfn, pn), 'depth_mean_fine': f(rfn, pn),
+          'volume': (f(1, 1, R, R, R) * 2 - 1), 'sdf_gradient_error': f(1, 1), 's': np.full((1, 1), 0.3, np.float32)}
+    q = rng.standard_normal((N, 4)).astype(np.float32)
+    pr['vgn_pred'] = (f(N) * 0.98 + 0.01, q / np.linalg.norm(q, axis=1, keepdims=True), f(N) * 0.08)
+    sdf_gt = (f(R, R, R) * 2 - 1)
+    sdf_gt[rng.random((R, R, R)) < 0.3] = -1.0
+    r2 = rng.standard_normal((N, 2, 4)).astype(np.float32)
+    gt = {'true_depth': 0.2 + 0.6 * f(rfn, 1, h, w), 'depth_range': np.repeat(np.asarray([[0.2, 0.8]], np.float32), rfn, 0),
+          'sdf_gt': sdf_gt,
+          'grasp_info': (rng.integers(0, 40, (N, 3)).astype(np.int64), (rng.random(N) > 0.5).astype(np.float32),
+                         r2 / np.linalg.norm(r2, axis=2, keepdims=True), f(N) * 0.08)}
+    return pr, gt

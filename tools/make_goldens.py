@@ -28,7 +28,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 from ref_import import import_reference, REF  # noqa: E402
-from graspnerf_amd.synth import make_scene, CONFIGS, synth_state_dict  # noqa: E402
+from graspnerf_amd.synth import make_scene, CONFIGS, synth_state_dict, synth_loss_case  # noqa: E402
 
 HOT = ('dist_decoder.', 'fine_dist_decoder.', 'agg_net.', 'fine_agg_net.')
 
@@ -182,8 +182,44 @@ def run_full_forward(renderer):
     print('full forward golden:', {k: v.shape for k, v in g.items()})
 
 
+def run_losses():
+    """Reference losses (loss.py) on synth_loss_case tensors -> tests/golden/golden_losses.npz."""
+    import types
+    for name in ('pyquaternion', 'torchmetrics', 'cv2', 'h5py', 'plyfile', 'skimage', 'skimage.io', 'skimage.metrics',
+                 'transforms3d', 'transforms3d.axangles', 'transforms3d.euler', 'open3d'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            return None
+    for name in list(sys.modules):
+        if name.split('.')[0] in ('pyquaternion', 'torchmetrics', 'cv2', 'h5py', 'plyfile', 'skimage', 'transforms3d', 'open3d') and not isinstance(sys.modules[name], _Any):
+            sys.modules[name] = _Any(name)
+    sys.modules['skimage.io'].imread = sys.modules['skimage.io'].imsave = None
+    sys.modules['transforms3d.axangles'].mat2axangle = None
+    sys.modules['transforms3d.euler'].mat2euler = sys.modules['transforms3d.euler'].euler2mat = None
+    sys.modules['plyfile'].PlyData = None
+    sys.modules['skimage.metrics'].structural_similarity = None
+    import network.loss as L
+    pr, gt = synth_loss_case()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    data_pr = {k: (tuple(t(x) for x in v) if isinstance(v, tuple) else t(v)) for k, v in pr.items()}
+    data_gt = {'ref_imgs_info': {'true_depth': t(gt['true_depth']), 'depth_range': t(gt['depth_range']), 'sdf_gt': t(gt['sdf_gt'])},
+               'grasp_info': tuple(t(x) for x in gt['grasp_info']), 'scene_name': 'vgn_syn/train/pile/x'}
+    out = {}
+    out.update(L.RenderLoss({'use_nr_fine_loss': True})(data_pr, data_gt, 0, True))
+    out.update(L.DepthLoss({})(data_pr, data_gt, 0, True))
+    out.update(L.SDFLoss({})(data_pr, data_gt, 0, True))
+    out.update(L.VGNLoss({})(data_pr, data_gt, 0, True))
+    g = {k: np.asarray(v.detach().numpy(), np.float64).reshape(-1) for k, v in out.items()}
+    np.savez_compressed(ROOT + '/tests/golden/golden_losses.npz', **g)
+    print('losses golden:', {k: float(v[0]) for k, v in g.items()})
+
+
 def main():
     renderer = import_reference()
+    if '--losses-only' in sys.argv:
+        return run_losses()
     if '--full-only' in sys.argv:
         return run_full_forward(renderer)
     os.makedirs(ROOT + '/tests/golden', exist_ok=True)
@@ -209,6 +245,7 @@ def main():
         for k, v in out.items():
             print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
     run_full_forward(renderer)
+    run_losses()
 
 
 if __name__ == '__main__':
