@@ -315,8 +315,11 @@ constexpr int SW = 20;
 #endif
 constexpr int view_unroll(int V) { return (GNR_VIEW_UNROLL >= 3 && V % 3 == 0) ? 3 : ((GNR_VIEW_UNROLL >= 2 && V % 2 == 0) ? 2 : 1); }     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c rgb
 
+#ifndef GNR_CHAIN_THREADS
+#define GNR_CHAIN_THREADS 512     // 8 wavefronts = 2 per SIMD at <= 256 registers; 256 (1 per SIMD, 512 registers) was measured too
+#endif
 template <int V, bool RENDER>
-__global__ __launch_bounds__(512, 2) void k_chain(ChainArgs a) {
+__global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ---- stage the CHAIN section of the packed weights into LDS (once per workgroup)
     {
