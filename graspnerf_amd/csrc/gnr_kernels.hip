@@ -53,11 +53,22 @@ DEV float gsum(float x) {
 // ---------------------------------------------------------------------------------------
 // chained-MFMA layer:  acc[nb] += W_frag(j, nb) * in[j]   for k-steps j in [J0, J0+J)
 // ---------------------------------------------------------------------------------------
+#ifndef GNR_LICM_FENCE
+#define GNR_LICM_FENCE 1
+#endif
+#if GNR_LICM_FENCE
+#define GNR_LAYER_FENCE() asm volatile("" ::: "memory")
+#else
+#define GNR_LAYER_FENCE() ((void)0)
+#endif
+#define GNR_ITER_FENCE() asm volatile("" ::: "memory")
+
 template <int J, int NB, int J0 = 0>
 DEV void mm(const float* __restrict__ w, int lane, const float (&in)[J], f4 (&acc)[NB]) {
-    // The weight image in LDS is loop-invariant; without this the compiler hoists every fragment
-    // load out of the view/tile loops (LICM) and spills hundreds of registers.
-    asm volatile("" ::: "memory");
+    // The weight image in LDS is loop-invariant; without a compiler barrier the fragment loads are hoisted
+    // out of the view/tile loops (LICM) and hundreds of registers spill.  GNR_LICM_FENCE 1 = fence at every
+    // layer (default), 0 = one fence per loop iteration only (lets the scheduler hoist loads across layers).
+    GNR_LAYER_FENCE();
     if constexpr (NB == 4 || NB == 3) {
         const f4* w4 = reinterpret_cast<const f4*>(w) + J0 * 64 + lane;
 #pragma unroll
@@ -95,7 +106,7 @@ DEV void mm(const float* __restrict__ w, int lane, const float (&in)[J], f4 (&ac
 
 template <int NB>
 DEV void load_bias(const float* __restrict__ b, int g, f4 (&acc)[NB]) {
-    asm volatile("" ::: "memory");
+    GNR_LAYER_FENCE();
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = reinterpret_cast<const f4*>(b)[nb * 4 + g];
 }
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
     const int chunk = (ntiles + NXCD - 1) / NXCD;
     const int t_end = min(ntiles, (xcd + 1) * chunk);
     for (int tile = xcd * chunk + lblk * waves_per_block + wave; tile < t_end; tile += nlblk * waves_per_block) {
+        GNR_ITER_FENCE();
         const int b = tile / tps;
         int ts = tile - b * tps;
         if (a.vol_res > 0) {
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
 #pragma unroll
           for (int vu = 0; vu < UNR; ++vu) {
             __builtin_amdgcn_sched_barrier(0);
+            GNR_ITER_FENCE();
             const int v = v0 + vu;
             float (&Sv)[SW] = S[V - UNR + vu];
             const int bv = b * V + v;
@@ -556,6 +569,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
 #pragma unroll
           for (int vu = 0; vu < UNR; ++vu) {
             __builtin_amdgcn_sched_barrier(0);
+            GNR_ITER_FENCE();
             const int v = v0 + vu;
             float (&X)[9] = X2[vu];
             float (&E)[8] = E2[vu];

@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the C-ABI library is built in-tree and git-ignored: build it on a fresh checkout (hipcc cross-compiles gfx950
+    # without a GPU).  On the GPU box the prebuilt .so travels with the snapshot.
+    so = os.path.join(ROOT, 'graspnerf_amd', 'csrc', 'libgnr.so')
+    if not os.path.exists(so):
+        import shutil
+        import subprocess
+        if shutil.which('hipcc'):
+            subprocess.check_call(['bash', os.path.join(ROOT, 'graspnerf_amd', 'csrc', 'build.sh')])
 
 
 @pytest.fixture(scope='session')
