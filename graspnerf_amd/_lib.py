@@ -22,7 +22,8 @@ class GnrRays(C.Structure):
     _fields_ = [('rn', C.c_int), ('dn', C.c_int), ('fdn', C.c_int),
                 ('ray_mask_view_num', C.c_int), ('ray_mask_point_num', C.c_int),
                 ('coords', C.c_void_p), ('que_pose', C.c_void_p), ('que_K', C.c_void_p),
-                ('que_depth_range', C.c_void_p), ('que_imgs', C.c_void_p)]
+                ('que_depth_range', C.c_void_p), ('que_imgs', C.c_void_p), ('fine_u', C.c_void_p),
+                ('ray_batch_num', C.c_int)]
 
 
 RENDER_OUT_FIELDS = ['depth', 'sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr',

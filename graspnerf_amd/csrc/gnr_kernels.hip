@@ -738,6 +738,7 @@ struct RayArgs {
     int view_num, point_num;
     // inverse-CDF resampling (coarse pass only; nullable)
     float* fine_depth; int* fine_inds; int fdn;
+    const float* fine_u;     // [nrays][fdn] caller-drawn samples (is_train) or null (eval midpoints)
 };
 
 // wave-level ordering of LDS traffic between lanes of the same wavefront
@@ -1105,7 +1106,8 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             wave_sync();
             const bool fact = lane < fdn;
             const float interval = 1.f / (float)fdn;
-            const float u = __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)lane, interval));
+            const float u = a.fine_u ? (fact ? a.fine_u[(size_t)ray * fdn + lane] : 0.f)
+                                     : __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)lane, interval));
             int inds = 0;
 #pragma unroll 8
             for (int j = 0; j <= dn; ++j) inds += (Cd[j] <= u) ? 1 : 0;          // searchsorted(right=True)
@@ -1185,16 +1187,18 @@ __global__ __launch_bounds__(256) void k_depth_mean(DepthMeanArgs a) {
     }
 }
 
-// mean over the scene's rays of the per-ray partial sums / (rn*dn)   (aggregate_net.py:139)
-__global__ void k_gerr_reduce(const float* __restrict__ part, float* __restrict__ out, int rn, int dn) {
+// mean over one chunk of a scene's rays of the per-ray partial sums / (rays*dn)   (aggregate_net.py:139; the
+// reference renders chunks of ray_batch_num rays, renderer.py:203-215).  grid (B, n_chunks); out [B][n_chunks]
+__global__ void k_gerr_reduce(const float* __restrict__ part, float* __restrict__ out, int rn, int dn, int chunk) {
     __shared__ float red[256];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, c = blockIdx.y;
+    const int r0 = c * chunk, r1 = min(rn, r0 + chunk);
     float s = 0.f;
-    for (int i = threadIdx.x; i < rn; i += 256) s += part[(size_t)b * rn + i];
+    for (int i = r0 + threadIdx.x; i < r1; i += 256) s += part[(size_t)b * rn + i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) out[b] = red[0] / (float)(rn * dn);
+    if (threadIdx.x == 0) out[(size_t)b * gridDim.y + c] = red[0] / ((float)(r1 - r0) * (float)dn);
 }
 
 // pixel_colors_gt: bilinear, zeros padding, align_corners=True  (renderer.py:125-127, ops.py:29-33)

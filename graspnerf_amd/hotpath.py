@@ -96,18 +96,25 @@ class HotPath:
         if imgs is not None:
             assert imgs.shape == (B, 3, H, W)
             t['imgs'] = imgs
+        fine_u = None
+        if que.get('fine_u') is not None:            # is_train: caller-drawn inverse-CDF samples (render_ops.py:204-205)
+            fine_u = t['fine_u'] = _f32(que['fine_u'], d)
+            assert fine_u.shape == (B, rn, fdn)
+        chunk = int(cfg.get('ray_batch_num', 0) or 0)
         r = GnrRays(rn, dn, fdn, cfg.get('ray_mask_view_num', 2), cfg.get('ray_mask_point_num', 8),
                     t['coords'].data_ptr(), t['pose'].data_ptr(), t['K'].data_ptr(), t['depth_range'].data_ptr(),
-                    imgs.data_ptr() if imgs is not None else None)
+                    imgs.data_ptr() if imgs is not None else None,
+                    fine_u.data_ptr() if fine_u is not None else None, chunk)
         return r, t
 
-    def _alloc_out(self, B, rn, dn, with_gt, debug):
+    def _alloc_out(self, B, rn, dn, with_gt, debug, chunk=0):
         d = self.device
+        nch = (rn + chunk - 1) // chunk if chunk > 0 else 1
         o = {'depth': torch.empty(B, rn, dn, device=d), 'sdf_values': torch.empty(B, rn, dn, device=d),
              'alpha_values': torch.empty(B, rn, dn, device=d), 'colors_nr': torch.empty(B, rn, dn, 3, device=d),
              'hit_prob_nr': torch.empty(B, rn, dn, device=d), 'pixel_colors_nr': torch.empty(B, rn, 3, device=d),
              'render_depth': torch.empty(B, rn, device=d), 'ray_mask': torch.empty(B, rn, dtype=torch.uint8, device=d),
-             'sdf_gradient_error': torch.empty(B, device=d)}
+             'sdf_gradient_error': torch.empty(B, nch, device=d) if chunk > 0 else torch.empty(B, device=d)}
         if with_gt:
             o['pixel_colors_gt'] = torch.empty(B, rn, 3, device=d)
         if debug:
@@ -125,8 +132,8 @@ class HotPath:
         B, rn = que['coords'].shape[:2]
         scene, keep, ws = prepared or self.prepare(ref, 1, rn, max(dn, fdn))
         rays, rkeep = self._rays(que, dn, fdn, cfg, scene.H, scene.W)
-        co_s, co = self._alloc_out(B, rn, dn, 'imgs' in que, debug)
-        fi_s, fi = self._alloc_out(B, rn, fdn, 'imgs' in que, debug)
+        co_s, co = self._alloc_out(B, rn, dn, 'imgs' in que, debug, rays.ray_batch_num)
+        fi_s, fi = self._alloc_out(B, rn, fdn, 'imgs' in que, debug, rays.ray_batch_num)
         fd_in = _f32(fine_depth_in, self.device) if fine_depth_in is not None else None
         inds = torch.empty(B, rn, fdn, dtype=torch.int32, device=self.device) if debug else None
         _lib.check(self.L.gnr_render_rays_fwd(C.byref(scene), C.byref(rays), self.wc.data_ptr(), self.wf.data_ptr(),
@@ -144,7 +151,7 @@ class HotPath:
         B, rn, dn = depth.shape
         scene, keep, ws = prepared or self.prepare(ref, 1, rn, dn)
         rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
-        o_s, o = self._alloc_out(B, rn, dn, 'imgs' in que, debug)
+        o_s, o = self._alloc_out(B, rn, dn, 'imgs' in que, debug, rays.ray_batch_num)
         w = self.wc if level == 'coarse' else self.wf
         _lib.check(self.L.gnr_render_by_depth_fwd(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
                                                   C.byref(o_s), ws.data_ptr(), ws.numel(), self._stream()),

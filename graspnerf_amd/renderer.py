@@ -79,6 +79,7 @@ class _AggNetParams(nn.Module):
         self.prob_embed = _mlp([34, 32, 32])
         self.agg_impl = _AggImplParams()
         self.deviation_network = _Deviation(cfg.get('init_s', 0.3))
+        self.step = 0                                                      # aggregate_net.py:99
 
 
 class NeuralRayRenderer(nn.Module):
@@ -154,7 +155,14 @@ class NeuralRayRenderer(nn.Module):
     def _render_cfg(self):
         c = self.cfg
         return {'depth_sample_num': c['depth_sample_num'], 'fine_depth_sample_num': c['fine_depth_sample_num'],
-                'ray_mask_view_num': c['ray_mask_view_num'], 'ray_mask_point_num': c['ray_mask_point_num']}
+                'ray_mask_view_num': c['ray_mask_view_num'], 'ray_mask_point_num': c['ray_mask_point_num'],
+                'ray_batch_num': c['ray_batch_num']}
+
+    @staticmethod
+    def draw_fine_u(rn, fdn, chunk):
+        """The is_train inverse-CDF samples exactly as the reference draws them: one torch.rand([1,chunk_rn,fdn])
+        on the default (CPU) generator per ray chunk, in chunk order (render_ops.py:204-205, renderer.py:207-209)."""
+        return torch.cat([torch.rand([1, min(chunk, rn - r0), fdn]) for r0 in range(0, rn, chunk)], 1)
 
     # ---- the reference's methods ------------------------------------------------------------------
     def sample_volume(self, ref_imgs_info, _prep=None):                     # renderer.py:164-199
@@ -168,16 +176,26 @@ class NeuralRayRenderer(nn.Module):
         if self.cfg['render_depth']:
             keys.append('render_depth')
         out = {k + suffix: o[k] for k in keys}
-        out['sdf_gradient_error' + suffix] = o['sdf_gradient_error'].reshape(1, 1)
-        out['s' + suffix] = level_net.deviation_network.variance.reshape(1, 1)
+        # the reference renders chunks of ray_batch_num rays and concatenates one [1,1] value per chunk
+        # (renderer.py:203-218); here all rays go in one launch and the per-chunk means come back as [1,n_chunks]
+        ge = o['sdf_gradient_error'].reshape(1, -1)
+        out['sdf_gradient_error' + suffix] = ge
+        out['s' + suffix] = level_net.deviation_network.variance.reshape(1, 1).expand(1, ge.shape[1])
         return out
 
     def render(self, que_imgs_info, ref_imgs_info, is_train, _prep=None):   # renderer.py:201-220 (+140-162)
+        rn = que_imgs_info['coords'].shape[1]
+        bref, prep = _prep or self._prepare(ref_imgs_info, rn)
+        bque = self._batched_que(que_imgs_info)
         if is_train:
-            raise NotImplementedError('training-mode rendering (random fine sampling, backward) is not built; '
-                                      'DESIGN.md §7')
-        bref, prep = _prep or self._prepare(ref_imgs_info, que_imgs_info['coords'].shape[1])
-        co, fi = self.hot().render(bref, self._batched_que(que_imgs_info), self._render_cfg(), prepared=prep)
+            # forward values only (no autograd through the HIP path).  The reference draws the
+            # inverse-CDF samples per chunk with torch.rand on the CPU generator (render_ops.py:204-208): same
+            # draws, same order, so a seeded run samples the same fine depths.
+            fdn, chunk = self.cfg['fine_depth_sample_num'], self.cfg['ray_batch_num']
+            bque['fine_u'] = self.draw_fine_u(rn, fdn, chunk)
+            for net in (self.agg_net, self.fine_agg_net):          # aggregate_net.py:135-137 bookkeeping
+                net.step += (rn + chunk - 1) // chunk
+        co, fi = self.hot().render(bref, bque, self._render_cfg(), prepared=prep)
         out = self._out_dict(co, '', self.agg_net)
         out.update(self._out_dict(fi, '_fine', self.fine_agg_net))
         return out

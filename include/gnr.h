@@ -54,6 +54,13 @@ typedef struct GnrRays {
     const float* que_K;       /* [B,3,3]                                                    */
     const float* que_depth_range; /* [B,2]                                                  */
     const float* que_imgs;    /* [B,3,H,W] or NULL (then pixel_colors_gt is not written)    */
+    const float* fine_u;      /* [B,rn,fdn] in [0,1) or NULL.  is_train=True draws the inverse-CDF
+                                 samples with torch.rand (render_ops.py:204-205): the caller draws them
+                                 (same generator, same shape as the reference) and passes them here;
+                                 NULL = eval mode, u_i = (i+.5)/fdn (render_ops.py:200-203)            */
+    int ray_batch_num;        /* cfg ray_batch_num (renderer.py:203-215): the reference renders rays in
+                                 chunks and returns one sdf_gradient_error per chunk; >0 -> the output
+                                 is [B, ceil(rn/ray_batch_num)] chunk means, 0 -> one mean per scene   */
 } GnrRays;
 
 /* Outputs of one render pass (coarse or fine).  Keys follow renderer.py:90-138; any
@@ -68,7 +75,8 @@ typedef struct GnrRenderOut {
     float* pixel_colors_gt;    /* [B,rn,3]                                                  */
     float* render_depth;       /* [B,rn]                                                    */
     unsigned char* ray_mask;   /* [B,rn] 0/1                                                */
-    float* sdf_gradient_error; /* [B]   mean((|grad|-1)^2) over the scene's rays            */
+    float* sdf_gradient_error; /* [B, n_chunks] mean((|grad|-1)^2) per chunk of ray_batch_num rays
+                                  (n_chunks = 1 when GnrRays.ray_batch_num == 0)            */
     float* sdf_gradient;       /* [B,rn,dn,3] optional (debug / eikonal loss)               */
     unsigned char* view_mask;  /* [B,rn,dn] optional: bit v = point inside view v's image   */
 } GnrRenderOut;

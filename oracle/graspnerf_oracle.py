@@ -384,8 +384,9 @@ def render_by_depth(sd, inp, que, depth, dec, agg, cfg, debug=None):
     return out
 
 
-def sample_fine_depth(depth, hit_prob, depth_range, fdn):
-    """Inverse-CDF resampling in normalised inverse depth, eval mode (deterministic u).
+def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None):
+    """Inverse-CDF resampling in normalised inverse depth.  u=None: eval mode (deterministic midpoints,
+    render_ops.py:200-203); u [rn,fdn]: the is_train draws of torch.rand (render_ops.py:204-205).
     -> fine depth [rn,fdn] (unsorted), inds [rn,fdn] int64.   ref: render_ops.py:172-229."""
     near, far = -1 / depth_range[0], -1 / depth_range[1]
     d = (-1 / depth - near) / (far - near)
@@ -394,7 +395,9 @@ def sample_fine_depth(depth, hit_prob, depth_range, fdn):
     pdf = hp / torch.sum(hp, -1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)  # [rn,dn+1]
     interval = 1 / fdn
-    u = (0.5 * interval + torch.arange(fdn) * interval)[None].expand(depth.shape[0], fdn).contiguous()
+    if u is None:
+        u = (0.5 * interval + torch.arange(fdn) * interval)[None].expand(depth.shape[0], fdn)
+    u = u.contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = (inds - 1).clamp(min=0)
     above = inds.clamp(max=cdf.shape[-1] - 1)
@@ -412,8 +415,8 @@ DEFAULT_RENDER_CFG = {'depth_sample_num': 40, 'fine_depth_sample_num': 40,
                       'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
 
 
-def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None):
-    """Coarse + fine ray rendering, eval mode.  `fine_depth_override` [rn,fdn] (sorted)
+def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None, fine_u=None):
+    """Coarse + fine ray rendering; eval mode unless `fine_u` [rn,fdn] supplies the is_train random draws.  `fine_depth_override` [rn,fdn] (sorted)
     teacher-forces the fine pass: inverse-CDF resampling is ill-conditioned where the coarse
     pdf is ~0 (a 3e-5 change of hit_prob moves a fine sample by ~1e-2 of the depth range), so
     tight fine-pass parity is checked on identical sample positions.  que: dict(coords[rn,2], pose[3,4], K[3,3],
@@ -426,7 +429,7 @@ def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None):
     depth = sample_depth(que['depth_range'], rn, cfg['depth_sample_num'])
     out = render_by_depth(sd, inp, que, depth, 'dist_decoder.', 'agg_net.', cfg, dbg_c)
     fd, inds = sample_fine_depth(depth, out['hit_prob_nr'][0], que['depth_range'],
-                                 cfg['fine_depth_sample_num'])
+                                 cfg['fine_depth_sample_num'], fine_u)
     fdepth = torch.sort(fd, -1)[0]                                         # renderer.py:148
     if fine_depth_override is not None:
         fdepth = fine_depth_override

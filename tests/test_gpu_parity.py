@@ -90,6 +90,29 @@ def test_render_matches_reference(name, hot, W, golden):
     close(fi['sdf_gradient'].cpu().numpy()[0], dbo['fine']['grad'].numpy(), 'fine sdf gradient', atol=2e-3)
 
 
+def test_train_mode_render_matches_reference(hot, golden):
+    """is_train=True forward: caller-drawn random inverse-CDF samples (GnrRays.fine_u) and per-chunk
+    sdf_gradient_error (GnrRays.ray_batch_num = 24 -> 3 chunks of the 64 rays)."""
+    G = golden('train_cfg1')
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16, 'ray_batch_num': int(G['ray_batch_num'])}
+    scenes, (bref, bque) = _batched('cfg1')
+    bque = dict(bque, fine_u=G['fine_u'][None])
+    co, fi, inds = hot.render(bref, bque, cfg, fine_depth_in=G['fine_depth_sorted'][None], debug=True)
+    torch.cuda.synchronize()
+    assert (inds.cpu().numpy()[0] != G['fine_inds']).mean() <= 2e-3
+    for k in ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth',
+              'sdf_gradient_error']:
+        assert co[k].shape[1:] == G['render.' + k].shape[1:], k
+        close(co[k].cpu().numpy(), G['render.' + k], 'coarse ' + k)
+        close(fi[k].cpu().numpy(), G['render.' + k + '_fine'], 'fine ' + k)
+    assert co['sdf_gradient_error'].shape == (1, 3)
+    # free-running: the kernel's own resampled + sorted depths
+    co2, fi2 = hot.render(bref, bque, cfg)
+    fd = fi2['depth'].cpu().numpy()[0]
+    assert np.all(np.diff(fd, axis=1) >= 0)
+    assert np.mean(np.abs(fd - G['fine_depth_sorted']) > 1e-3) < 0.02
+
+
 def test_free_running_fine_depths(hot, golden):
     """End to end (no teacher forcing): resampled depths agree with the reference except on the
     ill-conditioned samples; sorted ascending; inside the depth range."""

@@ -117,6 +117,41 @@ def test_full_forward_matches_reference(model, G):
 
 
 @pytest.mark.gpu
+def test_train_mode_forward_values(model):
+    """No 'eval' key -> is_train=True (renderer.py:271): random fine sampling from the CPU generator, per-chunk
+    `s` / `sdf_gradient_error` of shape [1,n_chunks]; same seed -> same outputs; counters advance."""
+    net = model.cuda()
+    old_chunk, net.nr_net.cfg['ray_batch_num'] = net.nr_net.cfg['ray_batch_num'], 24
+    step0 = net.nr_net.agg_net.step
+    ref, que = make_scene(0, 'cfg1')
+    t = lambda a: torch.from_numpy(a).cuda()
+    ref_info = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    data = {'step': 0, 'full_vol': True, 'ref_imgs_info': ref_info, 'que_imgs_info': que_info,
+            'src_imgs_info': dict(ref_info)}
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        with torch.no_grad():
+            outs.append(net(data))
+    torch.cuda.synchronize()
+    a, b = outs
+    assert a['s'].shape == (1, 3) and a['sdf_gradient_error_fine'].shape == (1, 3)
+    # (the PyTorch backbones may pick another MIOpen algorithm on the second call: compare with tolerance)
+    far = lambda x, y: ((x - y).abs() > 1e-3).float().mean().item()
+    assert far(a['sdf_values_fine'], b['sdf_values_fine']) < 0.02 and far(a['volume'], b['volume']) == 0.0
+    assert 'depth_mean' not in a                                   # eval-only without depth supervision (renderer.py:288)
+    assert net.nr_net.agg_net.step == step0 + 6 and net.nr_net.fine_agg_net.step == step0 + 6
+    torch.manual_seed(6)
+    with torch.no_grad():
+        c = net(data)
+    net.nr_net.cfg['ray_batch_num'] = old_chunk
+    assert far(a['sdf_values_fine'], c['sdf_values_fine']) > 0.2             # other draws, other fine samples
+    assert far(a['sdf_values'], c['sdf_values']) == 0.0                      # coarse pass does not depend on them
+
+
+@pytest.mark.gpu
 def test_hipgraph_replay_equals_eager(model):
     """The whole forward (PyTorch backbones + libgnr kernels + HIP grasp head) is hipGraph-capturable."""
     from graspnerf_amd.graph import GraphedForward

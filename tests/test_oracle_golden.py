@@ -52,6 +52,35 @@ def test_oracle_matches_reference(name, res, dn, weights_np, golden):
             assert np.abs(v - g).max() < TOL, (k, np.abs(v - g).max())
 
 
+def test_oracle_train_mode_sampling(weights_np, golden):
+    """is_train=True: random inverse-CDF samples (the reference's torch.rand draws, recorded in the fixture)
+    and per-chunk gradient-error outputs (ray_batch_num=24 -> chunks of 24/24/16 rays)."""
+    G = golden('train_cfg1')
+    ref, que = make_scene(0, 'cfg1')
+    W = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16}
+    dbg = {}
+    out = O.render(W, O.to_torch(ref), O.to_torch(que), cfg, debug=dbg, fine_u=torch.from_numpy(G['fine_u']),
+                   fine_depth_override=torch.from_numpy(G['fine_depth_sorted']))
+    assert (dbg['fine_inds'].numpy() != G['fine_inds']).mean() < 1e-3
+    for k in ['sdf_values', 'alpha_values', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth']:
+        for sfx in ('', '_fine'):
+            assert np.abs(out[k + sfx].numpy() - G['render.' + k + sfx]).max() < TOL, k + sfx
+    # free-running resampling (no teacher forcing) on the same u
+    dbg2 = {}
+    O.render(W, O.to_torch(ref), O.to_torch(que), cfg, debug=dbg2, fine_u=torch.from_numpy(G['fine_u']))
+    assert np.mean(np.abs(dbg2['fine_depth'].numpy() - G['fine_depth_sorted']) > 1e-3) < 0.02
+
+
+def test_train_mode_draws_follow_the_reference(golden):
+    """The host-side draw of the random samples reproduces the reference's RNG stream for a seed."""
+    from graspnerf_amd.renderer import NeuralRayRenderer
+    G = golden('train_cfg1')
+    torch.manual_seed(int(G['seed']))
+    u = NeuralRayRenderer.draw_fine_u(64, 16, int(G['ray_batch_num']))
+    assert np.array_equal(u.numpy()[0], G['fine_u'])
+
+
 def test_grid_index_map():
     """volume[0,0,x,y,z] <-> bbox_min + ((x,y,z)+.5)*s   (ref: field_utils.py:17-27)."""
     g = O.grid_points(40)

@@ -140,6 +140,49 @@ def run_reference(renderer, net, cfg, ref, que, res):
     return out
 
 
+def run_train_mode(renderer, weights):
+    """render(..., is_train=True) of the reference on cfg1 with ray_batch_num=24 (64 rays -> chunks 24/24/16):
+    pins the random inverse-CDF sampling (torch.rand on the CPU generator, render_ops.py:204-205) and the
+    per-chunk outputs `sdf_gradient_error` / `s` of shape [1,n_chunks] (renderer.py:203-218)."""
+    import network.render_ops as rops   # noqa: F401
+    net, cfg = build_net(renderer, 16, 16)
+    load_weights(net, weights)
+    net.cfg['ray_batch_num'] = 24
+    ref, que = make_scene(0, 'cfg1')
+    t = lambda a: torch.from_numpy(a.copy())
+    ref_info = {k: t(v) for k, v in ref.items()}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    cap = {'u': [], 'inds': [], 'fds': []}
+    orig_ss, orig_sort = torch.searchsorted, torch.sort
+
+    def ss(cdf, u, **kw):
+        r = orig_ss(cdf, u, **kw)
+        cap['u'].append(u.clone()); cap['inds'].append(r.clone())
+        return r
+
+    def srt(x, *a, **kw):
+        r = orig_sort(x, *a, **kw)
+        cap['fds'].append(r[0].clone())
+        return r
+    torch.searchsorted, torch.sort = ss, srt
+    try:
+        torch.manual_seed(7)
+        with torch.no_grad():
+            rend = net.render(que_info, ref_info, True)
+    finally:
+        torch.searchsorted, torch.sort = orig_ss, orig_sort
+    out = {'render.' + k: v.numpy() for k, v in rend.items()}
+    out['fine_u'] = torch.cat(cap['u'], 1).numpy()[0]
+    out['fine_inds'] = torch.cat(cap['inds'], 1).numpy()[0].astype(np.int64)
+    out['fine_depth_sorted'] = torch.cat(cap['fds'], 1).numpy()[0]
+    out['seed'] = np.int64(7)
+    out['ray_batch_num'] = np.int64(24)
+    np.savez_compressed(ROOT + '/tests/golden/golden_train_cfg1.npz', **out)
+    for k, v in out.items():
+        print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
+
+
 def run_full_forward(renderer):
     """GraspNeRF.forward (backbones + render + sample_volume + depth-mean head + grasp head), eval mode,
     cfg1 shape, parameters from synth_state_dict.  ref: renderer.py:268-331."""
@@ -222,6 +265,8 @@ def main():
         return run_losses()
     if '--full-only' in sys.argv:
         return run_full_forward(renderer)
+    if '--train-only' in sys.argv:
+        return run_train_mode(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     os.makedirs(ROOT + '/tests/golden', exist_ok=True)
     net40, cfg40 = build_net(renderer, 40, 40)
     weights = perturb_and_export(net40)
@@ -244,6 +289,7 @@ def main():
               'mask margin', out['volume_mask_min_margin_px'], 'inds margin', out['fine_inds_min_margin'])
         for k, v in out.items():
             print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
+    run_train_mode(renderer, weights)
     run_full_forward(renderer)
     run_losses()
 
