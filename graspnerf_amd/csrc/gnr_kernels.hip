@@ -53,22 +53,18 @@ DEV float gsum(float x) {
 // ---------------------------------------------------------------------------------------
 // chained-MFMA layer:  acc[nb] += W_frag(j, nb) * in[j]   for k-steps j in [J0, J0+J)
 // ---------------------------------------------------------------------------------------
+// The weight image in LDS is loop-invariant; without a compiler barrier the fragment loads are hoisted out of the
+// view/tile loops (LICM) and hundreds of registers spill.  Every loop iteration starts with GNR_ITER_FENCE();
+// LF (template flag of mm/load_bias) additionally fences every layer: needed for V >= 7 (S[V][20] leaves too few
+// registers for loads pulled across layers), 0.5 % slower for V <= 6.  -DGNR_LICM_FENCE=1 forces it everywhere.
 #ifndef GNR_LICM_FENCE
-#define GNR_LICM_FENCE 1
-#endif
-#if GNR_LICM_FENCE
-#define GNR_LAYER_FENCE() asm volatile("" ::: "memory")
-#else
-#define GNR_LAYER_FENCE() ((void)0)
+#define GNR_LICM_FENCE 0
 #endif
 #define GNR_ITER_FENCE() asm volatile("" ::: "memory")
 
-template <int J, int NB, int J0 = 0>
+template <int J, int NB, int J0 = 0, bool LF = true>
 DEV void mm(const float* __restrict__ w, int lane, const float (&in)[J], f4 (&acc)[NB]) {
-    // The weight image in LDS is loop-invariant; without a compiler barrier the fragment loads are hoisted
-    // out of the view/tile loops (LICM) and hundreds of registers spill.  GNR_LICM_FENCE 1 = fence at every
-    // layer (default), 0 = one fence per loop iteration only (lets the scheduler hoist loads across layers).
-    GNR_LAYER_FENCE();
+    if constexpr (LF) asm volatile("" ::: "memory");
     if constexpr (NB == 4 || NB == 3) {
         const f4* w4 = reinterpret_cast<const f4*>(w) + J0 * 64 + lane;
 #pragma unroll
@@ -104,9 +100,9 @@ DEV void mm(const float* __restrict__ w, int lane, const float (&in)[J], f4 (&ac
     }
 }
 
-template <int NB>
+template <int NB, bool LF = true>
 DEV void load_bias(const float* __restrict__ b, int g, f4 (&acc)[NB]) {
-    GNR_LAYER_FENCE();
+    if constexpr (LF) asm volatile("" ::: "memory");
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = reinterpret_cast<const f4*>(b)[nb * 4 + g];
 }
@@ -332,6 +328,7 @@ constexpr int view_unroll(int V) { return (GNR_VIEW_UNROLL >= 3 && V % 3 == 0) ?
 template <int V, bool RENDER>
 __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
     // ---- stage the CHAIN section of the packed weights into LDS (once per workgroup)
     {
         const f4* src = reinterpret_cast<const f4*>(a.wpk);
@@ -447,11 +444,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             for (int br = 0; br < 3; ++br) {
                 f4 acc[2];
                 float h1[8], h2[8];
-                load_bias<2>(lds + pk::B_DEC1 + br * 32, g, acc);
-                mm<8, 2>(lds + pk::DEC1 + br * frag_floats(8, 2), lane, FR, acc);
+                load_bias<2, LF>(lds + pk::B_DEC1 + br * 32, g, acc);
+                mm<8, 2, 0, LF>(lds + pk::DEC1 + br * frag_floats(8, 2), lane, FR, acc);
                 elu_to<2>(acc, h1);
-                load_bias<2>(lds + pk::B_DEC2 + br * 32, g, acc);
-                mm<8, 2>(lds + pk::DEC2 + br * frag_floats(8, 2), lane, h1, acc);
+                load_bias<2, LF>(lds + pk::B_DEC2 + br * 32, g, acc);
+                mm<8, 2, 0, LF>(lds + pk::DEC2 + br * frag_floats(8, 2), lane, h1, acc);
                 elu_to<2>(acc, h2);
                 if (br < 2) {
                     o5[2 * br] = gsum(dot8(lds + pk::T_DEC3 + (2 * br) * 32, g, h2)) + lds[pk::T_DEC3_B + 2 * br];
@@ -477,10 +474,10 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             {
                 f4 acc[2];
                 float e1[8];
-                load_bias<2>(lds + pk::B_PE1, g, acc);
-                mm<8, 2>(lds + pk::PE1, lane, FR, acc);
+                load_bias<2, LF>(lds + pk::B_PE1, g, acc);
+                mm<8, 2, 0, LF>(lds + pk::PE1, lane, FR, acc);
                 const float extra[1] = {g == 0 ? (hit - 0.5f) * 2.f : (g == 1 ? (vis - 0.5f) * 2.f : 0.f)};
-                mm<1, 2, 8>(lds + pk::PE1, lane, extra, acc);
+                mm<1, 2, 8, LF>(lds + pk::PE1, lane, extra, acc);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     e1[nb * 4 + 0] = fmaxf(acc[nb].x, 0.f); e1[nb * 4 + 1] = fmaxf(acc[nb].y, 0.f);
@@ -494,12 +491,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             {
                 f4 acc1[1], acc3[3];
                 float d1[4], df[12];
-                load_bias<1>(lds + pk::B_RDF1, g, acc1);
+                load_bias<1, LF>(lds + pk::B_RDF1, g, acc1);
                 const float ddg[1] = {g == 0 ? vg.dd[0] : (g == 1 ? vg.dd[1] : (g == 2 ? vg.dd[2] : vg.dd[3]))};
-                mm<1, 1>(lds + pk::RDF1, lane, ddg, acc1);
+                mm<1, 1, 0, LF>(lds + pk::RDF1, lane, ddg, acc1);
                 elu_to<1>(acc1, d1);
-                load_bias<3>(lds + pk::B_RDF2, g, acc3);
-                mm<4, 3>(lds + pk::RDF2, lane, d1, acc3);
+                load_bias<3, LF>(lds + pk::B_RDF2, g, acc3);
+                mm<4, 3, 0, LF>(lds + pk::RDF2, lane, d1, acc3);
                 elu_to<3>(acc3, df);
 #pragma unroll
                 for (int j = 0; j < 9; ++j) Sv[j] = fmaf(df[j], kLn2, XI[j]);
@@ -510,8 +507,8 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
                 float e[8], n1[4];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) e[j] = Sv[9 + j];
-                load_bias<1>(lds + pk::B_NR1, g, acc1);
-                mm<8, 1>(lds + pk::NR1, lane, e, acc1);
+                load_bias<1, LF>(lds + pk::B_NR1, g, acc1);
+                mm<8, 1, 0, LF>(lds + pk::NR1, lane, e, acc1);
                 elu_to<1>(acc1, n1);
                 Sv[17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
             }
@@ -546,8 +543,8 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
         }
         // view-invariant 140 columns of base_fc.0, once per point (+ bias)
         f4 G[4];
-        load_bias<4>(lds + pk::B_HOIST, g, G);
-        mm<36, 4>(lds + pk::HOIST, lane, SV, G);
+        load_bias<4, LF>(lds + pk::B_HOIST, g, G);
+        mm<36, 4, 0, LF>(lds + pk::HOIST, lane, SV, G);
 
         // ================= phase 2: per view, base_fc / vis_fc / vis_fc2 (/ rgb_fc)
         float vsum = 0.f;
@@ -580,12 +577,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             {
                 f4 acc4[4] = {G[0], G[1], G[2], G[3]};
                 float b1[16];
-                mm<9, 4>(lds + pk::BASE1, lane, X, acc4);
-                mm<8, 4, 9>(lds + pk::BASE1, lane, E, acc4);
+                mm<9, 4, 0, LF>(lds + pk::BASE1, lane, X, acc4);
+                mm<8, 4, 9, LF>(lds + pk::BASE1, lane, E, acc4);
                 elu_to<4>(acc4, b1);
                 f4 acc[2];
-                load_bias<2>(lds + pk::B_BASE2, g, acc);
-                mm<16, 2>(lds + pk::BASE2, lane, b1, acc);
+                load_bias<2, LF>(lds + pk::B_BASE2, g, acc);
+                mm<16, 2, 0, LF>(lds + pk::BASE2, lane, b1, acc);
                 elu_to<2>(acc, Hh);
             }
             float vis1;
@@ -594,11 +591,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
                 float xin[8], v1[8], res[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * w;
-                load_bias<2>(lds + pk::B_VIS1, g, acc);
-                mm<8, 2>(lds + pk::VIS1, lane, xin, acc);
+                load_bias<2, LF>(lds + pk::B_VIS1, g, acc);
+                mm<8, 2, 0, LF>(lds + pk::VIS1, lane, xin, acc);
                 elu_to<2>(acc, v1);
-                load_bias<2>(lds + pk::B_VIS2, g, acc);
-                mm<8, 2>(lds + pk::VIS2, lane, v1, acc);
+                load_bias<2, LF>(lds + pk::B_VIS2, g, acc);
+                mm<8, 2, 0, LF>(lds + pk::VIS2, lane, v1, acc);
                 elu_to<2>(acc, res);
                 const float logit = elu1(gsum(dot8(lds + pk::T_VIS2R, g, v1)) + lds[pk::T_SCAL + 1]);
                 vis1 = sigmoid1(logit) * m;                                    // ibrnet.py:479
@@ -611,8 +608,8 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
                 float xin[8], t1[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * vis1;
-                load_bias<2>(lds + pk::B_VISB1, g, acc);
-                mm<8, 2>(lds + pk::VISB1, lane, xin, acc);
+                load_bias<2, LF>(lds + pk::B_VISB1, g, acc);
+                mm<8, 2, 0, LF>(lds + pk::VISB1, lane, xin, acc);
                 elu_to<2>(acc, t1);
                 v2 = sigmoid1(gsum(dot8(lds + pk::T_VISB2, g, t1)) + lds[pk::T_SCAL + 2]) * m;   // :481
             }
@@ -624,13 +621,13 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
                 project_view<true>(vp, p, qd, a.H, a.W, vg);
                 f4 acc1[1];
                 float c1[4], c2[4];
-                load_bias<1>(lds + pk::B_RGB1, g, acc1);
-                mm<8, 1>(lds + pk::RGB1, lane, Hh, acc1);
+                load_bias<1, LF>(lds + pk::B_RGB1, g, acc1);
+                mm<8, 1, 0, LF>(lds + pk::RGB1, lane, Hh, acc1);
                 const float ex[2] = {g == 0 ? v2 : (g == 1 ? vg.dd[0] : (g == 2 ? vg.dd[1] : vg.dd[2])), g == 0 ? vg.dd[3] : 0.f};
-                mm<2, 1, 8>(lds + pk::RGB1, lane, ex, acc1);
+                mm<2, 1, 8, LF>(lds + pk::RGB1, lane, ex, acc1);
                 elu_to<1>(acc1, c1);
-                load_bias<1>(lds + pk::B_RGB2, g, acc1);
-                mm<4, 1>(lds + pk::RGB2, lane, c1, acc1);
+                load_bias<1, LF>(lds + pk::B_RGB2, g, acc1);
+                mm<4, 1, 0, LF>(lds + pk::RGB2, lane, c1, acc1);
                 elu_to<1>(acc1, c2);
                 clog = gsum(dot4(lds + pk::T_RGB3, g, c2)) + lds[pk::T_SCAL + 3];
                 if (m == 0.f) clog = -1e9f;
@@ -684,12 +681,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
         }
         f4 U[4];
         float u64[16];
-        load_bias<4>(lds + pk::B_GEO1, g, U);
-        mm<23, 4>(lds + pk::GEO1, lane, Z, U);
+        load_bias<4, LF>(lds + pk::B_GEO1, g, U);
+        mm<23, 4, 0, LF>(lds + pk::GEO1, lane, Z, U);
         elu_to<4>(U, u64);
         f4 g16[1];
-        load_bias<1>(lds + pk::B_GEO2, g, g16);
-        mm<16, 1>(lds + pk::GEO2, lane, u64, g16);
+        load_bias<1, LF>(lds + pk::B_GEO2, g, g16);
+        mm<16, 1, 0, LF>(lds + pk::GEO2, lane, u64, g16);
         float gg[4];
         elu_to<1>(g16, gg);
 
