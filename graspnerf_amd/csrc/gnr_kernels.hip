@@ -715,7 +715,10 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
 }
 
 // ---------------------------------------------------------------------------------------
-// k_ray: one wavefront per ray / voxel column, lane = sample
+// k_ray: one lane per sample of a ray / voxel column.  A 256-thread workgroup packs floor(256/slots) rays
+// back to back (slots = lanes per ray = max(dn, fdn)); rays straddle wavefront boundaries, so everything
+// "per ray" goes through LDS + workgroup barriers, never through wave shuffles: 94 % of the lanes work at
+// dn = 40 (one ray per wavefront would use 40 of 64).
 // ---------------------------------------------------------------------------------------
 struct RayArgs {
     const float* wpk;        // packed level blob (RAY section used)
@@ -726,6 +729,7 @@ struct RayArgs {
     const float* que_dr;     // [B][2]                         (RENDER)
     const unsigned char* vmask_pts;  // [nrays*dn] point order, or null
     int nrays, dn, rays_per_scene;
+    int slots, rays_per_block, ray_stride;       // lanes per ray, rays per workgroup, LDS floats per ray (host: ray_geometry)
     // volume outputs
     float* volume;           // [B][R*R][R] with z flipped back
     unsigned char* vmask_out;
@@ -738,16 +742,17 @@ struct RayArgs {
     const float* fine_u;     // [nrays][fdn] caller-drawn samples (is_train) or null (eval midpoints)
 };
 
-// wave-level ordering of LDS traffic between lanes of the same wavefront
-DEV void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-DEV float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+// LDS floats per ray after the attention scratch is dead (RENDER tail): per-ray reductions + resampling arrays
+namespace rt {
+constexpr int TF = 0;            // [64]  transmittance factors 1-alpha+1e-10
+constexpr int RED = 64;          // [6][64] hit*r, hit*g, hit*b, hit*z, (|grad|-1)^2, view-count flag
+constexpr int HP = 448;          // [64]  hit_prob + 1e-5
+constexpr int DN = 512;          // [64]  normalised inverse depth
+constexpr int PD = 576;          // [64]  pdf
+constexpr int CD = 640;          // [72]  cdf (dn+1)
+constexpr int CE = 712;          // [72]  bin centres (dn+1)
+constexpr int FD = 784;          // [64]  unsorted fine depth
+constexpr int END = 848;
 }
 
 // logits of one query against key j for the 4 heads; `ok` false reproduces the reference's
@@ -767,20 +772,26 @@ DEV void head_logits(const float (&q)[16], const float* __restrict__ Kj, bool ok
 template <bool RENDER>
 __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int ray = blockIdx.x * 4 + wave;
-    if (ray >= a.nrays) return;
-    const int dn = a.dn;
-    constexpr int PER = RENDER ? 76 : 32;            // floats of scratch per sample
-    float* sc = sm + (size_t)wave * dn * PER;
+    const int dn = a.dn, S = a.slots, rpb = a.rays_per_block;
+    // thread -> (ray in block, slot).  Threads beyond the last ray of the block / launch shadow the last valid
+    // ray (clamped indices, no stores) so that every thread reaches every barrier.
+    int rl = (int)threadIdx.x / S;
+    const int slot = (int)threadIdx.x - rl * S;
+    const bool in_blk = rl < rpb;
+    rl = min(rl, rpb - 1);
+    const int ray_u = blockIdx.x * rpb + rl;
+    const bool rvalid = in_blk && ray_u < a.nrays;
+    const int ray = min(ray_u, a.nrays - 1);
+    const bool act = rvalid && slot < dn;
+    const int i = min(slot, dn - 1);
+    constexpr int PER = RENDER ? 76 : 32;            // floats of attention scratch per sample
+    float* sc = sm + (size_t)rl * a.ray_stride;
     float* Kb = sc;                                   // [dn][16]
     float* Vb = sc + dn * 16;                         // [dn][16]
     float* Qb = sc + dn * 32;                         // [dn][16]   (RENDER)
     float* Ob = sc + dn * 48;                         // [dn][16]   dO  (RENDER)
-    float* St = sc + dn * 64;                         // [dn][12]   max[4], 1/sum[4], rs[4] (RENDER)
-    const bool act = lane < dn;
-    const int i = act ? lane : dn - 1;
+    float* St = sc + dn * 64;                         // [dn][12]   max[4], +-1/sum[4] (sign of [0] = row ok), rs[4] (RENDER)
+    (void)PER; (void)Qb; (void)Ob; (void)St;
     const size_t pt = (size_t)ray * dn + i;
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
     const float* rec = a.rec + pt * REC;
@@ -828,11 +839,9 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             }
         }
     }
-    wave_sync();
+    __syncthreads();
 
-    // ---- attention, lane = query row (ibrnet.py:15-27): softmax over dn keys, 4 heads per key visit.
-    // Loops are unrolled so the LDS broadcast reads of several keys are in flight at once (this
-    // kernel is latency-bound, not throughput-bound).
+    // ---- attention, lane = query row (ibrnet.py:15-27): softmax over dn keys, 4 heads per key visit
     float amax[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll UA
     for (int j = 0; j < dn; ++j) {
@@ -954,24 +963,25 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
                 const f4 d4 = {dO[4 * c], dO[4 * c + 1], dO[4 * c + 2], dO[4 * c + 3]};
                 reinterpret_cast<f4*>(Ob + i * 16)[c] = d4;
             }
-            const f4 m4 = {amax[0], amax[1], amax[2], amax[3]}, i4 = {ainv[0], ainv[1], ainv[2], ainv[3]};
+            // 1/sum is positive: its sign carries the row-ok flag of this query row to the column pass
+            const f4 m4 = {amax[0], amax[1], amax[2], amax[3]}, i4 = {rowok ? ainv[0] : -ainv[0], ainv[1], ainv[2], ainv[3]};
             const f4 r4 = {rsv[0], rsv[1], rsv[2], rsv[3]};
             reinterpret_cast<f4*>(St + i * 12)[0] = m4;
             reinterpret_cast<f4*>(St + i * 12)[1] = i4;
             reinterpret_cast<f4*>(St + i * 12)[2] = r4;
         }
-        const unsigned long long okmask = __ballot(rowok && act);     // row-ok flags of all query rows
-        wave_sync();
+        __syncthreads();
         // column pass (lane = key j = i): dK_j = sum_i dL_ij q_i / 2 ; dV_j = sum_i P_ij dO_i
         float dK[16], dV[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) { dK[f] = 0.f; dV[f] = 0.f; }
 #pragma unroll UB
         for (int qi = 0; qi < dn; ++qi) {
-            const bool ok = (okmask >> qi) & 1ull;
             const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
-            const f4 il4 = reinterpret_cast<const f4*>(St + qi * 12)[1];
+            f4 il4 = reinterpret_cast<const f4*>(St + qi * 12)[1];
             const f4 rs4 = reinterpret_cast<const f4*>(St + qi * 12)[2];
+            const bool ok = il4.x > 0.f;
+            il4.x = fabsf(il4.x);
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const f4 qv = reinterpret_cast<const f4*>(Qb + qi * 16)[h];
@@ -1033,60 +1043,64 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         }
         // ================= NeuS alpha (aggregate_net.py:105-121), compositing (render_ops.py:72-80)
         const float z = a.depth[pt];
-        const float znext = __shfl_down(z, 1);
-        const float dist = (lane + 1 < dn) ? znext - z : 1e6f;
+        const float znext = a.depth[pt + ((i + 1 < dn) ? 1 : 0)];
+        const float dist = (i + 1 < dn) ? znext - z : 1e6f;
         const float inv_s = fminf(fmaxf(__expf(W[pk::R_VARIANCE] * 10.f), 1e-6f), 1e6f);
         const float tcos = -(qd[0] * grad[0] + qd[1] * grad[1] + qd[2] * grad[2]);
         const float icos = fminf(tcos, 0.f);                        // -relu(-cos)
         const float nxt = sdf + icos * dist * 0.5f, prv = sdf - icos * dist * 0.5f;
         const float pcdf = sigmoid1(prv * inv_s), ncdf = sigmoid1(nxt * inv_s);
         const float alpha = fminf(fmaxf((pcdf - ncdf + 1e-5f) / (pcdf + 1e-5f), 0.f), 1.f);
-        // exclusive transmittance product as a wave prefix scan (6 shuffle steps instead of a dn-long
-        // dependent chain; differs from the sequential cumprod by fp32 rounding only)
-        float incl = act ? 1.f - alpha + 1e-10f : 1.f;
-#pragma unroll
-        for (int o2 = 1; o2 < 64; o2 <<= 1) {
-            const float up = __shfl_up(incl, o2);
-            if (lane >= o2) incl *= up;
-        }
-        float T = __shfl_up(incl, 1);
-        if (lane == 0) T = 1.f;
+        // the attention scratch is dead from here on: the ray's LDS region is re-used for the per-ray reductions
+        float* Tf = sc + rt::TF;
+        float* Red = sc + rt::RED;
+        float* Hp = sc + rt::HP;
+        __syncthreads();
+        if (act) Tf[i] = 1.f - alpha + 1e-10f;
+        __syncthreads();
+        // exclusive transmittance product in sample order (the order of the reference's cumprod)
+        float T = 1.f;
+#pragma unroll 8
+        for (int j = 0; j < dn; ++j) { const float f = Tf[j]; T = (j < i) ? T * f : T; }
         const float hitp = act ? alpha * T : 0.f;
         const float gn = sqrtf(grad[0] * grad[0] + grad[1] * grad[1] + grad[2] * grad[2]) - 1.f;
-        const float gerr = wave_sum(act ? gn * gn : 0.f);
-        const float cr = a.colors[pt * 3], cg = a.colors[pt * 3 + 1], cb = a.colors[pt * 3 + 2];
-        const float pr = wave_sum(hitp * cr), pg = wave_sum(hitp * cg), pb = wave_sum(hitp * cb);
-        const float rd = wave_sum(hitp * z);
-        const unsigned long long cnt = __ballot(act && nvalid > (float)a.view_num);
+        const float hp = __fadd_rn(hitp, 1e-5f);
         if (act) {
+            const float cr = a.colors[pt * 3], cg = a.colors[pt * 3 + 1], cb = a.colors[pt * 3 + 2];
+            Red[i] = hitp * cr; Red[64 + i] = hitp * cg; Red[128 + i] = hitp * cb; Red[192 + i] = hitp * z;
+            Red[256 + i] = gn * gn; Red[320 + i] = (nvalid > (float)a.view_num) ? 1.f : 0.f;
+            Hp[i] = hp;
             if (a.sdf) a.sdf[pt] = sdf;
             if (a.alpha) a.alpha[pt] = alpha;
             if (a.hit) a.hit[pt] = hitp;
             if (a.grad) { a.grad[pt * 3] = grad[0]; a.grad[pt * 3 + 1] = grad[1]; a.grad[pt * 3 + 2] = grad[2]; }
         }
-        if (lane == 0) {
-            if (a.pix) { a.pix[(size_t)ray * 3] = pr; a.pix[(size_t)ray * 3 + 1] = pg; a.pix[(size_t)ray * 3 + 2] = pb; }
-            if (a.rdepth) a.rdepth[ray] = rd;
-            if (a.rmask) a.rmask[ray] = (__popcll(cnt) > a.point_num) ? 1 : 0;     // renderer.py:130-132
-            if (a.gerr_part) a.gerr_part[ray] = gerr;
+        __syncthreads();
+        if (rvalid) {
+            for (int qn = slot; qn < 6; qn += S) {      // slot q sums quantity q (q, q+S, .. when a ray has < 6 slots)
+                float s = 0.f;
+                for (int j = 0; j < dn; ++j) s += Red[qn * 64 + j];
+                if (qn < 3) { if (a.pix) a.pix[(size_t)ray * 3 + qn] = s; }
+                else if (qn == 3) { if (a.rdepth) a.rdepth[ray] = s; }
+                else if (qn == 4) { if (a.gerr_part) a.gerr_part[ray] = s; }
+                else { if (a.rmask) a.rmask[ray] = (s > (float)a.point_num) ? 1 : 0; }     // renderer.py:130-132
+            }
         }
-        // ================= inverse-CDF resampling for the fine pass (render_ops.py:172-229), eval mode
-        if (a.fine_depth) {
+        // ================= inverse-CDF resampling for the fine pass (render_ops.py:172-229)
+        if (a.fine_depth) {                             // uniform over the launch
             const int fdn = a.fdn;
             const int b = ray / a.rays_per_scene;
             const float near = __fdiv_rn(-1.f, a.que_dr[b * 2]), far = __fdiv_rn(-1.f, a.que_dr[b * 2 + 1]);
             const float span = __fsub_rn(far, near);
-            float* Dn = Vb;                 // [dn]   normalised inverse depth
-            float* Pd = Vb + 64;            // [dn]   pdf
-            float* Cd = Vb + 128;           // [dn+1] cdf
-            float* Ce = Vb + 200;           // [dn+1] bin centres
-            float* Fd = Vb + 272;           // [fdn]  unsorted fine depth
-            wave_sync();
-            const float dnv = __fdiv_rn(__fsub_rn(__fdiv_rn(-1.f, z), near), span);
-            const float hp = __fadd_rn(hitp, 1e-5f);
-            const float hsum = wave_sum(act ? hp : 0.f);
-            if (act) { Dn[i] = dnv; Pd[i] = __fdiv_rn(hp, hsum); }
-            wave_sync();
+            float* Dn = sc + rt::DN; float* Pd = sc + rt::PD; float* Cd = sc + rt::CD; float* Ce = sc + rt::CE; float* Fd = sc + rt::FD;
+            float hsum = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < dn; ++j) hsum = __fadd_rn(hsum, Hp[j]);
+            if (act) {
+                Dn[i] = __fdiv_rn(__fsub_rn(__fdiv_rn(-1.f, z), near), span);
+                Pd[i] = __fdiv_rn(hp, hsum);
+            }
+            __syncthreads();
             {
                 float c = 0.f;                                                   // sequential cumsum, same
 #pragma unroll 8
@@ -1100,11 +1114,12 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
                     if (i == 0) { Cd[0] = 0.f; Ce[0] = Dn[0]; }
                 }
             }
-            wave_sync();
-            const bool fact = lane < fdn;
+            __syncthreads();
+            const bool fact = rvalid && slot < fdn;
+            const int fs = min(slot, fdn - 1);
             const float interval = 1.f / (float)fdn;
-            const float u = a.fine_u ? (fact ? a.fine_u[(size_t)ray * fdn + lane] : 0.f)
-                                     : __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)lane, interval));
+            const float u = a.fine_u ? a.fine_u[(size_t)ray * fdn + fs]
+                                     : __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)fs, interval));
             int inds = 0;
 #pragma unroll 8
             for (int j = 0; j <= dn; ++j) inds += (Cd[j] <= u) ? 1 : 0;          // searchsorted(right=True)
@@ -1116,14 +1131,14 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             float fd = __fadd_rn(b0, __fmul_rn(tt, __fsub_rn(b1, b0)));
             fd = __fadd_rn(__fmul_rn(fd, span), near);
             fd = __fdiv_rn(-1.f, fd);
-            if (fact) Fd[lane] = fd;
-            wave_sync();
+            if (fact) Fd[fs] = fd;
+            __syncthreads();
             if (fact) {
                 int rank = 0;                                                    // stable rank sort (renderer.py:148)
 #pragma unroll 8
-                for (int j = 0; j < fdn; ++j) { const float o2 = Fd[j]; rank += (o2 < fd || (o2 == fd && j < lane)) ? 1 : 0; }
+                for (int j = 0; j < fdn; ++j) { const float o2 = Fd[j]; rank += (o2 < fd || (o2 == fd && j < fs)) ? 1 : 0; }
                 a.fine_depth[(size_t)ray * fdn + rank] = fd;
-                if (a.fine_inds) a.fine_inds[(size_t)ray * fdn + lane] = inds;
+                if (a.fine_inds) a.fine_inds[(size_t)ray * fdn + fs] = inds;
             }
         }
     }
