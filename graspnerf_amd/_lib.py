@@ -34,6 +34,16 @@ class GnrRenderOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in RENDER_OUT_FIELDS]
 
 
+GNR_GAUSS_MAX_RADIUS = 16
+
+
+class GnrSelectParams(C.Structure):
+    _fields_ = [('gauss_radius', C.c_int), ('gauss_w', C.c_double * (GNR_GAUSS_MAX_RADIUS + 1)),
+                ('tsdf_thres_high', C.c_float), ('tsdf_thres_low', C.c_float), ('min_width', C.c_float),
+                ('max_width', C.c_float), ('threshold', C.c_float), ('dilate_iterations', C.c_int),
+                ('max_filter_size', C.c_int)]
+
+
 class GnrError(RuntimeError):
     pass
 
@@ -86,6 +96,12 @@ def lib():
                                      C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_grasp_head_fwd.restype = C.c_int
     L.gnr_head_last_error.restype = C.c_char_p
+    L.gnr_grasp_select_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    L.gnr_grasp_select_workspace_bytes.restype = C.c_size_t
+    L.gnr_grasp_select_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.POINTER(GnrSelectParams)] + \
+                                      [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_grasp_select_fwd.restype = C.c_int
+    L.gnr_post_last_error.restype = C.c_char_p
     L.gnr_time_chain_kernel.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                         c_float_p, C.c_void_p]
     L.gnr_time_chain_kernel.restype = C.c_int
@@ -102,7 +118,8 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
-            'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end']
+            'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_grasp_select_workspace_bytes',
+            'gnr_grasp_select_fwd', 'gnr_post_last_error']
 
 
 def check(rc, what):

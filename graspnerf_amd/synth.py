@@ -113,3 +113,31 @@ def synth_loss_case(seed=5, rfn=3, h=96, w=128, rn=64, pn=256, R=16, N=12):
           'grasp_info': (rng.integers(0, 40, (N, 3)).astype(np.int64), (rng.random(N) > 0.5).astype(np.float32),
                          r2 / np.linalg.norm(r2, axis=2, keepdims=True), f(N) * 0.08)}
     return pr, gt
+
+
+def synth_head_outputs(seed, R=40):
+    """Smooth random (tsdf, qual, rot, width) volumes in the value ranges the grasp head produces, for the
+    grasp post-processing path (main.py:23-74): a blobby surface, broad high-quality regions that survive the
+    Gaussian smoothing, unit quaternions, widths in voxel units.  -> float32 [1,1,R,R,R], [1,1,..], [1,4,..], [1,1,..]"""
+    rng = np.random.default_rng(7000 + seed)
+
+    def field(n_ch=1, coarse=6):
+        c = rng.standard_normal((n_ch, coarse, coarse, coarse))
+        x = np.linspace(0, coarse - 1, R)
+        i0 = np.clip(np.floor(x).astype(int), 0, coarse - 2)
+        t = x - i0
+        for ax in (1, 2, 3):                                     # separable linear upsampling
+            a = np.take(c, i0, axis=ax)
+            b = np.take(c, i0 + 1, axis=ax)
+            shp = [1, 1, 1, 1]
+            shp[ax] = R
+            tt = t.reshape(shp)
+            c = a * (1 - tt) + b * tt
+        return c
+    tsdf = np.clip(0.8 * field()[0] - 0.2, -1, 1)
+    qual = 1.0 / (1.0 + np.exp(-(3.0 * field()[0] + 1.0)))
+    rot = field(4) + 0.05 * rng.standard_normal((4, R, R, R))
+    rot /= np.linalg.norm(rot, axis=0, keepdims=True)
+    width = 5.0 + 4.5 * field()[0]
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    return f(tsdf)[None, None], f(qual)[None, None], f(rot)[None], f(width)[None, None]

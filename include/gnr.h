@@ -151,6 +151,32 @@ int gnr_grasp_head_fwd(int B, int volume_res, const float* volume, const float* 
                        float* width, void* workspace, size_t workspace_bytes, void* stream);
 const char* gnr_head_last_error(void);
 
+/* ---- grasp post-processing on the device -------------------------------------------------
+ * Replaces the reference planner's `process` + `select` (src/nr/main.py:23-57, 60-84), which run
+ * scipy.ndimage (gaussian_filter sigma=1 mode='nearest'; binary_dilation iterations=2 with mask;
+ * maximum_filter size=4) on the host for every plan.  Bit-exact with scipy: fp64 accumulation in
+ * scipy's order, fp32 rounding after every Gaussian axis.
+ *   tsdf, qual, width [B,R,R,R], rot [B,4,R,R,R]  (outputs of sample_volume / the grasp head)
+ *   qual_out [B,R,R,R]      processed quality volume                        (main.py:41-55)
+ *   count [B]               selected grasps per scene (may exceed max_n: only the first max_n are stored)
+ *   index [B,max_n,3] (i,j,k), score [B,max_n], quat [B,max_n,4] (x,y,z,w as stored in rot),
+ *   width_out [B,max_n]     in np.argwhere order                            (main.py:70-84)              */
+#define GNR_GAUSS_MAX_RADIUS 16
+typedef struct GnrSelectParams {
+    int gauss_radius;                          /* int(4*sigma + 0.5)                                    */
+    double gauss_w[GNR_GAUSS_MAX_RADIUS + 1];  /* w[k] = exp(-k^2/(2 sigma^2)) / sum, k = 0..radius     */
+    float tsdf_thres_high, tsdf_thres_low;     /* planner: 0, -0.85 (main.py:93-94)                     */
+    float min_width, max_width;                /* 1.33, 9.33 (main.py:29-30)                            */
+    float threshold;                           /* 0.90 (main.py:60)                                     */
+    int dilate_iterations;                     /* 2 (main.py:48)                                        */
+    int max_filter_size;                       /* 4 (main.py:60)                                        */
+} GnrSelectParams;
+size_t gnr_grasp_select_workspace_bytes(int B, int R);
+int gnr_grasp_select_fwd(const float* tsdf, const float* qual, const float* rot, const float* width, int B, int R,
+                         const GnrSelectParams* params, float* qual_out, int* count, int* index, float* score,
+                         float* quat, float* width_out, int max_n, void* workspace, size_t workspace_bytes, void* stream);
+const char* gnr_post_last_error(void);
+
 /* ---- introspection / measurement -------------------------------------------------------*/
 /* name of the dominant kernel as it appears in rocprofv3 traces, and the last HIP error text */
 const char* gnr_dominant_kernel_name(void);

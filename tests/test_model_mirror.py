@@ -194,3 +194,34 @@ def test_planner_core_matches_forward(model, G):
         np.testing.assert_allclose(q[..., ::2, ::2, ::2], G['vgn_qual_sub'], rtol=1e-3, atol=3e-4)
     finally:
         net.nr_net.cfg['render_rgb'] = old
+
+
+@pytest.mark.gpu
+def test_planner_plan_runs_process_and_select_on_device():
+    """planner.plan = GraspNeRFPlanner.__call__ from arrays (main.py:185-209): forward at the planner's 40^3 resolution,
+    device-side process + select, seeded permutation; checked against the numpy oracle on the very same volumes."""
+    import copy
+    from graspnerf_amd.planner import load_model, plan
+    from oracle import grasp_post_oracle as P
+    cfg = copy.deepcopy(CFG)
+    cfg.update(volume_resolution=40, depth_sample_num=40, fine_depth_sample_num=40)
+    cfg['agg_net_cfg']['sample_num'] = cfg['fine_agg_net_cfg']['sample_num'] = 40
+    from graspnerf_amd.renderer import GraspNeRF
+    shapes = {k: tuple(v.shape) for k, v in GraspNeRF(cfg).state_dict().items()}
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth_state_dict(shapes).items()}
+    sd['vgn_net.conv_qual.bias'] = sd['vgn_net.conv_qual.bias'] + 2.5          # push some qualities above 0.9
+    net = load_model(cfg, sd)
+    ref, que = make_scene(0, 'cfg1')
+    g, dt = plan(net, ref['imgs'], ref['poses'], ref['Ks'], seed=3, return_volumes=True)
+    vol, q, r, w, qp = g['volumes']
+    assert vol.shape == (1, 1, 40, 40, 40) and q.shape == (1, 1, 40, 40, 40)
+    qo = P.process(vol[0, 0], q[0, 0], r[0], w[0, 0], thres_high=0.0, thres_low=-0.85)
+    assert np.array_equal(qp[0], qo)
+    idx, score, quat, wd = P.select(qo, r[0], w[0, 0])
+    assert len(idx) == len(g['index'])
+    if len(idx):
+        np.random.seed(3)
+        p = np.random.permutation(len(idx))
+        assert np.array_equal(g['index'], idx[p]) and np.array_equal(g['score'], score[p])
+        np.testing.assert_allclose(g['pos'], idx[p] * (0.3 / 40))
+        np.testing.assert_allclose(g['width'], wd[p] * np.float32(0.3 / 40), rtol=1e-6)

@@ -259,8 +259,44 @@ def run_losses():
     print('losses golden:', {k: float(v[0]) for k, v in g.items()})
 
 
+def _stub_optional_modules():
+    import types
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            return None
+    for name in ('pyquaternion', 'torchmetrics', 'cv2', 'h5py', 'plyfile', 'skimage', 'skimage.io', 'skimage.metrics',
+                 'transforms3d', 'transforms3d.axangles', 'transforms3d.euler', 'open3d'):
+        if not isinstance(sys.modules.get(name), _Any):
+            sys.modules[name] = _Any(name)
+
+
+def run_post():
+    """The reference planner's own process() / select() (main.py:23-84, scipy.ndimage inside) on synthetic head
+    outputs -> tests/golden/golden_post.npz (planner thresholds main.py:93-94 and the function defaults)."""
+    from graspnerf_amd.synth import synth_head_outputs
+    _stub_optional_modules()
+    import main as refmain                     # /root/reference/src/nr/main.py
+    out = {}
+    for seed, (hi, lo) in ((0, (0.0, -0.85)), (1, (0.0, -0.85)), (2, (0.5, 1e-3))):
+        tsdf, qual, rot, width = synth_head_outputs(seed)
+        q, r, w = refmain.process(tsdf.copy(), qual.copy(), rot.copy(), width.copy(), tsdf_thres_high=hi, tsdf_thres_low=lo)
+        grasps, scores, indexs = refmain.select(q.copy(), r, w)
+        out[f's{seed}.qual'] = q.astype(np.float32)
+        out[f's{seed}.index'] = np.asarray(indexs, np.int64).reshape(-1, 3)
+        out[f's{seed}.score'] = np.asarray(scores, np.float32)
+        out[f's{seed}.quat'] = np.asarray([g.pose.rotation.as_quat() for g in grasps], np.float64).reshape(-1, 4)
+        out[f's{seed}.pos'] = np.asarray([g.pose.translation for g in grasps], np.float64).reshape(-1, 3)
+        out[f's{seed}.width'] = np.asarray([g.width for g in grasps], np.float32)
+        out[f's{seed}.thres'] = np.asarray([hi, lo], np.float64)
+        print('post golden seed', seed, 'nonzero qual', int((q != 0).sum()), 'grasps', len(grasps))
+    np.savez_compressed(ROOT + '/tests/golden/golden_post.npz', **out)
+
+
 def main():
     renderer = import_reference()
+    if '--post-only' in sys.argv:
+        return run_post()
     if '--losses-only' in sys.argv:
         return run_losses()
     if '--full-only' in sys.argv:
@@ -292,6 +328,7 @@ def main():
     run_train_mode(renderer, weights)
     run_full_forward(renderer)
     run_losses()
+    run_post()
 
 
 if __name__ == '__main__':
