@@ -94,7 +94,7 @@ def main():
         sys.exit('bench.py needs a ROCm GPU; the hot path has no CPU fallback')
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:      # under torch.distributed.run, also for one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
