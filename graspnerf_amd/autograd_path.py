@@ -1,0 +1,261 @@
+"""Differentiable PyTorch statement of the volumetric path, for TRAINING ONLY.
+
+The HIP kernels behind libgnr.so are forward-only in this round; their `*_bwd` twins (and the second-order
+path through the in-forward SDF gradient that the eikonal and NeuS-alpha terms need, `ibrnet.py:497-504`
+`create_graph=True`) are not built.  Until they are, a train step differentiates this module with autograd on the GPU:
+same algebra and the same parameter tensors as the kernels (live `nn.Parameter`s of the mirror modules, reference
+state-dict names), nothing detached, the in-forward VJP taken with `create_graph=True`.  Inference and evaluation never
+come here (`NeuralRayRenderer.forward` routes to the HIP path whenever autograd is off).
+
+Layout: one scene per call, view-major flat arrays [V, N, C] with N = rn*dn points.
+ref: src/nr/network/renderer.py:62-220, render_ops.py, dist_decoder.py, aggregate_net.py, ibrnet.py:447-513.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _lin(x, P, name):
+    y = x @ P[name + '.weight'].t()
+    b = P.get(name + '.bias')
+    return y if b is None else y + b
+
+
+def _mlp3(x, P, pre, last):
+    x = F.elu(_lin(x, P, pre + '.0'))
+    x = F.elu(_lin(x, P, pre + '.2'))
+    return last(_lin(x, P, pre + '.4'))
+
+
+def grid_points(res, volume_size=0.3):
+    """utils/field_utils.py:12-27: voxel centres, index x*res^2 + y*res + z (fp64 then cast)."""
+    vs = volume_size / res
+    i = np.arange(res, dtype=np.float64) * vs + vs / 2
+    X, Y, Z = np.meshgrid(i, i, i, indexing='ij')
+    return np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
+
+
+def project(pts, poses, Ks, h, w):
+    """render_ops.py:82-130 -> uv [V,N,2], z [V,N], mask [V,N] bool, dir [V,N,3]."""
+    N = pts.shape[0]
+    KRt = Ks @ poses
+    hp = torch.cat([pts, pts.new_ones(N, 1)], 1)
+    pc = torch.einsum('vij,nj->vni', KRt, hp)
+    z = pc[..., 2]
+    invalid = z.abs() < 1e-4
+    z = torch.where(invalid, torch.full_like(z, 1e-3), z)
+    uv = pc[..., :2] / z[..., None]
+    outside = (uv[..., 0] < -0.5) | (uv[..., 0] >= w - 0.5) | (uv[..., 1] < -0.5) | (uv[..., 1] >= h - 0.5)
+    cam = -(poses[:, :, :3].transpose(1, 2) @ poses[:, :, 3:])[..., 0]
+    d = pts[None] - cam[:, None]
+    return uv, z, (~invalid) & (~outside), -d / torch.clamp_min(torch.linalg.norm(d, dim=2, keepdim=True), 1e-5)
+
+
+def bilinear_border(feat, uv, h, w):
+    """render_ops.py:54-70 / ops.py:14-34: feat [V,C,fh,fw], uv [V,N,2] (full-res pixels) -> [V,N,C]; border padding;
+    align_corners True for full-res maps, False otherwise.  Differentiable w.r.t. feat."""
+    V, C, fh, fw = feat.shape
+    xn = uv[..., 0] / (w - 1) * 2 - 1
+    yn = uv[..., 1] / (h - 1) * 2 - 1
+    if fh == h and fw == w:
+        px, py = (xn + 1) / 2 * (fw - 1), (yn + 1) / 2 * (fh - 1)
+    else:
+        px, py = ((xn + 1) * fw - 1) / 2, ((yn + 1) * fh - 1) / 2
+    px, py = px.clamp(0, fw - 1), py.clamp(0, fh - 1)
+    x0, y0 = torch.floor(px), torch.floor(py)
+    wx1, wy1 = px - x0, py - y0
+    x0i, y0i = x0.long(), y0.long()
+    x1i, y1i = (x0i + 1).clamp(max=fw - 1), (y0i + 1).clamp(max=fh - 1)
+    fl = feat.permute(0, 2, 3, 1).reshape(V, fh * fw, C)
+
+    def tap(yi, xi, wgt):
+        return torch.gather(fl, 1, (yi * fw + xi)[..., None].expand(-1, -1, C)) * wgt[..., None]
+    return tap(y0i, x0i, (1 - wx1) * (1 - wy1)) + tap(y0i, x1i, wx1 * (1 - wy1)) + \
+        tap(y1i, x0i, (1 - wx1) * wy1) + tap(y1i, x1i, wx1 * wy1)
+
+
+def decode_hit_vis(P, dec, f_ray, z, mask, depth_range, lo, hi):
+    """dist_decoder.py:99-142 + renderer.py:62-78 -> hit, vis [V,N] (masked)."""
+    mean = _mlp3(f_ray, P, dec + 'mean_decoder', F.softplus)
+    var = _mlp3(f_ray, P, dec + 'var_decoder', F.softplus) + 0.05
+    aw = _mlp3(f_ray, P, dec + 'aw_decoder', torch.sigmoid)
+    near_r, far_r = -1 / depth_range[:, 0][:, None], -1 / depth_range[:, 1][:, None]
+    dhat = (-1 / torch.clamp(z, min=1e-5) - near_r) / (far_r - near_r)
+    near, far = (dhat - lo)[..., None], (dhat + hi)[..., None]
+    mix = torch.cat([aw, 1 - aw], -1)
+    cdf0 = 0.5 + 0.5 * torch.tanh((near - mean) * var)
+    cdf1 = 0.5 + 0.5 * torch.tanh((far - mean) * var)
+    m = mask.to(f_ray.dtype)
+    return torch.sum((cdf1 - cdf0) * mix, -1) * m, torch.sum((1 - cdf0) * mix, -1) * m
+
+
+def sinusoid_table(n, d=16):
+    pos = np.arange(n, dtype=np.float64)[:, None]
+    j = np.arange(d)
+    ang = pos / np.power(10000, 2 * (j // 2) / d)
+    tab = ang.copy()
+    tab[:, 0::2], tab[:, 1::2] = np.sin(ang[:, 0::2]), np.cos(ang[:, 1::2])
+    return torch.from_numpy(tab).float()
+
+
+def _mean_var(x, w):
+    mean = torch.sum(x * w, 0)
+    return mean, torch.sum(w * (x - mean[None]) ** 2, 0)
+
+
+def aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, rn, dn, want_grad, want_rgb):
+    """aggregate_net.py:35-70 + ibrnet.py:447-513.  -> sdf [rn,dn], grad [rn,dn,3] | None (differentiable: taken with
+    create_graph=True), rgb [rn,dn,3] | None."""
+    a = agg + 'agg_impl.'
+    m = mask.to(f_ray.dtype)[..., None]
+    pe_in = torch.cat([f_ray, ((hit - 0.5) * 2)[..., None], ((vis - 0.5) * 2)[..., None]], -1)
+    e = _lin(F.relu(_lin(pe_in, P, agg + 'prob_embed.0')), P, agg + 'prob_embed.2')
+    dd = torch.cat([dirv - qdir[None], torch.sum(dirv * qdir[None], -1, keepdim=True)], -1)
+    x = torch.cat([rgb, f_img], -1) + F.elu(_lin(F.elu(_lin(dd, P, a + 'ray_dir_fc.0')), P, a + 'ray_dir_fc.2'))
+    w = m / (torch.sum(m, 0, keepdim=True) + 1e-8)
+    w0 = torch.sigmoid(_lin(F.elu(_lin(e, P, a + 'neuray_fc.0')), P, a + 'neuray_fc.2')) * w
+    mean0, var0 = _mean_var(x, w0)
+    mean1, var1 = _mean_var(x, w)
+    W0 = P[a + 'base_fc.0.weight']
+    pre = torch.cat([mean0, var0, mean1, var1], -1) @ W0[:, :140].t() + P[a + 'base_fc.0.bias']
+    h = F.elu(pre[None] + x @ W0[:, 140:175].t() + e @ W0[:, 175:].t())
+    h = F.elu(_lin(h, P, a + 'base_fc.2'))
+    xv = F.elu(_lin(F.elu(_lin(h * w, P, a + 'vis_fc.0')), P, a + 'vis_fc.2'))
+    v1 = torch.sigmoid(xv[..., 32:]) * m
+    h = h + xv[..., :32]
+    v2 = torch.sigmoid(_lin(F.elu(_lin(h * v1, P, a + 'vis_fc2.0')), P, a + 'vis_fc2.2')) * m
+    w2 = v2 / (torch.sum(v2, 0, keepdim=True) + 1e-8)
+    mean, var = _mean_var(h, w2)
+    nvalid = torch.sum(m, 0)[:, 0]
+    p = pts.detach().clone().requires_grad_(want_grad)
+    with torch.enable_grad():
+        emb = torch.cat([p] + [fn(p * f) for f in (1.0, 2.0, 4.0) for fn in (torch.sin, torch.cos)], -1)
+        z86 = torch.cat([mean, var, torch.mean(w2, 0), emb], -1)
+        g = F.elu(_lin(F.elu(_lin(z86, P, a + 'geometry_fc.0')), P, a + 'geometry_fc.2'))
+        t = g.reshape(rn, dn, 16) + sinusoid_table(dn).to(g.device)[None]
+        heads = lambda name: _lin(t, P, a + 'ray_attention.' + name).reshape(rn, dn, 4, 4).transpose(1, 2)
+        q, k, v = heads('w_qs'), heads('w_ks'), heads('w_vs')
+        logits = ((q / 2.0) @ k.transpose(2, 3)).masked_fill(~(nvalid.reshape(rn, 1, dn, 1) > 1), -1e9)
+        o = (torch.softmax(logits, -1) @ v).transpose(1, 2).reshape(rn, dn, 16)
+        y = _lin(o, P, a + 'ray_attention.fc') + t
+        n = F.layer_norm(y, (16,), P[a + 'ray_attention.layer_norm.weight'], P[a + 'ray_attention.layer_norm.bias'], 1e-6)
+        s = _lin(_lin(n, P, a + 'out_geometry_fc.0'), P, a + 'out_geometry_fc.1')[..., 0]
+        sdf = s.clip(-1.0, 1.0).masked_fill(nvalid.reshape(rn, dn) < 1, 1.0)
+        grad = None
+        if want_grad:
+            grad = torch.autograd.grad(sdf, p, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0].reshape(rn, dn, 3)
+    col = None
+    if want_rgb:
+        c = F.elu(_lin(torch.cat([h, v2, dd], -1), P, a + 'rgb_fc.0'))
+        c = _lin(F.elu(_lin(c, P, a + 'rgb_fc.2')), P, a + 'rgb_fc.4').masked_fill(m == 0, -1e9)
+        col = torch.sum(rgb * torch.softmax(c, 0), 0).reshape(rn, dn, 3)
+    return sdf, grad, col
+
+
+def _gather(ref, uv, mask):
+    h, w = ref['imgs'].shape[-2:]
+    m = mask.to(ref['imgs'].dtype)[..., None]
+    return (bilinear_border(ref['ray_feats'], uv, h, w) * m, bilinear_border(ref['imgs'], uv, h, w) * m,
+            bilinear_border(ref['img_feats'], uv, h, w) * m)
+
+
+def sample_volume(P, ref, res, dec='dist_decoder.', agg='agg_net.'):
+    """renderer.py:164-199 for one scene -> [1,1,res,res,res]."""
+    dev = ref['imgs'].device
+    h, w = ref['imgs'].shape[-2:]
+    pts = (torch.from_numpy(grid_points(res)).to(dev) + ref['bbox3d'][0].to(dev)).reshape(res * res, res, 3)
+    pts = torch.flip(pts, (1,)).reshape(-1, 3)
+    uv, z, mask, dirv = project(pts, ref['poses'], ref['Ks'], h, w)
+    f_ray, rgb, f_img = _gather(ref, uv, mask)
+    hit, vis = decode_hit_vis(P, dec, f_ray, z, mask, ref['depth_range'], 0.005, 0.005)
+    qdir = torch.tensor([0., 0., 1.], device=dev).expand(pts.shape[0], 3)
+    sdf, _, _ = aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, res * res, res, False, False)
+    return torch.flip(sdf.reshape(1, 1, res, res, res), (-1,))
+
+
+def render_by_depth(P, ref, que, depth, dec, agg, cfg):
+    """renderer.py:90-138 for one scene; depth [rn,dn].  que: coords [rn,2], pose [3,4], K [3,3], depth_range [2]."""
+    rn, dn = depth.shape
+    h, w = ref['imgs'].shape[-2:]
+    rot = que['pose'][:, :3].t()
+    trans = -rot @ que['pose'][:, 3:]
+    cam = torch.inverse(que['K']) @ torch.cat([que['coords'], que['coords'].new_ones(rn, 1)], 1).t()
+    d = (rot @ cam + trans - trans).t()
+    pts = (trans.t()[:, None] + d[:, None] * depth[..., None]).reshape(-1, 3)
+    qdir = -d / torch.linalg.norm(d, dim=1, keepdim=True)
+    uv, z, mask, dirv = project(pts, ref['poses'], ref['Ks'], h, w)
+    f_ray, rgb, f_img = _gather(ref, uv, mask)
+    near, far = -1 / que['depth_range'][0], -1 / que['depth_range'][1]
+    di = (-1 / depth - near) / (far - near)
+    half = torch.cat([di[:, 1:] - di[:, :-1], torch.full_like(di[:, :1], 1e6)], -1) / 2
+    ext = torch.cat([half[:, :1], half], -1)
+    hit, vis = decode_hit_vis(P, dec, f_ray, z, mask, ref['depth_range'], ext[:, :-1].reshape(-1), ext[:, 1:].reshape(-1))
+    qd = qdir[:, None].expand(rn, dn, 3).reshape(-1, 3)
+    sdf, grad, col = aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qd, pts, rn, dn, True, True)
+    variance = P[agg + 'deviation_network.variance']
+    inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)                    # aggregate_net.py:105-121
+    dists = torch.cat([depth[:, 1:] - depth[:, :-1], torch.full_like(depth[:, :1], 1e6)], -1)
+    iter_cos = -F.relu(-torch.sum(-qdir[:, None] * grad, -1))
+    pc = torch.sigmoid((sdf - iter_cos * dists * 0.5) * inv_s)
+    nc = torch.sigmoid((sdf + iter_cos * dists * 0.5) * inv_s)
+    alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)
+    hp = alpha * T[:, :-1]                                                # render_ops.py:72-80
+    nv = torch.sum(mask.reshape(-1, rn, dn).int(), 0)
+    out = {'sdf_values': sdf[None], 'alpha_values': alpha[None], 'colors_nr': col[None], 'hit_prob_nr': hp[None],
+           'pixel_colors_nr': torch.sum(hp[..., None] * col, 1)[None],
+           'sdf_gradient_error': torch.mean((torch.linalg.norm(grad, dim=-1) - 1.0) ** 2).reshape(1, 1),
+           's': variance.reshape(1, 1), 'render_depth': torch.sum(hp * depth, -1)[None],
+           'ray_mask': (torch.sum((nv > cfg['ray_mask_view_num']).int(), 1) > cfg['ray_mask_point_num'])[None]}
+    if 'imgs' in que:                                                     # renderer.py:125-127
+        gt = F.grid_sample(que['imgs'], (que['coords'] / torch.tensor([w - 1, h - 1], dtype=depth.dtype, device=depth.device)
+                                         * 2 - 1)[None, None], mode='bilinear', padding_mode='zeros', align_corners=True)
+        out['pixel_colors_gt'] = gt[0, :, 0].t()[None]
+    return out
+
+
+def sample_fine_depth(depth, hit_prob, depth_range, fdn, u):
+    """render_ops.py:172-229 (hit_prob arrives detached, renderer.py:141); u [rn,fdn]."""
+    near, far = -1 / depth_range[0], -1 / depth_range[1]
+    d = (-1 / depth - near) / (far - near)
+    centre = torch.cat([d[:, :1], (d[:, 1:] + d[:, :-1]) / 2, d[:, -1:]], -1)
+    hp = hit_prob + 1e-5
+    pdf = hp / torch.sum(hp, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below, above = (inds - 1).clamp(min=0), inds.clamp(max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    b0, b1 = torch.gather(centre, 1, below), torch.gather(centre, 1, above)
+    den = c1 - c0
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    fd = b0 + (u - c0) / den * (b1 - b0)
+    return -1 / (fd * (far - near) + near)
+
+
+def render(P, ref, que, cfg, fine_u=None):
+    """renderer.py:140-162 for one chunk of rays of one scene -> dict with '' and '_fine' keys."""
+    dev = ref['imgs'].device
+    rn, dn, fdn = que['coords'].shape[0], cfg['depth_sample_num'], cfg['fine_depth_sample_num']
+    near, far = que['depth_range'][0], que['depth_range'][1]
+    diff = 1 / far - 1 / near
+    ticks = torch.cat([torch.zeros(1, device=dev), diff / (dn - 1) * torch.arange(1, dn - 1, dtype=torch.float32, device=dev),
+                       diff.reshape(1)])
+    depth = (1 / (1 / near + ticks))[None].expand(rn, dn).contiguous()    # render_ops.py:146-170
+    out = render_by_depth(P, ref, que, depth, 'dist_decoder.', 'agg_net.', cfg)
+    if fine_u is None:
+        fine_u = ((0.5 + torch.arange(fdn, dtype=torch.float32, device=dev)) / fdn)[None].expand(rn, fdn)
+    fd = sample_fine_depth(depth, out['hit_prob_nr'][0].detach(), que['depth_range'], fdn, fine_u.to(dev))
+    fine = render_by_depth(P, ref, que, torch.sort(fd, -1)[0], 'fine_dist_decoder.', 'fine_agg_net.', cfg)
+    out.update({k + '_fine': v for k, v in fine.items()})
+    return out
+
+
+def depth_mean(P, ref, coords_rc, dec):
+    """predict_mean_for_depth_loss for one level (renderer.py:230-266): coords [pn,2] are fed as (x,y) although they
+    hold (row,col) -> [V,pn,2]."""
+    h, w = ref['imgs'].shape[-2:]
+    V = ref['imgs'].shape[0]
+    uv = coords_rc.to(torch.float32)[None].expand(V, -1, -1)
+    f = bilinear_border(ref['ray_feats'], uv, h, w)
+    return _mlp3(f, P, dec + 'mean_decoder', F.softplus)

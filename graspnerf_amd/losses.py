@@ -1,7 +1,7 @@
 """Loss / metric terms of the reference evaluated on the forward outputs (first half): plain
 PyTorch reductions over the output dict, same keys and weights as `src/nr/network/loss.py` for the configured path
 (`loss: [render, depth, sdf, vgn]`, configs/nrvgn_sdf.yaml:36).  They run on whatever device the outputs live on.
-The training step itself (backward through the HIP path, RCCL gradient all-reduce) is not built in this round."""
+The training step is graspnerf_amd/trainer.py."""
 import math
 
 import torch

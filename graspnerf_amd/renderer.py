@@ -4,7 +4,8 @@ and `GraspNeRF(cfg).forward / select` with the reference's names, dict schemas, 
 state-dict keys (ref: src/nr/network/renderer.py:13-335), so `src/gd`'s consumers and reference
 checkpoints plug in unchanged.  The 2D backbones and the grasp head are PyTorch-ROCm modules
 (backbone.py); everything between `ray_feats` and `volume` / the render dict runs in the HIP
-kernels behind libgnr.so (hotpath.py).  Forward / eval only in this round.
+kernels behind libgnr.so (hotpath.py).  The kernels are forward-only: with autograd enabled in training mode the
+same parameters are differentiated through autograd_path.py instead.
 """
 import numpy as np
 import torch
@@ -14,6 +15,7 @@ from . import weights as _w
 from .backbone import ResUNetLight, CostVolumeInitNet, DefaultVisEncoder, ConvNet
 from .hotpath import HotPath
 from .grasp_head import GraspHead
+from . import autograd_path as _ag
 
 
 def _kaiming(mods):
@@ -79,7 +81,15 @@ class _AggNetParams(nn.Module):
         self.prob_embed = _mlp([34, 32, 32])
         self.agg_impl = _AggImplParams()
         self.deviation_network = _Deviation(cfg.get('init_s', 0.3))
+        self.fix_s = cfg.get('fix_s', False)                               # aggregate_net.py:91
         self.step = 0                                                      # aggregate_net.py:99
+
+    def train_step_bookkeeping(self):
+        """aggregate_net.py:135-137 + neus.py:13-18: one render pass in training mode advances the step counter and,
+        once step > fix_s, makes the NeuS variance trainable."""
+        self.step += 1
+        if self.fix_s != -1 and self.step > self.fix_s:
+            self.deviation_network.variance.requires_grad_(True)
 
 
 class NeuralRayRenderer(nn.Module):
@@ -158,6 +168,34 @@ class NeuralRayRenderer(nn.Module):
                 'ray_mask_view_num': c['ray_mask_view_num'], 'ray_mask_point_num': c['ray_mask_point_num'],
                 'ray_batch_num': c['ray_batch_num']}
 
+    def _use_autograd(self, is_train):
+        """Training (autograd on, parameters trainable) goes through the differentiable PyTorch statement of the path
+        (autograd_path.py); the HIP kernels have no backward yet."""
+        return bool(is_train) and torch.is_grad_enabled()
+
+    def _params(self):
+        return dict(self.named_parameters())
+
+    def _render_autograd(self, que, ref):
+        """renderer.py:201-220 with autograd: ray chunks of ray_batch_num, per-chunk random samples, outputs
+        concatenated along the ray axis (the [1,1] scalars become [1,n_chunks])."""
+        c, P = self.cfg, self._params()
+        rn, chunk, fdn = que['coords'].shape[1], self.cfg['ray_batch_num'], self.cfg['fine_depth_sample_num']
+        parts = []
+        for r0 in range(0, rn, chunk):
+            u = torch.rand([1, min(chunk, rn - r0), fdn])                  # render_ops.py:204-205 (CPU generator)
+            for net in (self.agg_net, self.fine_agg_net):
+                net.train_step_bookkeeping()
+            q = {'coords': que['coords'][0, r0:r0 + chunk], 'pose': que['poses'][0], 'K': que['Ks'][0],
+                 'depth_range': que['depth_range'][0]}
+            if 'imgs' in que:
+                q['imgs'] = que['imgs']
+            parts.append(_ag.render(P, ref, q, self._render_cfg(), u[0]))
+        out = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
+        if not c['render_depth']:
+            out.pop('render_depth', None), out.pop('render_depth_fine', None)
+        return out
+
     @staticmethod
     def draw_fine_u(rn, fdn, chunk):
         """The is_train inverse-CDF samples exactly as the reference draws them: one torch.rand([1,chunk_rn,fdn])
@@ -165,7 +203,9 @@ class NeuralRayRenderer(nn.Module):
         return torch.cat([torch.rand([1, min(chunk, rn - r0), fdn]) for r0 in range(0, rn, chunk)], 1)
 
     # ---- the reference's methods ------------------------------------------------------------------
-    def sample_volume(self, ref_imgs_info, _prep=None):                     # renderer.py:164-199
+    def sample_volume(self, ref_imgs_info, _prep=None, is_train=False):     # renderer.py:164-199
+        if self._use_autograd(is_train):
+            return _ag.sample_volume(self._params(), ref_imgs_info, self.cfg['volume_resolution'])
         bref, prep = _prep or self._prepare(ref_imgs_info)
         return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
 
@@ -185,6 +225,8 @@ class NeuralRayRenderer(nn.Module):
 
     def render(self, que_imgs_info, ref_imgs_info, is_train, _prep=None):   # renderer.py:201-220 (+140-162)
         rn = que_imgs_info['coords'].shape[1]
+        if self._use_autograd(is_train):
+            return self._render_autograd(que_imgs_info, ref_imgs_info)
         bref, prep = _prep or self._prepare(ref_imgs_info, rn)
         bque = self._batched_que(que_imgs_info)
         if is_train:
@@ -194,7 +236,8 @@ class NeuralRayRenderer(nn.Module):
             fdn, chunk = self.cfg['fine_depth_sample_num'], self.cfg['ray_batch_num']
             bque['fine_u'] = self.draw_fine_u(rn, fdn, chunk)
             for net in (self.agg_net, self.fine_agg_net):          # aggregate_net.py:135-137 bookkeeping
-                net.step += (rn + chunk - 1) // chunk
+                for _ in range((rn + chunk - 1) // chunk):
+                    net.train_step_bookkeeping()
         co, fi = self.hot().render(bref, bque, self._render_cfg(), prepared=prep)
         out = self._out_dict(co, '', self.agg_net)
         out.update(self._out_dict(fi, '_fine', self.fine_agg_net))
@@ -212,10 +255,16 @@ class NeuralRayRenderer(nn.Module):
         idx = torch.randperm(h * w, device=gen_dev)[:self.cfg['depth_loss_coords_num']]
         return torch.stack([idx // w, idx % w], -1).to(device)              # (row, col)
 
-    def predict_mean_for_depth_loss(self, ref_imgs_info, _prep=None):       # renderer.py:230-266
+    def predict_mean_for_depth_loss(self, ref_imgs_info, _prep=None, is_train=False):       # renderer.py:230-266
         h, w = ref_imgs_info['imgs'].shape[-2:]
         rfn = ref_imgs_info['imgs'].shape[0]
         coords = self.gen_depth_loss_coords(h, w, ref_imgs_info['imgs'].device)
+        if self._use_autograd(is_train):
+            P = self._params()
+            mc = _ag.depth_mean(P, ref_imgs_info, coords, 'dist_decoder.')
+            mf = _ag.depth_mean(P, ref_imgs_info, coords, 'fine_dist_decoder.')
+            return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
+                    'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]}
         # the reference feeds (row, col) where (x, y) is expected; kept
         xy = coords.to(torch.float32)[None]
         bref, prep = _prep or self._prepare(ref_imgs_info)
@@ -233,13 +282,14 @@ class NeuralRayRenderer(nn.Module):
         ref['ray_feats'] = self.init_net(ref, data.get('src_imgs_info'), is_train)
         ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
         out = {}
-        prep = self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
+        prep = None if self._use_autograd(is_train) else \
+            self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
         if self.cfg['render_rgb']:
             out = self.render(que, ref, is_train, _prep=prep)
         if self.cfg.get('sample_volume', False):
-            out['volume'] = self.sample_volume(ref, _prep=prep)
+            out['volume'] = self.sample_volume(ref, _prep=prep, is_train=is_train)
         if (self.cfg.get('use_depth_loss', False) and 'true_depth' in ref) or (not is_train):
-            out.update(self.predict_mean_for_depth_loss(ref, _prep=prep))
+            out.update(self.predict_mean_for_depth_loss(ref, _prep=prep, is_train=is_train))
         return out
 
 

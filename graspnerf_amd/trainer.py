@@ -1,0 +1,90 @@
+"""Minimal training step for the reference's configuration (BASELINE.json configs[4]):
+forward in training mode, the configured losses (`loss: [render, depth, sdf, vgn]`), backward, ONE flat gradient
+all-reduce over RCCL, Adam with the exponential-decay schedule.
+ref: src/nr/train/trainer.py:142-158 (step), train/lr_common_manager.py:19-29 (ExpDecayLR), network/loss.py.
+
+Scenes are independent, so data parallelism is "every rank takes its scenes, gradients are summed": the only
+collective is a sum all-reduce of one flat fp32 buffer (4.66 M parameters = 18.6 MB), divided by the global scene count.
+Parameters that received no gradient contribute zeros (the NeuS variance only becomes trainable after the first step,
+neus.py:17-18), so the buffer layout is static.  The backward of the volumetric path is PyTorch autograd over
+autograd_path.py in this round (the HIP kernels are forward-only)."""
+import torch
+import torch.distributed as dist
+
+from . import losses
+
+
+def train_losses(out, data, cfg=None):
+    """Every loss / metric term of the configured losses for one scene's outputs (ref: loss.py, name2loss)."""
+    ref = data['ref_imgs_info']
+    terms = {}
+    terms.update(losses.render_loss(out))
+    terms.update(losses.depth_loss(out, ref['true_depth'], ref['depth_range']))
+    terms.update(losses.sdf_loss(out, ref['sdf_gt']))
+    terms.update(losses.vgn_loss(out['vgn_pred'], data['grasp_info']))
+    return terms
+
+
+def exp_decay_lr(step, lr_init=1e-4, decay_step=100000, decay_rate=0.5, lr_min=1e-5):
+    return max(lr_init * (decay_rate ** (step // decay_step)), lr_min)
+
+
+class Trainer:
+    def __init__(self, net, lr_cfg=None):
+        self.net = net
+        self.lr_cfg = lr_cfg or {}
+        self.params = [p for p in net.parameters()]
+        self.optimizer = torch.optim.Adam(self.params, lr=1e-3)            # lr_common_manager.py:9-13
+        self.step_id = 0
+        self._flat = None
+
+    def _allreduce_grads(self, n_local):
+        """Sum of per-scene gradients over all ranks / global scene count, through one flat buffer."""
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        if self._flat is None or self._flat.numel() != n + 1 or self._flat.device != dev:
+            self._flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        flat = self._flat
+        flat.zero_()
+        off = 0
+        for p in self.params:
+            if p.grad is not None:
+                flat[off:off + p.numel()] = p.grad.reshape(-1)
+            off += p.numel()
+        flat[n] = float(n_local)                                          # scene count rides along
+        if world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        total = flat[n].clamp(min=1.0)
+        off = 0
+        for p in self.params:
+            g = (flat[off:off + p.numel()] / total).reshape(p.shape)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += p.numel()
+        return world
+
+    def step(self, scenes):
+        """scenes: list of `data` dicts (this rank's share of the global batch).  Gradients of the per-scene total
+        losses are accumulated, all-reduced, averaged over the global scene count; one Adam update.
+        -> dict of loss terms averaged over the local scenes, lr."""
+        self.net.train()
+        lr = exp_decay_lr(self.step_id, **self.lr_cfg)
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr
+        self.optimizer.zero_grad(set_to_none=True)
+        log = {}
+        for data in scenes:
+            data = dict(data, step=self.step_id)
+            out = self.net(data)
+            terms = train_losses(out, data)
+            losses.total_loss(terms).backward()                           # accumulates into .grad
+            for k, v in terms.items():
+                log[k] = log.get(k, 0.0) + float(v.detach().mean()) / len(scenes)
+        self._allreduce_grads(len(scenes))
+        self.optimizer.step()
+        self.step_id += 1
+        log['lr'] = lr
+        return log

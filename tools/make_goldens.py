@@ -225,6 +225,57 @@ def run_full_forward(renderer):
     print('full forward golden:', {k: v.shape for k, v in g.items()})
 
 
+def run_train_step(renderer):
+    """One training step of the reference (trainer.py:142-158): GraspNeRF.forward in train mode on the cfg1 scene with
+    synthetic supervision (synth_loss_case targets), the configured losses (loss: [render, depth, sdf, vgn]), backward.
+    -> tests/golden/golden_train_step.npz: every loss term, the gradient of every hot-path parameter (full arrays) and the
+    L2 norm of every parameter's gradient."""
+    _stub_optional_modules()
+    import network.loss as L
+    cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
+    for k, v in (('volume_resolution', 16), ('depth_sample_num', 16), ('fine_depth_sample_num', 16), ('ray_batch_num', 40)):
+        cfg[k] = v
+    cfg['agg_net_cfg']['sample_num'] = cfg['fine_agg_net_cfg']['sample_num'] = 16
+    import utils.field_utils as fu
+    fu.RESOLUTION, fu.VOXEL_SIZE = 16, fu.VOLUME_SIZE / 16
+    fu.HALF_VOXEL_SIZE = fu.VOXEL_SIZE / 2
+    renderer.TSDF_SAMPLE_POINTS = fu.generate_grid_points()
+    net = renderer.GraspNeRF(cfg)
+    net.train()
+    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
+    ref, que = make_scene(0, 'cfg1')
+    _, gt = synth_loss_case()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    ref_info = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
+    ref_info.update(true_depth=t(gt['true_depth']), sdf_gt=t(gt['sdf_gt']))
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    data = {'step': 0, 'ref_imgs_info': ref_info, 'que_imgs_info': que_info, 'src_imgs_info': dict(ref_info),
+            'grasp_info': tuple(t(x) for x in gt['grasp_info']), 'scene_name': 'vgn_syn/train/pile/x'}
+    torch.manual_seed(321)
+    out = net(data)
+    terms = {}
+    for loss in (L.RenderLoss({'use_nr_fine_loss': True}), L.DepthLoss({}), L.SDFLoss({}), L.VGNLoss({})):
+        terms.update(loss(out, data, 0))
+    total = sum(torch.mean(v) for k, v in terms.items() if k.startswith('loss'))
+    total.backward()
+    g = {'loss.' + k: np.asarray(v.detach().numpy(), np.float64).reshape(-1) for k, v in terms.items()}
+    g['total'] = np.float64(total.item())
+    names, norms = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        norms.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+        if p.grad is not None and any(s in k for s in ('dist_decoder', 'agg_net')):
+            g['grad.' + k] = p.grad.numpy()
+    g['param_names'] = np.array(names)
+    g['grad_norms'] = np.asarray(norms)
+    g['no_grad'] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+    np.savez_compressed(ROOT + '/tests/golden/golden_train_step.npz', **g)
+    print('train step golden: total', total.item(), {k: float(v.mean()) for k, v in terms.items() if k.startswith('loss')})
+    print('  params', len(names), 'without grad', len(g['no_grad']), 'hot-path grads stored', sum(k.startswith('grad.') for k in g))
+
+
 def run_losses():
     """Reference losses (loss.py) on synth_loss_case tensors -> tests/golden/golden_losses.npz."""
     import types
@@ -297,6 +348,8 @@ def main():
     renderer = import_reference()
     if '--post-only' in sys.argv:
         return run_post()
+    if '--train-step-only' in sys.argv:
+        return run_train_step(renderer)
     if '--losses-only' in sys.argv:
         return run_losses()
     if '--full-only' in sys.argv:
@@ -329,6 +382,7 @@ def main():
     run_full_forward(renderer)
     run_losses()
     run_post()
+    run_train_step(renderer)
 
 
 if __name__ == '__main__':

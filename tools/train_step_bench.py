@@ -1,0 +1,85 @@
+"""End-to-end train step (BASELINE.json configs[4]): backbones + volumetric path + grasp head + losses, backward, one flat
+gradient all-reduce over RCCL, Adam.  `--scenes` scenes per GPU per step (default 8), full-size scenes (6 views 288x512,
+40^3 volume, 512 rays x (40+40) samples).  The backward of the volumetric path is PyTorch autograd over
+graspnerf_amd/autograd_path.py in this round (HIP `*_bwd` kernels are not built), so this measures the interim
+training path, not the HIP kernels.
+    python tools/train_step_bench.py [--scenes 8] [--steps 3] [--warmup 1]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py ..."""
+import argparse, json, os, sys, time
+import numpy as np, torch, yaml
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graspnerf_amd.renderer import GraspNeRF
+from graspnerf_amd.synth import make_scene, synth_state_dict, synth_loss_case
+from graspnerf_amd.trainer import Trainer
+
+CFG = yaml.safe_load("""
+network: grasp_nerf
+init_net_type: cost_volume
+agg_net_type: neus
+use_hierarchical_sampling: true
+use_depth_loss: true
+dist_decoder_cfg: {use_vis: false}
+fine_dist_decoder_cfg: {use_vis: false}
+ray_batch_num: 4096
+sample_volume: true
+render_rgb: true
+volume_type: [sdf]
+volume_resolution: 40
+depth_sample_num: 40
+fine_depth_sample_num: 40
+agg_net_cfg: {sample_num: 40, init_s: 0.3, fix_s: 0}
+fine_agg_net_cfg: {sample_num: 40, init_s: 0.3, fix_s: 0}
+render_depth: true
+""")
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--scenes', type=int, default=8)
+ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--warmup', type=int, default=1)
+a = ap.parse_args()
+world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
+torch.cuda.set_device(local)
+dev = torch.device('cuda', local)
+dist = None
+if 'TORCHELASTIC_RUN_ID' in os.environ or world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+net = GraspNeRF(CFG)
+syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
+net = net.to(dev)
+tr = Trainer(net)
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+scenes = []
+for i in range(a.scenes):
+    ref, que = make_scene(rank * a.scenes + i, 'cfg2')
+    _, gt = synth_loss_case(seed=100 + i, rfn=6, h=288, w=512, rn=512, R=40)
+    ri = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
+    ri.update(true_depth=t(gt['true_depth']), sdf_gt=t(gt['sdf_gt']))
+    qi = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+          'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    scenes.append({'ref_imgs_info': ri, 'que_imgs_info': qi, 'src_imgs_info': dict(ri), 'grasp_info': tuple(t(x) for x in gt['grasp_info'])})
+
+def sync():
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+for _ in range(a.warmup):
+    log = tr.step(scenes)
+sync(); t0 = time.perf_counter()
+for _ in range(a.steps):
+    log = tr.step(scenes)
+sync(); dt = time.perf_counter() - t0
+tm = torch.tensor([dt], device=dev)
+if dist is not None:
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+if rank == 0:
+    dt = float(tm)
+    print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
+                      'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+                      'scenes_per_gpu': a.scenes, 'backward': 'torch autograd over graspnerf_amd/autograd_path.py (interim; no HIP bwd kernels yet)',
+                      'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
+                      'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
+if dist is not None:
+    dist.destroy_process_group()
