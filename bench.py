@@ -37,13 +37,15 @@ def chain_flops(points, views, render):
 
 def recorded_traffic(batch):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
-    (profiles/r01_pmc_counters.json: separate --pmc runs of FETCH_SIZE and WRITE_SIZE, gfx950 2x read
-    correction applied).  PMC counters cannot be read from inside this process, so the figure is the
+    (newest profiles/r*_pmc_counters.json, made by tools/collect_profiles.sh: separate --pmc runs of FETCH_SIZE and
+    WRITE_SIZE, gfx950 2x read correction applied).  PMC counters cannot be read from inside this process, so the figure is the
     recorded one and only reported for the batch size it was measured at."""
     try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_counters.json')))
-        return rec['k_chain_volume_traffic_bytes_per_launch'] if batch == 32 else None
-    except (OSError, KeyError, ValueError):
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
+        rec = json.load(open(newest))
+        return int(rec['kernels']['k_chain<6, false>']['hbm_bytes_corrected']) if batch == 32 else None
+    except (OSError, KeyError, ValueError, IndexError):
         return None
 
 

@@ -1,0 +1,32 @@
+"""Aggregate rocprofv3 --pmc CSV outputs (one run per counter set) into the per-kernel JSON kept under profiles/.
+Usage: python tools/pmc_summary.py <dir with *_counter_collection.csv> <out.json>"""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+src, out = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
+    per_dispatch = defaultdict(float)
+    meta = {}
+    for r in csv.DictReader(open(f)):
+        key = (f, r['Dispatch_Id'], r['Counter_Name'])
+        per_dispatch[key] += float(r['Counter_Value'])
+        meta[(f, r['Dispatch_Id'])] = r['Kernel_Name']
+    for (ff, did, cname), v in per_dispatch.items():
+        name = meta[(ff, did)]
+        m = re.search(r'gnr::(k_\w+(<[^>]*>)?)', name)
+        if m:
+            acc[m.group(1)][cname].append(v)
+res = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
+for k, cs in res.items():
+    if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
+        cs['hbm_bytes_corrected'] = (2 * cs['FETCH_SIZE'] + cs['WRITE_SIZE']) * 1024
+json.dump({
+    'command': 'rocprofv3 --pmc <set> --output-format csv -- python tools/run_hot.py --iters 1   (B=32 scenes, 6 views, 40^3 + 512 rays; '
+               'one run per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU SQ_INSTS_MFMA | '
+               'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES | SQ_WAVE_CYCLES GRBM_GUI_ACTIVE)',
+    'units': 'FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; per-launch averages',
+    'note': 'gfx950: FETCH_SIZE under-counts wide (16 B/lane) reads by 2x (MI355X_MICROARCH.md, HBM section); hbm_bytes_corrected = '
+            '(2*FETCH_SIZE + WRITE_SIZE)*1024 is the corrected upper bound used for roofline.traffic.',
+    'kernels': res}, open(out, 'w'), indent=1)
+print(json.dumps({k: {c: round(v, 1) for c, v in cs.items()} for k, cs in res.items() if k.startswith('k_chain')}, indent=1))
