@@ -320,7 +320,37 @@ constexpr int SW = 20;
 #ifndef GNR_VIEW_UNROLL
 #define GNR_VIEW_UNROLL 1
 #endif
-constexpr int view_unroll(int V) { return (GNR_VIEW_UNROLL >= 3 && V % 3 == 0) ? 3 : ((GNR_VIEW_UNROLL >= 2 && V % 2 == 0) ? 2 : 1); }     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c rgb
+constexpr int view_unroll(int V) { return GNR_VIEW_UNROLL >= V ? V : ((GNR_VIEW_UNROLL >= 3 && V % 3 == 0) ? 3 : ((GNR_VIEW_UNROLL >= 2 && V % 2 == 0) ? 2 : 1)); }     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c rgb
+
+// GNR_ROW_SWITCH 1 (both view loops) / 2 (second view loop only): the per-view state S[V][SW] is addressed through wave-uniform branches on the view index (one
+// specialised copy of the 20-register row move per view) instead of being rotated by one row per view; needs
+// -mllvm -simplifycfg-sink-common=false, otherwise LLVM merges the arms into one access through a pointer phi and S
+// falls out of registers.
+#ifndef GNR_ROW_SWITCH
+#define GNR_ROW_SWITCH 0
+#endif
+template <int K, int V, int N>
+DEV void row_store(float (&S)[V][SW], int v, const float (&R)[N]) {
+    if constexpr (K < V) {
+        if (v == K) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) S[K][q] = R[q];
+        } else {
+            row_store<K + 1, V, N>(S, v, R);
+        }
+    }
+}
+template <int K, int V>
+DEV void row_load(const float (&S)[V][SW], int v, float (&R)[SW]) {
+    if constexpr (K < V) {
+        if (v == K) {
+#pragma unroll
+            for (int q = 0; q < SW; ++q) R[q] = S[K][q];
+        } else {
+            row_load<K + 1, V>(S, v, R);
+        }
+    }
+}
 
 #ifndef GNR_CHAIN_THREADS
 #define GNR_CHAIN_THREADS 512     // 8 wavefronts = 2 per SIMD at <= 256 registers; 256 (1 per SIMD, 512 registers) was measured too
@@ -394,16 +424,22 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
         // register file S is rotated once per trip instead of once per view.
 #pragma unroll 1
         for (int v0 = 0; v0 < V; v0 += UNR) {
+#if GNR_ROW_SWITCH != 1
 #pragma unroll
             for (int k = 0; k < V - UNR; ++k)
 #pragma unroll
                 for (int q = 0; q < SW; ++q) S[k][q] = S[k + UNR][q];
+#endif
 #pragma unroll
           for (int vu = 0; vu < UNR; ++vu) {
             __builtin_amdgcn_sched_barrier(0);
             GNR_ITER_FENCE();
             const int v = v0 + vu;
+#if GNR_ROW_SWITCH == 1
+            float Sv[SW];
+#else
             float (&Sv)[SW] = S[V - UNR + vu];
+#endif
             const int bv = b * V + v;
             const float* vp = a.viewp + bv * VIEWP_FLOATS;
             ViewGeom vg;
@@ -513,6 +549,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
                 Sv[17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
             }
             Sv[18] = m;
+#if GNR_ROW_SWITCH == 1
+            row_store<0, V, SW>(S, v, Sv);
+#endif
             if (a.dbg && g == 0 && row_ok) { a.dbg[pt * 32 + v] = hit; a.dbg[pt * 32 + 8 + v] = vis; }
         }
         }
@@ -550,28 +589,55 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
         float vsum = 0.f;
 #pragma unroll 1
         for (int v0 = 0; v0 < V; v0 += UNR) {
-          float X2[UNR][9], E2[UNR][8], m2[UNR], rgb2[UNR];
+          // fully unrolled (UNR == V): every view works in place on its own row of S, nothing is copied or rotated
+          constexpr int CU = (UNR == V) ? 1 : UNR;
+          float X2[CU][9], E2[CU][8], m2[CU], rgb2[CU];
+#if GNR_ROW_SWITCH
+          static_assert(UNR == 1, "GNR_ROW_SWITCH needs the rolled view loop");
+          float Rv[SW];
+          row_load<0, V>(S, v0, Rv);
 #pragma unroll
-          for (int vu = 0; vu < UNR; ++vu) {
+          for (int j = 0; j < 9; ++j) X2[0][j] = Rv[j];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) X2[vu][j] = S[vu][j];
+          for (int j = 0; j < 8; ++j) E2[0][j] = Rv[9 + j];
+          m2[0] = Rv[18]; rgb2[0] = Rv[19];
+          if constexpr (false) {
+#else
+          if constexpr (UNR != V) {
+#endif
 #pragma unroll
-            for (int j = 0; j < 8; ++j) E2[vu][j] = S[vu][9 + j];
-            m2[vu] = S[vu][18]; rgb2[vu] = S[vu][19];
-          }
+            for (int vu = 0; vu < UNR; ++vu) {
+#pragma unroll
+              for (int j = 0; j < 9; ++j) X2[vu][j] = S[vu][j];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) E2[vu][j] = S[vu][9 + j];
+              m2[vu] = S[vu][18]; rgb2[vu] = S[vu][19];
+            }
 #pragma unroll
             for (int k = 0; k < V - UNR; ++k)
 #pragma unroll
                 for (int q = 0; q < SW; ++q) S[k][q] = S[k + UNR][q];
+          }
 #pragma unroll
           for (int vu = 0; vu < UNR; ++vu) {
             __builtin_amdgcn_sched_barrier(0);
             GNR_ITER_FENCE();
             const int v = v0 + vu;
-            float (&X)[9] = X2[vu];
-            float (&E)[8] = E2[vu];
-            const float m = m2[vu], rgbraw = rgb2[vu];
+#if GNR_ROW_SWITCH
+            float Sv[11];
+#else
             float (&Sv)[SW] = S[V - UNR + vu];
+#endif
+            if constexpr (UNR == V && !GNR_ROW_SWITCH) {
+#pragma unroll
+              for (int j = 0; j < 9; ++j) X2[0][j] = Sv[j];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) E2[0][j] = Sv[9 + j];
+              m2[0] = Sv[18]; rgb2[0] = Sv[19];
+            }
+            float (&X)[9] = X2[UNR == V ? 0 : vu];
+            float (&E)[8] = E2[UNR == V ? 0 : vu];
+            const float m = m2[UNR == V ? 0 : vu], rgbraw = rgb2[UNR == V ? 0 : vu];
             const float w = m * inv_msum;
             float Hh[8];
             {
@@ -637,6 +703,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             Sv[8] = v2;
             Sv[9] = clog;
             Sv[10] = rgbraw;
+#if GNR_ROW_SWITCH
+            row_store<0, V, 11>(S, v, Sv);
+#endif
             if (a.dbg && g == 0 && row_ok) a.dbg[pt * 32 + 16 + v] = v2;
         }
         }
