@@ -49,6 +49,23 @@ def recorded_traffic(batch):
         return None
 
 
+def recorded_counters(batch):
+    """MFMA-pipe busy fraction and L2 hit rate of the dominant kernel from the same recorded PMC pass."""
+    try:
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
+        k = json.load(open(newest))['kernels']['k_chain<6, false>']
+        if batch != 32:
+            return None
+        return {'source': os.path.relpath(newest, ROOT),
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+                'mfma_pipe_busy': round(k['SQ_VALU_MFMA_BUSY_CYCLES'] / (k['GRBM_GUI_ACTIVE'] / 8 * 1024), 3),
+                'l2_hit_rate': round(k['TCC_HIT_sum'] / (k['TCC_HIT_sum'] + k['TCC_MISS_sum']), 3),
+                'mfma_per_launch': k['SQ_INSTS_MFMA'], 'valu_incl_mfma_per_launch': k['SQ_INSTS_VALU']}
+    except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError):
+        return None
+
+
 def cpu_baseline(weights_np, budget_s=25.0):
     """The oracle (torch-CPU fp32 port of the reference path) timed on this box's host cores on a
     bounded sample: whole scenes of the same workload (volume + 512-ray render)."""
@@ -163,6 +180,14 @@ def main():
                          'flops_per_launch': fl,
                          'note': 'algorithmic (un-hoisted) fp32 FLOPs: 2*(6*27736+6528) per point, SURVEY.md §8d'},
         }
+        # SURVEY.md §8d extras: the whole step against both rooflines (38.7 GFLOP and 26.0 MB compulsory HBM bytes
+        # per scene, TSDF + render) and the recorded counters of the dominant kernel
+        sps = world * B * args.steps / dt / world
+        out['roofline']['whole_step'] = {'fp32_fraction': round(38.7e9 * sps / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                                         'hbm_fraction': round(26.0e6 * sps / 8.0e12, 5),
+                                         'traffic_GBps_dominant_kernel': None if recorded_traffic(B) is None else
+                                         round(recorded_traffic(B) / (ms * 1e-3) / 1e9, 1)}
+        out['roofline']['counters'] = recorded_counters(B)
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wnp)
         print(json.dumps(out), flush=True)

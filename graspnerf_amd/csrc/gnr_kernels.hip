@@ -853,14 +853,17 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     const int ray = min(ray_u, a.nrays - 1);
     const bool act = rvalid && slot < dn;
     const int i = min(slot, dn - 1);
-    constexpr int PER = RENDER ? 76 : 32;            // floats of attention scratch per sample
+    constexpr int PER = RENDER ? 76 : 36;            // floats of attention scratch per sample
     float* sc = sm + (size_t)rl * a.ray_stride;
     float* Kb = sc;                                   // [dn][16]
     float* Vb = sc + dn * 16;                         // [dn][16]
     float* Qb = sc + dn * 32;                         // [dn][16]   (RENDER)
     float* Ob = sc + dn * 48;                         // [dn][16]   dO  (RENDER)
     float* St = sc + dn * 64;                         // [dn][12]   max[4], +-1/sum[4] (sign of [0] = row ok), rs[4] (RENDER)
-    (void)PER; (void)Qb; (void)Ob; (void)St;
+    // squared key norms per head: in the dO slots until the VJP needs them (RENDER), else 4 extra floats per sample
+    float* KN = RENDER ? Ob : sc + dn * 32;
+    constexpr int KNS = RENDER ? 16 : 4;
+    (void)PER; (void)Qb; (void)St;
     const size_t pt = (size_t)ray * dn + i;
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
     const float* rec = a.rec + pt * REC;
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             const f4 v4 = {vv[4 * c], vv[4 * c + 1], vv[4 * c + 2], vv[4 * c + 3]};
             reinterpret_cast<f4*>(Kb + i * 16)[c] = k4;
             reinterpret_cast<f4*>(Vb + i * 16)[c] = v4;
+            KN[i * KNS + c] = k4.x * k4.x + k4.y * k4.y + k4.z * k4.z + k4.w * k4.w;
             if constexpr (RENDER) {
                 const f4 q4 = {q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]};
                 reinterpret_cast<f4*>(Qb + i * 16)[c] = q4;
@@ -910,32 +914,57 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     }
     __syncthreads();
 
-    // ---- attention, lane = query row (ibrnet.py:15-27): softmax over dn keys, 4 heads per key visit
-    float amax[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-#pragma unroll UA
-    for (int j = 0; j < dn; ++j) {
-        float sj[4];
-        head_logits(q, Kb + j * 16, rowok, sj);
+    // ---- attention, lane = query row (ibrnet.py:15-27): softmax over dn keys, 4 heads per key visit.
+    // Softmax shift without a pass over the logits: s_ij = q_i.k_j/2 <= |q_i| max_j|k_j| / 2 (Cauchy-Schwarz), so that
+    // bound replaces the row maximum (softmax is shift-invariant; exp(s - shift) <= 1 cannot overflow).  If the bound is
+    // so loose that a whole row underflows (shift - max s > ~87) the lane falls back to the true maximum.
+    float amax[4];
+    {
+        f4 kmax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int j = 0; j < dn; ++j) {
+            const f4 n = *reinterpret_cast<const f4*>(KN + j * KNS);
+            kmax.x = fmaxf(kmax.x, n.x); kmax.y = fmaxf(kmax.y, n.y); kmax.z = fmaxf(kmax.z, n.z); kmax.w = fmaxf(kmax.w, n.w);
+        }
 #pragma unroll
-        for (int h = 0; h < 4; ++h) amax[h] = fmaxf(amax[h], sj[h]);
+        for (int h = 0; h < 4; ++h) {
+            const float qn = q[4 * h] * q[4 * h] + q[4 * h + 1] * q[4 * h + 1] + q[4 * h + 2] * q[4 * h + 2] + q[4 * h + 3] * q[4 * h + 3];
+            amax[h] = rowok ? 0.5f * sqrtf(qn * kmax[h]) : -1e9f;
+        }
     }
     float o[16], ainv[4];
     {
-        float l[4] = {0.f, 0.f, 0.f, 0.f};
+        float l[4];
+        auto sweep = [&]() {
 #pragma unroll
-        for (int f = 0; f < 16; ++f) o[f] = 0.f;
+            for (int h = 0; h < 4; ++h) l[h] = 0.f;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) o[f] = 0.f;
 #pragma unroll UA
-        for (int j = 0; j < dn; ++j) {
-            float sj[4];
-            head_logits(q, Kb + j * 16, rowok, sj);
+            for (int j = 0; j < dn; ++j) {
+                float sj[4];
+                head_logits(q, Kb + j * 16, rowok, sj);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
-                const float pj = __expf(sj[h] - amax[h]);
-                l[h] += pj;
-                o[4 * h] = fmaf(pj, vj.x, o[4 * h]); o[4 * h + 1] = fmaf(pj, vj.y, o[4 * h + 1]);
-                o[4 * h + 2] = fmaf(pj, vj.z, o[4 * h + 2]); o[4 * h + 3] = fmaf(pj, vj.w, o[4 * h + 3]);
+                for (int h = 0; h < 4; ++h) {
+                    const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
+                    const float pj = __expf(sj[h] - amax[h]);
+                    l[h] += pj;
+                    o[4 * h] = fmaf(pj, vj.x, o[4 * h]); o[4 * h + 1] = fmaf(pj, vj.y, o[4 * h + 1]);
+                    o[4 * h + 2] = fmaf(pj, vj.z, o[4 * h + 2]); o[4 * h + 3] = fmaf(pj, vj.w, o[4 * h + 3]);
+                }
             }
+        };
+        sweep();
+        if (!(fminf(fminf(l[0], l[1]), fminf(l[2], l[3])) > 1e-30f)) {      // rare: exact row maxima, second sweep
+#pragma unroll
+            for (int h = 0; h < 4; ++h) amax[h] = -3.0e38f;
+            for (int j = 0; j < dn; ++j) {
+                float sj[4];
+                head_logits(q, Kb + j * 16, rowok, sj);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) amax[h] = fmaxf(amax[h], sj[h]);
+            }
+            sweep();
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -1026,6 +1055,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
 #pragma unroll
             for (int f = 0; f < 16; ++f) dQ[f] = (A1[f] - rsv[f >> 2] * B1[f]) * sc2;
         }
+        __syncthreads();                                  // every lane is past the key-norm sweep: the dO slots are free
         if (act) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {

@@ -245,6 +245,31 @@ def test_ragged_and_extreme_sizes(res, rn, dn, hot, W):
         assert np.array_equal(o['ray_mask'].cpu().numpy()[i], ref_o['ray_mask'].numpy()[0])
 
 
+@pytest.mark.parametrize('scale', [6.0, 40.0])
+def test_attention_with_peaked_softmax(scale, weights_np):
+    """Attention projections scaled up: logits of +-hundreds (one-hot softmax).  The kernel shifts the softmax by the
+    Cauchy-Schwarz bound |q||k|/2 and must fall back to the exact row maximum when that bound underflows a whole row."""
+    from graspnerf_amd.hotpath import HotPath
+    wn = dict(weights_np)
+    for lvl in ('agg_net', 'fine_agg_net'):
+        for m in ('w_qs', 'w_ks'):
+            k = f'{lvl}.agg_impl.ray_attention.{m}.weight'
+            wn[k] = wn[k] * np.float32(scale)
+    hp = HotPath(weights.pack_state_dict(wn, 'coarse'), weights.pack_state_dict(wn, 'fine'))
+    Wt = {k: torch.from_numpy(v) for k, v in wn.items()}
+    scenes, (bref, bque) = _batched('cfg1')
+    vol = hp.sample_volume(bref, 16).cpu().numpy()
+    assert np.isfinite(vol).all()
+    close(vol[0], O.sample_volume(Wt, O.to_torch(scenes[0][0]), 16).numpy()[0], f'volume, attention x{scale}', atol=5e-4)
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16}
+    co, fi = hp.render(bref, bque, cfg)
+    ref_o = O.render(Wt, O.to_torch(scenes[0][0]), O.to_torch(scenes[0][1]), cfg, fine_depth_override=fi['depth'][0].cpu())
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr'):
+        a = co[k].cpu().numpy()
+        assert np.isfinite(a).all()
+        close(a, ref_o[k].numpy(), f'coarse {k}, attention x{scale}', atol=2e-3)
+
+
 def test_bad_sizes_are_refused(hot):
     from graspnerf_amd import _lib
     scenes, (bref, bque) = _batched('cfg1')

@@ -54,7 +54,7 @@ def scene_data(device='cpu', scene_id=0):
 
 def check_against_golden(net, terms, G, rtol_loss, rtol_grad):
     for k in ('loss_rgb_nr', 'loss_rgb_nr_fine', 'loss_depth', 'loss_depth_fine', 'loss_sdf', 'loss_eikonal', 'loss_vgn'):
-        np.testing.assert_allclose(float(terms[k].mean()), G['loss.' + k].mean(), rtol=rtol_loss, err_msg=k)
+        np.testing.assert_allclose(float(terms[k].detach().mean()), G['loss.' + k].mean(), rtol=rtol_loss, err_msg=k)
     norms = dict(zip(G['param_names'].tolist(), G['grad_norms'].tolist()))
     worst = 0.0
     for k, p in net.named_parameters():
@@ -81,7 +81,7 @@ def test_train_step_gradients_match_reference():
     assert out['s'].shape == (1, 2) and out['sdf_gradient_error_fine'].shape == (1, 2)      # 64 rays, chunks of 40
     terms = train_losses(out, data)
     total = losses.total_loss(terms)
-    np.testing.assert_allclose(float(total), float(G['total']), rtol=2e-5)
+    np.testing.assert_allclose(float(total.detach()), float(G['total']), rtol=2e-5)
     total.backward()
     check_against_golden(net, terms, G, rtol_loss=5e-5, rtol_grad=2e-3)
     assert net.nr_net.agg_net.deviation_network.variance.grad is not None                   # trainable from step 1 (fix_s 0)
