@@ -66,6 +66,44 @@ def make_scene(scene_id=0, cfg='cfg2', with_query_image=True):
     return ref, que
 
 
+def random_scene(seed):
+    """A scene with randomised geometry for parity sweeps: 2..8 views on a jittered ring (one camera may sit close to
+    or inside the workspace), per-view intrinsics and depth ranges, image and feature-map sizes without the fixed 1/4
+    ratio, a shifted workspace box, fractional (partly out-of-image) ray coordinates.
+    -> (ref, que, meta) with meta = dict(V, H, W, fh, fw, res, rn, dn)."""
+    rng = np.random.default_rng(5000 + seed)
+    V = int(rng.integers(2, 9))
+    H, W = int(rng.integers(24, 80)), int(rng.integers(32, 120))
+    fh, fw = max(3, int(H / rng.uniform(2.0, 6.0))), max(3, int(W / rng.uniform(2.0, 6.0)))
+    res, rn, dn = int(rng.integers(5, 15)), int(rng.integers(1, 40)), int(rng.integers(3, 49))
+    poses = []
+    for i in range(V):
+        phi = 2 * np.pi * (i + rng.uniform(-0.3, 0.3)) / V
+        theta = rng.uniform(0.5, 1.3)
+        radius = rng.uniform(0.08, 0.25) if (i == 0 and seed % 3 == 0) else rng.uniform(0.35, 0.7)
+        tgt = np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), 0.1 + rng.uniform(-0.05, 0.05)])
+        eye = tgt + radius * np.array([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)])
+        zf = (tgt - eye) / np.linalg.norm(tgt - eye)
+        xr = np.cross(zf, np.array([0.0, 0.0, 1.0]))
+        xr /= np.linalg.norm(xr)
+        R = np.stack([xr, np.cross(zf, xr), zf], 0)
+        poses.append(np.concatenate([R, (-R @ eye)[:, None]], 1))
+    poses = np.asarray(poses, np.float32)
+    f = rng.uniform(0.7, 1.3, V) * 0.75 * W
+    Ks = np.zeros((V, 3, 3), np.float32)
+    Ks[:, 0, 0], Ks[:, 1, 1], Ks[:, 2, 2] = f, f * rng.uniform(0.9, 1.1, V), 1.0
+    Ks[:, 0, 2], Ks[:, 1, 2] = W / 2 + rng.uniform(-4, 4, V), H / 2 + rng.uniform(-4, 4, V)
+    dr = np.stack([rng.uniform(0.1, 0.3, V), rng.uniform(0.6, 1.2, V)], 1).astype(np.float32)
+    bb0 = np.array([-0.15, -0.15, -0.05]) + rng.uniform(-0.1, 0.1, 3)
+    ref = dict(imgs=rng.random((V, 3, H, W)).astype(np.float32),
+               img_feats=(0.5 * rng.standard_normal((V, 32, fh, fw))).astype(np.float32),
+               ray_feats=(0.5 * rng.standard_normal((V, 32, fh, fw))).astype(np.float32),
+               poses=poses, Ks=Ks, depth_range=dr, bbox3d=np.stack([bb0, bb0 + 0.3]).astype(np.float32))
+    coords = np.stack([rng.uniform(-3, W + 2, rn), rng.uniform(-3, H + 2, rn)], -1).astype(np.float32)
+    que = dict(coords=coords, pose=poses[0].copy(), K=Ks[0].copy(), depth_range=dr[0].copy(), imgs=ref['imgs'][:1].copy())
+    return ref, que, dict(V=V, H=H, W=W, fh=fh, fw=fw, res=res, rn=rn, dn=dn)
+
+
 def synth_state_dict(shapes, seed=7):
     """Deterministic, construction-order independent parameters for a whole GraspNeRF model:
     every tensor is drawn from its own PCG64 stream keyed by crc32(name).  Used by the full-forward

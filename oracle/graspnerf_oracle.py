@@ -411,6 +411,14 @@ def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None):
     return fd, inds
 
 
+def query_pixel_colors(que):
+    """pixel_colors_gt: bilinear sample of the query image at the ray pixels, zeros padding, align_corners=True.
+    que: coords [rn,2], imgs [1,3,H,W] -> [1,rn,3].   ref: renderer.py:125-127."""
+    wh = torch.tensor([que['imgs'].shape[-1] - 1, que['imgs'].shape[-2] - 1], dtype=F32)
+    return F.grid_sample(que['imgs'], (que['coords'] / wh * 2 - 1)[None, None], mode='bilinear', padding_mode='zeros',
+                         align_corners=True)[0, :, 0].t()[None]
+
+
 DEFAULT_RENDER_CFG = {'depth_sample_num': 40, 'fine_depth_sample_num': 40,
                       'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
 
@@ -436,10 +444,8 @@ def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None, fine_u=
     fine = render_by_depth(sd, inp, que, fdepth, 'fine_dist_decoder.', 'fine_agg_net.', cfg, dbg_f)
     for k, v in fine.items():
         out[k + '_fine'] = v
-    if 'imgs' in que:                                                      # renderer.py:125-127
-        gt = F.grid_sample(que['imgs'], (que['coords'] / torch.tensor(
-            [que['imgs'].shape[-1] - 1, que['imgs'].shape[-2] - 1], dtype=F32) * 2 - 1)[None, None],
-            mode='bilinear', padding_mode='zeros', align_corners=True)[0, :, 0].t()[None]
+    if 'imgs' in que:
+        gt = query_pixel_colors(que)
         out['pixel_colors_gt'] = gt
         out['pixel_colors_gt_fine'] = gt
     if debug is not None:

@@ -245,6 +245,47 @@ def test_ragged_and_extreme_sizes(res, rn, dn, hot, W):
         assert np.array_equal(o['ray_mask'].cpu().numpy()[i], ref_o['ray_mask'].numpy()[0])
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_random_geometry_sweep(seed, hot, W):
+    """Randomised view counts, cameras (also close to / inside the workspace), per-view intrinsics and depth ranges,
+    image / feature-map sizes without the 1/4 ratio, shifted boxes, fractional and out-of-image ray coordinates.
+    Values are compared where the index-valued decisions (in-image masks) are not within float noise of a border."""
+    from graspnerf_amd.synth import random_scene
+    from graspnerf_amd.hotpath import batch_scenes
+    ref, que, m = random_scene(seed)
+    bref, bque = batch_scenes([(ref, que)])
+    V, res, rn, dn = m['V'], m['res'], m['rn'], m['dn']
+
+    def safe_points(dbg):                                    # points whose every view is >= 1e-3 px away from a border
+        uv, z = dbg['uv'].numpy(), dbg['z'].numpy()
+        marg = np.minimum.reduce([np.abs(uv[..., 0] + 0.5), np.abs(uv[..., 0] - (m['W'] - 0.5)),
+                                  np.abs(uv[..., 1] + 0.5), np.abs(uv[..., 1] - (m['H'] - 0.5))])
+        return ((marg > 1e-3) & (np.abs(np.abs(z) - 1e-4) > 1e-6)).all(0)
+    dbg = {}
+    vol_o = O.sample_volume(W, O.to_torch(ref), res, debug=dbg).numpy()
+    vol, vm = hot.sample_volume(bref, res, want_mask=True)
+    ok = safe_points(dbg).reshape(res * res, res)
+    cols = ok.all(1)                                        # a column's samples interact through the attention
+    mine = vol.cpu().numpy()[0, 0].reshape(res * res, res)[:, ::-1]
+    close(mine[cols], vol_o[0, 0].reshape(res * res, res)[:, ::-1][cols], f'seed {seed} volume {m}')
+    vmn = vm.cpu().numpy()[0].reshape(res * res, res)[:, ::-1]
+    for v in range(V):
+        assert np.array_equal(((vmn >> v) & 1).astype(bool)[ok], dbg['mask'][v].numpy().reshape(res * res, res)[ok])
+    depth = O.sample_depth(torch.from_numpy(que['depth_range']), rn, dn)
+    dbr = {}
+    ref_o = O.render_by_depth(W, O.to_torch(ref), O.to_torch(que), depth, 'dist_decoder.', 'agg_net.',
+                              O.DEFAULT_RENDER_CFG, debug=dbr)
+    o = hot.render_by_depth(bref, bque, depth[None], 'coarse')
+    # border margins of the ray points from the oracle's projection
+    pts, _ = O.ray_points(torch.from_numpy(que['coords']), torch.from_numpy(que['pose']), torch.from_numpy(que['K']), depth)
+    uv, z, _, _ = O.project_points(pts.reshape(-1, 3), torch.from_numpy(ref['poses']), torch.from_numpy(ref['Ks']), m['H'], m['W'])
+    rays = safe_points({'uv': uv, 'z': z}).reshape(rn, dn).all(1)
+    ref_o['pixel_colors_gt'] = O.query_pixel_colors(O.to_torch(que))
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'pixel_colors_nr', 'pixel_colors_gt'):
+        close(o[k].cpu().numpy()[0][rays], ref_o[k].numpy()[0][rays], f'seed {seed} {k} {m}', atol=3e-4)
+    assert np.array_equal(o['ray_mask'].cpu().numpy()[0][rays], ref_o['ray_mask'].numpy()[0][rays])
+
+
 @pytest.mark.parametrize('scale', [6.0, 40.0])
 def test_attention_with_peaked_softmax(scale, weights_np):
     """Attention projections scaled up: logits of +-hundreds (one-hot softmax).  The kernel shifts the softmax by the
