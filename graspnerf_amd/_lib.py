@@ -96,6 +96,14 @@ def lib():
                                      C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_grasp_head_fwd.restype = C.c_int
     L.gnr_head_last_error.restype = C.c_char_p
+    L.gnr_packed_bwd_floats.restype = C.c_int
+    L.gnr_pack_weights_bwd.argtypes = [c_float_p, c_float_p]
+    L.gnr_pack_weights_bwd.restype = C.c_int
+    L.gnr_depth_mean_bwd_workspace_bytes.argtypes = [C.POINTER(GnrScene)]
+    L.gnr_depth_mean_bwd_workspace_bytes.restype = C.c_size_t
+    L.gnr_depth_mean_bwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int] + [C.c_void_p] * 5 + \
+                                    [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_depth_mean_bwd.restype = C.c_int
     L.gnr_grasp_select_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.gnr_grasp_select_workspace_bytes.restype = C.c_size_t
     L.gnr_grasp_select_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.POINTER(GnrSelectParams)] + \
@@ -119,7 +127,8 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
             'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_grasp_select_workspace_bytes',
-            'gnr_grasp_select_fwd', 'gnr_post_last_error']
+            'gnr_grasp_select_fwd', 'gnr_post_last_error', 'gnr_packed_bwd_floats', 'gnr_pack_weights_bwd',
+            'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd']
 
 
 def check(rc, what):

@@ -1334,4 +1334,5 @@ __global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restri
 
 }  // namespace gnr
 
+#include "gnr_bwd.inc"
 #include "gnr_capi.inc"

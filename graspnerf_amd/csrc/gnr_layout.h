@@ -132,4 +132,12 @@ constexpr int REC_VOL = 20;     // g16[16], nvalid, pad
 constexpr int REC_RAY = 84;     // g16[16], u[64], nvalid, pad
 constexpr int MAX_DN = 64;      // samples per ray / column handled by one wavefront in k_ray
 
+// Backward blob (gnr_pack_weights_bwd): transposed weights as chained-MFMA A fragments, true scale (gradients are
+// kept in the true domain; the forward's log2e-scaled activations are rescaled where they enter a product).
+namespace pkb {
+constexpr int DM_W2T = 0;                  // mean_decoder.2^T : 32 (natural) -> 32 (natural)
+constexpr int DM_W1T = DM_W2T + 1024;      // mean_decoder.0^T : 32 (natural) -> 32 ray channels in gather layout (8g + j)
+constexpr int TOTAL = DM_W1T + 1024;
+}  // namespace pkb
+
 }  // namespace gnr

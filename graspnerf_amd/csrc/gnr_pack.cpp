@@ -81,6 +81,25 @@ extern "C" int gnr_layout_offset(const char* name) {
     return -1;
 }
 
+extern "C" int gnr_packed_bwd_floats(void) { return gnr::pkb::TOTAL; }
+
+// Transposed fragments for the backward twins (see gnr_layout.h, namespace pkb)
+extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
+    if (!c || !p) return GNR_ERR_ARG;
+    using namespace gnr;
+    std::memset(p, 0, sizeof(float) * pkb::TOTAL);
+    std::vector<float> T(1024);
+    auto transpose32 = [&](const float* W) { for (int o = 0; o < 32; ++o) for (int i = 0; i < 32; ++i) T[i * 32 + o] = W[o * 32 + i]; };
+    const IdxFn natI = nat_in, natO = nat_out;
+    // output rows land in the gather layout: lane group g, register 4*nb + t  <->  ray channel 8g + 4nb + t
+    const IdxFn gatherO = [](int nb, int i) { return 8 * (i / 4) + 4 * nb + (i % 4); };
+    transpose32(c + can::MEAN2_W);
+    pack_frag(p + pkb::DM_W2T, T.data(), 32, 8, 2, natI, natO);
+    transpose32(c + can::MEAN0_W);
+    pack_frag(p + pkb::DM_W1T, T.data(), 32, 8, 2, natI, gatherO);
+    return GNR_OK;
+}
+
 extern "C" int gnr_canonical_weights_floats(void) { return gnr::can::TOTAL; }
 extern "C" int gnr_packed_weights_floats(void) { return gnr::pk::TOTAL; }
 

@@ -52,7 +52,7 @@ class HotPath:
         return s, t
 
     def _workspace(self, scene, res, rn, dn):
-        need = self.L.gnr_workspace_bytes(C.byref(scene), res, rn, dn)
+        need = max(self.L.gnr_workspace_bytes(C.byref(scene), res, rn, dn), 0 if self._ws is None else self._ws.numel())
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -169,6 +169,33 @@ class HotPath:
         _lib.check(self.L.gnr_depth_mean_fwd(C.byref(scene), coords.data_ptr(), pn, w.data_ptr(), out.data_ptr(),
                                              ws.data_ptr(), ws.numel(), self._stream()), 'gnr_depth_mean_fwd')
         return out
+
+    def depth_mean_bwd(self, ref, coords, dmean, level='coarse', prepared=None, want_feat_grad=True):
+        """Backward of depth_mean: dmean [B,V,pn,2] -> (d_canonical [36958] gradient blob of the level in state-dict
+        order (mean_decoder entries), d_ray_feats [B,V,32,fh,fw] or None).  Packed weights must be current
+        (`set_bwd_weights`)."""
+        if getattr(self, 'wb', None) is None or self.wb.get(level) is None:
+            raise _lib.GnrError('depth_mean_bwd: call set_bwd_weights() first')
+        scene, keep, ws = prepared or self.prepare(ref, 1)
+        need = self.L.gnr_depth_mean_bwd_workspace_bytes(C.byref(scene))
+        if ws.numel() < need:                      # keep region A (prepared feature maps): grow and re-prepare
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            scene, keep, ws = self.prepare(ref, 1)
+        coords = _f32(coords, self.device)
+        dmean = _f32(dmean, self.device)
+        B, pn, _ = coords.shape
+        assert dmean.shape == (B, scene.V, pn, 2)
+        dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
+        dray = torch.empty(B, scene.V, 32, scene.fh, scene.fw, dtype=torch.float32, device=self.device) if want_feat_grad else None
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_depth_mean_bwd(C.byref(scene), coords.data_ptr(), pn, w.data_ptr(), self.wb[level].data_ptr(),
+                                             dmean.data_ptr(), dcan.data_ptr(), dray.data_ptr() if want_feat_grad else None,
+                                             ws.data_ptr(), ws.numel(), self._stream()), 'gnr_depth_mean_bwd')
+        return dcan, dray
+
+    def set_bwd_weights(self, packed_bwd_coarse, packed_bwd_fine=None):
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+        self.wb = {'coarse': t(packed_bwd_coarse), 'fine': t(packed_bwd_fine)}
 
     def time_chain_kernel(self, ref, res=40, iters=10):
         """Average ms per launch of the dominant kernel (k_chain on the volume points), HIP events

@@ -92,6 +92,28 @@ class _AggNetParams(nn.Module):
             self.deviation_network.variance.requires_grad_(True)
 
 
+_DM_PARAMS = ('0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias')
+
+
+class _DepthMeanFn(torch.autograd.Function):
+    """predict_mean_for_depth_loss for one level and one scene on the HIP path in both directions
+    (gnr_depth_mean_fwd / gnr_depth_mean_bwd).  Differentiable inputs: ray_feats [V,32,fh,fw] and the six
+    mean_decoder parameters; `prep` must stay untouched between forward and backward."""
+
+    @staticmethod
+    def forward(ctx, hot, bref, prep, xy, level, ray_feats, *params):
+        ctx.args = (hot, bref, prep, xy, level)
+        return hot.depth_mean(bref, xy, level, prepared=prep)[0]
+
+    @staticmethod
+    def backward(ctx, dmean):
+        hot, bref, prep, xy, level = ctx.args
+        dcan, dray = hot.depth_mean_bwd(bref, xy, dmean.contiguous()[None], level, prepared=prep)
+        dec = _w.LEVELS[level][0]
+        g = _w.split_canonical(dcan, level)
+        return (None, None, None, None, None, dray[0]) + tuple(g[dec + 'mean_decoder.' + n] for n in _DM_PARAMS)
+
+
 class NeuralRayRenderer(nn.Module):
     base_cfg = {
         'vis_encoder_type': 'default', 'vis_encoder_cfg': {}, 'dist_decoder_type': 'mixture_logistics',
@@ -139,6 +161,20 @@ class NeuralRayRenderer(nn.Module):
             sd = self.state_dict()
             dev = next(self.parameters()).device
             self._hot = HotPath(_w.pack_state_dict(sd, 'coarse'), _w.pack_state_dict(sd, 'fine'), device=dev)
+        return self._hot
+
+    def hot_for_training(self):
+        """The HIP path with weights re-packed from the CURRENT parameter values (they move every optimiser step), plus
+        the transposed fragments of the backward twins."""
+        sd = self._params()
+        dev = next(self.parameters()).device
+        can = {lvl: _w.canonical_blob_device(sd, lvl) for lvl in ('coarse', 'fine')}
+        if self._hot is None:
+            self._hot = HotPath(_w.pack(can['coarse']), _w.pack(can['fine']), device=dev)
+        else:
+            self._hot.wc.copy_(torch.from_numpy(_w.pack(can['coarse'])))
+            self._hot.wf.copy_(torch.from_numpy(_w.pack(can['fine'])))
+        self._hot.set_bwd_weights(_w.pack_bwd(can['coarse']), _w.pack_bwd(can['fine']))
         return self._hot
 
     @staticmethod
@@ -261,8 +297,19 @@ class NeuralRayRenderer(nn.Module):
         coords = self.gen_depth_loss_coords(h, w, ref_imgs_info['imgs'].device)
         if self._use_autograd(is_train):
             P = self._params()
-            mc = _ag.depth_mean(P, ref_imgs_info, coords, 'dist_decoder.')
-            mf = _ag.depth_mean(P, ref_imgs_info, coords, 'fine_dist_decoder.')
+            if ref_imgs_info['imgs'].is_cuda:
+                # first backward twin: HIP forward + HIP backward behind an autograd.Function (csrc/gnr_bwd.inc)
+                hot = self.hot_for_training()
+                bref = self._batched_ref({**ref_imgs_info, 'ray_feats': ref_imgs_info['ray_feats'].detach(),
+                                          'img_feats': ref_imgs_info['img_feats'].detach()})
+                prep = hot.prepare(bref, 1)
+                xy = coords.to(torch.float32)[None]
+                mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'],
+                                             *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
+                          for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
+            else:
+                mc = _ag.depth_mean(P, ref_imgs_info, coords, 'dist_decoder.')
+                mf = _ag.depth_mean(P, ref_imgs_info, coords, 'fine_dist_decoder.')
             return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
                     'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]}
         # the reference feeds (row, col) where (x, y) is expected; kept

@@ -80,3 +80,31 @@ def pack(canonical):
 
 def pack_state_dict(state_dict, level, prefix=''):
     return pack(canonical_blob(state_dict, level, prefix))
+
+
+def pack_bwd(canonical):
+    """canonical float32 [36958] -> transposed-fragment blob for the backward twins (host numpy)."""
+    L = _lib.lib()
+    canonical = np.ascontiguousarray(canonical, np.float32)
+    out = np.zeros(L.gnr_packed_bwd_floats(), np.float32)
+    _lib.check(L.gnr_pack_weights_bwd(canonical.ctypes.data_as(_lib.c_float_p), out.ctypes.data_as(_lib.c_float_p)),
+               'gnr_pack_weights_bwd')
+    return out
+
+
+def split_canonical(flat, level, prefix=''):
+    """A canonical-layout array (e.g. a gradient blob from a *_bwd entry point) -> {state-dict key: view}."""
+    out, off = {}, 0
+    for k, shape in level_keys(level, prefix):
+        n = int(np.prod(shape)) if len(shape) else 1
+        out[k] = flat[off:off + n].reshape(shape)
+        off += n
+    return out
+
+
+def canonical_blob_device(params, level, prefix=''):
+    """Same blob from live torch tensors with ONE device->host copy (the per-key path costs a sync per tensor)."""
+    import torch
+    flat = torch.cat([params[k].detach().reshape(-1).to(torch.float32) for k, _ in level_keys(level, prefix)])
+    assert flat.numel() == _lib.lib().gnr_canonical_weights_floats()
+    return flat.cpu().numpy()

@@ -151,6 +151,23 @@ int gnr_grasp_head_fwd(int B, int volume_res, const float* volume, const float* 
                        float* width, void* workspace, size_t workspace_bytes, void* stream);
 const char* gnr_head_last_error(void);
 
+/* ---- backward twins ------------------------------------------------------------------------
+ * Round 1 ships the first one: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss,
+ * renderer.py:230-266, consumed by DepthLoss, loss.py:87-144).  The remaining *_bwd entry points
+ * (sample_volume, render) are not built; training differentiates graspnerf_amd/autograd_path.py.
+ *   gnr_pack_weights_bwd: canonical blob -> transposed MFMA fragments [gnr_packed_bwd_floats()]
+ *   gnr_depth_mean_bwd:   dmean [B,V,pn,2] -> d_canonical [gnr_canonical_weights_floats()] (ACCUMULATED:
+ *                         mean_decoder.{0,2,4}.{weight,bias} entries, state-dict order) and
+ *                         d_ray_feats [B,V,32,fh,fw] (overwritten; NULL to skip).  Needs gnr_prepare's
+ *                         workspace (feature maps in channel-last form) of at least
+ *                         gnr_depth_mean_bwd_workspace_bytes(scene).                                          */
+int gnr_packed_bwd_floats(void);
+int gnr_pack_weights_bwd(const float* canonical_host, float* packed_bwd_host);
+size_t gnr_depth_mean_bwd_workspace_bytes(const GnrScene* scene);
+int gnr_depth_mean_bwd(const GnrScene* scene, const float* coords, int pn, const float* level_weights,
+                       const float* level_weights_bwd, const float* dmean, float* d_canonical, float* d_ray_feats,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- grasp post-processing on the device -------------------------------------------------
  * Replaces the reference planner's `process` + `select` (src/nr/main.py:23-57, 60-84), which run
  * scipy.ndimage (gaussian_filter sigma=1 mode='nearest'; binary_dilation iterations=2 with mask;

@@ -78,7 +78,7 @@ if rank == 0:
     dt = float(tm)
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-                      'scenes_per_gpu': a.scenes, 'backward': 'torch autograd over graspnerf_amd/autograd_path.py (interim; no HIP bwd kernels yet)',
+                      'scenes_per_gpu': a.scenes, 'backward': 'torch autograd over graspnerf_amd/autograd_path.py for render / sample_volume (interim), HIP twin pair for the depth-mean head',
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
 if dist is not None:
