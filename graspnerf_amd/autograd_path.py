@@ -103,35 +103,47 @@ def _mean_var(x, w):
     return mean, torch.sum(w * (x - mean[None]) ** 2, 0)
 
 
-def aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, rn, dn, want_grad, want_rgb):
+def _tap(taps, name, t):
+    """Test hook: keep an intermediate (and its gradient) so the backward twins can be checked stage by stage."""
+    if taps is not None:
+        if t.requires_grad:
+            t.retain_grad()
+        taps[name] = t
+    return t
+
+
+def aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, rn, dn, want_grad, want_rgb, taps=None):
     """aggregate_net.py:35-70 + ibrnet.py:447-513.  -> sdf [rn,dn], grad [rn,dn,3] | None (differentiable: taken with
     create_graph=True), rgb [rn,dn,3] | None."""
     a = agg + 'agg_impl.'
     m = mask.to(f_ray.dtype)[..., None]
     pe_in = torch.cat([f_ray, ((hit - 0.5) * 2)[..., None], ((vis - 0.5) * 2)[..., None]], -1)
-    e = _lin(F.relu(_lin(pe_in, P, agg + 'prob_embed.0')), P, agg + 'prob_embed.2')
+    e1 = _tap(taps, 'e1', F.relu(_lin(pe_in, P, agg + 'prob_embed.0')))
+    e = _tap(taps, 'e', _lin(e1, P, agg + 'prob_embed.2'))
     dd = torch.cat([dirv - qdir[None], torch.sum(dirv * qdir[None], -1, keepdim=True)], -1)
-    x = torch.cat([rgb, f_img], -1) + F.elu(_lin(F.elu(_lin(dd, P, a + 'ray_dir_fc.0')), P, a + 'ray_dir_fc.2'))
+    x = _tap(taps, 'x', torch.cat([rgb, f_img], -1) + F.elu(_lin(F.elu(_lin(dd, P, a + 'ray_dir_fc.0')), P, a + 'ray_dir_fc.2')))
     w = m / (torch.sum(m, 0, keepdim=True) + 1e-8)
-    w0 = torch.sigmoid(_lin(F.elu(_lin(e, P, a + 'neuray_fc.0')), P, a + 'neuray_fc.2')) * w
+    gate = _tap(taps, 'gate', torch.sigmoid(_lin(F.elu(_lin(e, P, a + 'neuray_fc.0')), P, a + 'neuray_fc.2')))
+    w0 = gate * w
     mean0, var0 = _mean_var(x, w0)
     mean1, var1 = _mean_var(x, w)
     W0 = P[a + 'base_fc.0.weight']
-    pre = torch.cat([mean0, var0, mean1, var1], -1) @ W0[:, :140].t() + P[a + 'base_fc.0.bias']
+    pre = _tap(taps, 'G', _tap(taps, 'SV', torch.cat([mean0, var0, mean1, var1], -1)) @ W0[:, :140].t() + P[a + 'base_fc.0.bias'])
     h = F.elu(pre[None] + x @ W0[:, 140:175].t() + e @ W0[:, 175:].t())
     h = F.elu(_lin(h, P, a + 'base_fc.2'))
     xv = F.elu(_lin(F.elu(_lin(h * w, P, a + 'vis_fc.0')), P, a + 'vis_fc.2'))
     v1 = torch.sigmoid(xv[..., 32:]) * m
-    h = h + xv[..., :32]
-    v2 = torch.sigmoid(_lin(F.elu(_lin(h * v1, P, a + 'vis_fc2.0')), P, a + 'vis_fc2.2')) * m
+    h = _tap(taps, 'h', h + xv[..., :32])
+    v2 = _tap(taps, 'v2', torch.sigmoid(_lin(F.elu(_lin(h * v1, P, a + 'vis_fc2.0')), P, a + 'vis_fc2.2')) * m)
     w2 = v2 / (torch.sum(v2, 0, keepdim=True) + 1e-8)
     mean, var = _mean_var(h, w2)
+    mean, var = _tap(taps, 'mean', mean), _tap(taps, 'var', var)
     nvalid = torch.sum(m, 0)[:, 0]
     p = pts.detach().clone().requires_grad_(want_grad)
     with torch.enable_grad():
         emb = torch.cat([p] + [fn(p * f) for f in (1.0, 2.0, 4.0) for fn in (torch.sin, torch.cos)], -1)
         z86 = torch.cat([mean, var, torch.mean(w2, 0), emb], -1)
-        g = F.elu(_lin(F.elu(_lin(z86, P, a + 'geometry_fc.0')), P, a + 'geometry_fc.2'))
+        g = _tap(taps, 'g16', F.elu(_lin(F.elu(_lin(z86, P, a + 'geometry_fc.0')), P, a + 'geometry_fc.2')))
         t = g.reshape(rn, dn, 16) + sinusoid_table(dn).to(g.device)[None]
         heads = lambda name: _lin(t, P, a + 'ray_attention.' + name).reshape(rn, dn, 4, 4).transpose(1, 2)
         q, k, v = heads('w_qs'), heads('w_ks'), heads('w_vs')
@@ -159,7 +171,7 @@ def _gather(ref, uv, mask):
             bilinear_border(ref['img_feats'], uv, h, w) * m)
 
 
-def sample_volume(P, ref, res, dec='dist_decoder.', agg='agg_net.'):
+def sample_volume(P, ref, res, dec='dist_decoder.', agg='agg_net.', taps=None):
     """renderer.py:164-199 for one scene -> [1,1,res,res,res]."""
     dev = ref['imgs'].device
     h, w = ref['imgs'].shape[-2:]
@@ -169,7 +181,9 @@ def sample_volume(P, ref, res, dec='dist_decoder.', agg='agg_net.'):
     f_ray, rgb, f_img = _gather(ref, uv, mask)
     hit, vis = decode_hit_vis(P, dec, f_ray, z, mask, ref['depth_range'], 0.005, 0.005)
     qdir = torch.tensor([0., 0., 1.], device=dev).expand(pts.shape[0], 3)
-    sdf, _, _ = aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, res * res, res, False, False)
+    if taps is not None:
+        taps.update(hit=_tap(taps, 'hit', hit), vis=_tap(taps, 'vis', vis), mask=mask)
+    sdf, _, _ = aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, res * res, res, False, False, taps)
     return torch.flip(sdf.reshape(1, 1, res, res, res), (-1,))
 
 

@@ -268,6 +268,11 @@ struct ChainArgs {
     float* dbg;            // [B*P][32] or null
     int B, P, H, W, fh, fw;
     int vol_res;           // volume launches: grid resolution R (tile order is brick-permuted); 0 for ray points
+    // training forward (backward twins): per-view state after each view loop and the hoisted pre-activation, in
+    // register order [tile][..][64 lanes]; all null in inference
+    float* save1;          // [tiles][V][19][64]  X[9], e1[8], gate, m
+    float* save2;          // [tiles][V][9][64]   h~[8], v2
+    float* saveG;          // [tiles][17][64]     G[16] (log2e-scaled pre-activation incl. bias), 1/(sum m + 1e-8)
 };
 
 struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
@@ -549,6 +554,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
                 Sv[17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
             }
             Sv[18] = m;
+            if (a.save1) {
+                float* sp = a.save1 + (((size_t)b * tps + ts) * V + v) * 19 * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 19; ++q) sp[q * 64] = Sv[q];
+            }
 #if GNR_ROW_SWITCH == 1
             row_store<0, V, SW>(S, v, Sv);
 #endif
@@ -584,6 +594,14 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
         f4 G[4];
         load_bias<4, LF>(lds + pk::B_HOIST, g, G);
         mm<36, 4, 0, LF>(lds + pk::HOIST, lane, SV, G);
+        if (a.saveG) {
+            float* sp = a.saveG + ((size_t)b * tps + ts) * 17 * 64 + lane;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                sp[(4 * nb) * 64] = G[nb].x; sp[(4 * nb + 1) * 64] = G[nb].y; sp[(4 * nb + 2) * 64] = G[nb].z; sp[(4 * nb + 3) * 64] = G[nb].w;
+            }
+            sp[16 * 64] = inv_msum;
+        }
 
         // ================= phase 2: per view, base_fc / vis_fc / vis_fc2 (/ rgb_fc)
         float vsum = 0.f;
@@ -703,6 +721,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             Sv[8] = v2;
             Sv[9] = clog;
             Sv[10] = rgbraw;
+            if (a.save2) {
+                float* sp = a.save2 + (((size_t)b * tps + ts) * V + v) * 9 * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) sp[q * 64] = Sv[q];
+            }
 #if GNR_ROW_SWITCH
             row_store<0, V, 11>(S, v, Sv);
 #endif

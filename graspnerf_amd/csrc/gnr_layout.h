@@ -137,7 +137,10 @@ constexpr int MAX_DN = 64;      // samples per ray / column handled by one wavef
 namespace pkb {
 constexpr int DM_W2T = 0;                  // mean_decoder.2^T : 32 (natural) -> 32 (natural)
 constexpr int DM_W1T = DM_W2T + 1024;      // mean_decoder.0^T : 32 (natural) -> 32 ray channels in gather layout (8g + j)
-constexpr int TOTAL = DM_W1T + 1024;
+constexpr int GEO2T = DM_W1T + 1024;                         // geometry_fc.2^T : 16 (natural, J=4) -> 64 (natural)   4 x 4
+constexpr int GEO1T_A = GEO2T + frag_floats(4, 4);           // geometry_fc.0^T : 64 (natural) -> Z slots 0..15       16 x 4
+constexpr int GEO1T_B = GEO1T_A + frag_floats(16, 4);        //                                   -> Z slots 16..19    16 x 1
+constexpr int TOTAL = GEO1T_B + frag_floats(16, 1);
 }  // namespace pkb
 
 }  // namespace gnr

@@ -97,6 +97,24 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
     pack_frag(p + pkb::DM_W2T, T.data(), 32, 8, 2, natI, natO);
     transpose32(c + can::MEAN0_W);
     pack_frag(p + pkb::DM_W1T, T.data(), 32, 8, 2, natI, gatherO);
+    auto transposed = [&](const float* W, int rows, int cols) {       // W [rows][cols] -> [cols][rows]
+        std::vector<float> t((size_t)rows * cols);
+        for (int o = 0; o < rows; ++o) for (int i = 0; i < cols; ++i) t[(size_t)i * rows + o] = W[(size_t)o * cols + i];
+        return t;
+    };
+    {   // geometry_fc.2^T [64][16], geometry_fc.0^T [86][64]; output rows in the Z-slot layout of the forward (gnr_pack_weights)
+        const std::vector<float> g2t = transposed(c + can::GEO2_W, 16, 64), g1t = transposed(c + can::GEO0_W, 64, 86);
+        pack_frag(p + pkb::GEO2T, g2t.data(), 16, 4, 4, natI, natO);
+        const auto zslot = [](int j, int g) {
+            if (j < 8) return nat_in(j, g);
+            if (j < 16) return 32 + nat_in(j - 8, g);
+            const int k = j - 16;
+            if (g == 0) return k == 0 ? 64 : -1;
+            return 65 + 3 * k + (g - 1);
+        };
+        pack_frag(p + pkb::GEO1T_A, g1t.data(), 64, 16, 4, natI, [&](int nb, int i) { return zslot(4 * nb + (i & 3), i >> 2); });
+        pack_frag(p + pkb::GEO1T_B, g1t.data(), 64, 16, 1, natI, [&](int, int i) { return zslot(16 + (i & 3), i >> 2); });
+    }
     return GNR_OK;
 }
 

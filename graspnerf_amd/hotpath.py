@@ -193,6 +193,45 @@ class HotPath:
                                              ws.data_ptr(), ws.numel(), self._stream()), 'gnr_depth_mean_bwd')
         return dcan, dray
 
+    # ---- sample_volume for training: forward with saved states + staged backward (csrc/gnr_bwd.inc) --------------
+    def sample_volume_train(self, ref, res=40, prepared=None):
+        scene, keep, ws = prepared or self.prepare(ref, res)
+        need = self.L.gnr_sample_volume_train_workspace_bytes(C.byref(scene), res)
+        if getattr(self, '_tws', None) is None or self._tws.numel() < need:
+            self._tws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        bbox_min = _f32(ref['bbox3d'], self.device)[:, 0].contiguous()
+        vol = torch.empty(scene.B, 1, res, res, res, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.gnr_sample_volume_fwd_train(C.byref(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(), vol.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), self._tws.data_ptr(), self._tws.numel(),
+                                                      self._stream()), 'gnr_sample_volume_fwd_train')
+        self._train_ctx = (scene, keep, ws, res)
+        return vol
+
+    def train_ws_section(self, name, scene, res):
+        """Float view of one section of the training workspace (tests): save1 save2 saveG dg16 dS2 dG dS1 dfeat64 dtail."""
+        names = ['save1', 'save2', 'saveG', 'dg16', 'dS2', 'dG', 'dS1', 'dfeat64', 'dtail']
+        off = (C.c_size_t * 9)()
+        _lib.check(self.L.gnr_train_workspace_layout(C.byref(scene), res, off), 'gnr_train_workspace_layout')
+        i = names.index(name)
+        end = off[i + 1] if i + 1 < 9 else self._tws.numel()
+        return self._tws[off[i]:end].view(torch.float32)
+
+    def sample_volume_bwd(self, dvol, canonical_dev, stages=0x1f, want_feat_grads=True):
+        """Backward of the last sample_volume_train: dvol [B,1,R,R,R] -> (d_canonical [36958], d_ray_feats, d_img_feats)."""
+        scene, keep, ws, res = self._train_ctx
+        dvol = _f32(dvol, self.device)
+        dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
+        shp = (scene.B, scene.V, 32, scene.fh, scene.fw)
+        dray = torch.zeros(shp, dtype=torch.float32, device=self.device) if want_feat_grads else None
+        dimg = torch.zeros(shp, dtype=torch.float32, device=self.device) if want_feat_grads else None
+        _lib.check(self.L.gnr_sample_volume_bwd(C.byref(scene), res, self.wc.data_ptr(), self.wb['coarse'].data_ptr(),
+                                                canonical_dev.data_ptr(), dvol.data_ptr(), dcan.data_ptr(),
+                                                dray.data_ptr() if want_feat_grads else None,
+                                                dimg.data_ptr() if want_feat_grads else None, ws.data_ptr(), ws.numel(),
+                                                self._tws.data_ptr(), self._tws.numel(), stages, self._stream()),
+                   'gnr_sample_volume_bwd')
+        return dcan, dray, dimg
+
     def set_bwd_weights(self, packed_bwd_coarse, packed_bwd_fine=None):
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
         self.wb = {'coarse': t(packed_bwd_coarse), 'fine': t(packed_bwd_fine)}

@@ -168,6 +168,20 @@ int gnr_depth_mean_bwd(const GnrScene* scene, const float* coords, int pn, const
                        const float* level_weights_bwd, const float* dmean, float* d_canonical, float* d_ray_feats,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* sample_volume for training: the forward that also saves the per-view states, and its backward (in progress:
+ * `stages` bit 4 = attention / LayerNorm / out_geometry_fc tail, bit 3 = geometry_fc + second cross-view reduction;
+ * the view loops follow).  d_canonical is ACCUMULATED (state-dict order).  The training workspace must survive from
+ * the forward to the backward; gnr_train_workspace_layout() exposes its sections to tests.                         */
+size_t gnr_sample_volume_train_workspace_bytes(const GnrScene* scene, int volume_res);
+int gnr_train_workspace_layout(const GnrScene* scene, int volume_res, size_t* offsets_out9);
+int gnr_sample_volume_fwd_train(const GnrScene* scene, const float* bbox_min, int volume_res, const float* level_weights,
+                                float* sdf_out, void* workspace, size_t workspace_bytes, void* train_workspace,
+                                size_t train_workspace_bytes, void* stream);
+int gnr_sample_volume_bwd(const GnrScene* scene, int volume_res, const float* level_weights, const float* level_weights_bwd,
+                          const float* canonical_weights_dev, const float* dvol, float* d_canonical, float* d_ray_feats,
+                          float* d_img_feats, void* workspace, size_t workspace_bytes, void* train_workspace,
+                          size_t train_workspace_bytes, int stages, void* stream);
+
 /* ---- grasp post-processing on the device -------------------------------------------------
  * Replaces the reference planner's `process` + `select` (src/nr/main.py:23-57, 60-84), which run
  * scipy.ndimage (gaussian_filter sigma=1 mode='nearest'; binary_dilation iterations=2 with mask;

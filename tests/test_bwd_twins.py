@@ -13,7 +13,7 @@ def test_bwd_blob_layout(weights_np):
     from graspnerf_amd import _lib
     can = weights.canonical_blob(weights_np, 'coarse')
     pb = weights.pack_bwd(can)
-    assert pb.size == _lib.lib().gnr_packed_bwd_floats() == 2048
+    assert pb.size == _lib.lib().gnr_packed_bwd_floats() >= 2048
     W2 = weights_np['dist_decoder.mean_decoder.2.weight']
     W1 = weights_np['dist_decoder.mean_decoder.0.weight']
     nat = lambda j, g: 16 * (j // 4) + 4 * g + j % 4
@@ -72,3 +72,76 @@ def test_depth_mean_bwd_matches_autograd(level, pn, weights_np):
         m0 = ag.depth_mean(P, {'imgs': torch.from_numpy(bref['imgs'][0]).cuda(), 'ray_feats': ray[0]},
                            torch.from_numpy(coords[0]).cuda(), dec).cpu().numpy()
     assert np.abs(fwd[0] - m0).max() < 1e-4
+
+
+# ---- sample_volume backward, stage by stage against autograd taps ------------------------------------------------
+def _regs_to_feats(buf, tiles, V, nregs, P):
+    """[tiles][V][nregs][64 lanes] register dump -> [V, P, nregs, 4 groups] (lane = 16*g + r, point = 16*tile + r)."""
+    a = buf[:tiles * V * nregs * 64].reshape(tiles, V, nregs, 4, 16)
+    return a.permute(1, 0, 4, 2, 3).reshape(V, tiles * 16, nregs, 4)[:, :P]
+
+
+def _nat(x8):
+    """[..., 8 regs, 4 groups] natural layout -> [..., 32] features (feature = 16*(j//4) + 4*g + j%4)."""
+    out = torch.empty(*x8.shape[:-2], 32, dtype=x8.dtype, device=x8.device)
+    for j in range(8):
+        for g in range(4):
+            out[..., 16 * (j // 4) + 4 * g + j % 4] = x8[..., j, g]
+    return out
+
+
+@pytest.fixture(scope='module')
+def vol_bwd_case(weights_np):
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    from graspnerf_amd import autograd_path as ag
+    res = 16
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    can = weights.canonical_blob(weights_np, 'coarse')
+    hp.set_bwd_weights(weights.pack_bwd(can))
+    ref, _ = make_scene(3, 'cfg1')
+    bref, _ = batch_scenes([(ref, make_scene(3, 'cfg1')[1])])
+    vol = hp.sample_volume_train(bref, res)
+    rng = np.random.default_rng(5)
+    dvol = torch.from_numpy(rng.standard_normal((1, 1, res, res, res)).astype(np.float32)).cuda()
+    # autograd reference with taps
+    P = {k: torch.from_numpy(v).cuda().requires_grad_(True) for k, v in weights_np.items()}
+    tref = {k: torch.from_numpy(v).cuda() for k, v in ref.items()}
+    tref['ray_feats'].requires_grad_(True)
+    tref['img_feats'].requires_grad_(True)
+    taps = {}
+    vol_ag = ag.sample_volume(P, tref, res, taps=taps)
+    (vol_ag * dvol).sum().backward()
+    return dict(hp=hp, can=torch.from_numpy(can).cuda(), vol=vol, vol_ag=vol_ag.detach(), dvol=dvol, P=P, taps=taps, tref=tref, res=res)
+
+
+def _close(got, ref, what, rel=3e-4):
+    got, ref = got.detach().float().cpu().numpy(), ref.detach().float().cpu().numpy()
+    scale = max(np.abs(ref).max(), 1e-8)
+    assert np.abs(got - ref).max() <= rel * scale, f'{what}: max|d| {np.abs(got - ref).max():.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.gpu
+def test_volume_bwd_tail_and_geometry(vol_bwd_case):
+    c = vol_bwd_case
+    hp, res, taps, P = c['hp'], c['res'], c['taps'], c['P']
+    _close(c['vol'], c['vol_ag'], 'training forward volume', rel=1e-4)
+    dcan, _, _ = hp.sample_volume_bwd(c['dvol'], c['can'], stages=16 | 8)
+    torch.cuda.synchronize()
+    scene = hp._train_ctx[0]
+    npts = res ** 3
+    _close(hp.train_ws_section('dg16', scene, res)[:npts * 16].reshape(npts, 16), taps['g16'].grad, 'd g16')
+    got = weights.split_canonical(dcan, 'coarse')
+    for k in ('ray_attention.w_qs.weight', 'ray_attention.w_ks.weight', 'ray_attention.w_vs.weight', 'ray_attention.fc.weight',
+              'ray_attention.layer_norm.weight', 'ray_attention.layer_norm.bias', 'out_geometry_fc.0.weight',
+              'out_geometry_fc.0.bias', 'out_geometry_fc.1.weight', 'out_geometry_fc.1.bias',
+              'geometry_fc.2.weight', 'geometry_fc.2.bias', 'geometry_fc.0.weight', 'geometry_fc.0.bias'):
+        kk = 'agg_net.agg_impl.' + k
+        _close(got[kk], P[kk].grad, kk)
+    V, tiles = scene.V, npts // 16
+    d = _regs_to_feats(hp.train_ws_section('dS2', scene, res), tiles, V, 9, npts)        # [V,P,9,4]
+    # h also feeds vis_fc2 (stage 3 adds that path): compare the direct part through the weighted mean / variance
+    with torch.no_grad():
+        w2 = taps['v2'] / (taps['v2'].sum(0, keepdim=True) + 1e-8)
+        direct = w2 * (taps['mean'].grad[None] + 2 * (taps['h'] - taps['mean'][None]) * taps['var'].grad[None])
+    _close(_nat(d[:, :, :8]), direct, 'd h_v (direct part)')
+    _close(d[:, :, 8, 0], taps['v2'].grad[..., 0], 'd v2_v')
