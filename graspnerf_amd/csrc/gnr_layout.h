@@ -140,7 +140,18 @@ constexpr int DM_W1T = DM_W2T + 1024;      // mean_decoder.0^T : 32 (natural) ->
 constexpr int GEO2T = DM_W1T + 1024;                         // geometry_fc.2^T : 16 (natural, J=4) -> 64 (natural)   4 x 4
 constexpr int GEO1T_A = GEO2T + frag_floats(4, 4);           // geometry_fc.0^T : 64 (natural) -> Z slots 0..15       16 x 4
 constexpr int GEO1T_B = GEO1T_A + frag_floats(16, 4);        //                                   -> Z slots 16..19    16 x 1
-constexpr int TOTAL = GEO1T_B + frag_floats(16, 1);
+// second view loop (k_view2_bwd), one contiguous section copied into LDS
+constexpr int V2_BEGIN = GEO1T_B + frag_floats(16, 1);
+constexpr int PE2F = V2_BEGIN;                               // prob_embed.2 forward (unfolded), natural -> natural      8 x 2
+constexpr int B_PE2 = PE2F + 1024;                           // its bias (32, bias-table layout)
+constexpr int VISB1T = B_PE2 + 32;                           // vis_fc2.0^T                                              8 x 2
+constexpr int VIS2T = VISB1T + 1024;                         // vis_fc.2[:32]^T                                          8 x 2
+constexpr int VIS1T = VIS2T + 1024;                          // vis_fc.0^T                                               8 x 2
+constexpr int BASE2T = VIS1T + 1024;                         // base_fc.2^T : 32 -> 64                                   8 x 4
+constexpr int BASE1XT = BASE2T + frag_floats(8, 4);          // base_fc.0[:,140:175]^T : 64 -> x slots                  16 x 3
+constexpr int BASE1ET = BASE1XT + frag_floats(16, 3);        // base_fc.0[:,175:207]^T : 64 -> 32                       16 x 2
+constexpr int V2_END = BASE1ET + frag_floats(16, 2);
+constexpr int TOTAL = V2_END;
 }  // namespace pkb
 
 }  // namespace gnr

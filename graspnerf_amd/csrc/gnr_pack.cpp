@@ -115,6 +115,29 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
         pack_frag(p + pkb::GEO1T_A, g1t.data(), 64, 16, 4, natI, [&](int nb, int i) { return zslot(4 * nb + (i & 3), i >> 2); });
         pack_frag(p + pkb::GEO1T_B, g1t.data(), 64, 16, 1, natI, [&](int, int i) { return zslot(16 + (i & 3), i >> 2); });
     }
+    {   // second view loop
+        pack_frag(p + pkb::PE2F, c + can::PE2_W, 32, 8, 2, natI, natO);
+        pack_bias(p + pkb::B_PE2, c + can::PE2_B, 2, natO);
+        const std::vector<float> vb1t = transposed(c + can::VISB0_W, 32, 32), v2t = transposed(c + can::VIS2_W, 32, 32),
+                                 v1t = transposed(c + can::VIS0_W, 32, 32), b2t = transposed(c + can::BASE2_W, 32, 64);
+        pack_frag(p + pkb::VISB1T, vb1t.data(), 32, 8, 2, natI, natO);
+        pack_frag(p + pkb::VIS2T, v2t.data(), 32, 8, 2, natI, natO);          // rows 0..31 of the 33 (first 32x32 block)
+        pack_frag(p + pkb::VIS1T, v1t.data(), 32, 8, 2, natI, natO);
+        pack_frag(p + pkb::BASE2T, b2t.data(), 32, 8, 4, natI, natO);
+        std::vector<float> xt(35 * 64), et(32 * 64);
+        for (int o = 0; o < 64; ++o) {
+            for (int i = 0; i < 35; ++i) xt[i * 64 + o] = c[can::BASE0_W + o * 207 + 140 + i];
+            for (int i = 0; i < 32; ++i) et[i * 64 + o] = c[can::BASE0_W + o * 207 + 175 + i];
+        }
+        const IdxFn xout = [](int nb, int i) {
+            const int g = i >> 2, r = i & 3;
+            if (nb == 0) return 3 + 8 * g + r;
+            if (nb == 1) return 3 + 8 * g + 4 + r;
+            return (r == 0 && g < 3) ? g : -1;
+        };
+        pack_frag(p + pkb::BASE1XT, xt.data(), 64, 16, 3, natI, xout);
+        pack_frag(p + pkb::BASE1ET, et.data(), 64, 16, 2, natI, natO);
+    }
     return GNR_OK;
 }
 

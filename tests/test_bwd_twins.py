@@ -145,3 +145,26 @@ def test_volume_bwd_tail_and_geometry(vol_bwd_case):
         direct = w2 * (taps['mean'].grad[None] + 2 * (taps['h'] - taps['mean'][None]) * taps['var'].grad[None])
     _close(_nat(d[:, :, :8]), direct, 'd h_v (direct part)')
     _close(d[:, :, 8, 0], taps['v2'].grad[..., 0], 'd v2_v')
+
+
+@pytest.mark.gpu
+def test_volume_bwd_second_view_loop(vol_bwd_case):
+    c = vol_bwd_case
+    hp, res, taps, P = c['hp'], c['res'], c['taps'], c['P']
+    dcan, _, _ = hp.sample_volume_bwd(c['dvol'], c['can'], stages=16 | 8 | 4)
+    torch.cuda.synchronize()
+    scene = hp._train_ctx[0]
+    npts, tiles = res ** 3, res ** 3 // 16
+    got = weights.split_canonical(dcan, 'coarse')
+    for k in ('vis_fc2.2.weight', 'vis_fc2.2.bias', 'vis_fc2.0.weight', 'vis_fc2.0.bias', 'vis_fc.2.weight', 'vis_fc.2.bias',
+              'vis_fc.0.weight', 'vis_fc.0.bias', 'base_fc.2.weight', 'base_fc.2.bias', 'base_fc.0.bias'):
+        kk = 'agg_net.agg_impl.' + k
+        _close(got[kk], P[kk].grad, kk)
+    kk = 'agg_net.agg_impl.base_fc.0.weight'
+    _close(got[kk][:, 140:], P[kk].grad[:, 140:], kk + '[:,140:]')
+    dG = _regs_to_feats(hp.train_ws_section('dG', scene, res), tiles, 1, 16, npts)[0]          # [P,16,4]
+    dGn = torch.empty(npts, 64, device=dG.device)
+    for j in range(16):
+        for g in range(4):
+            dGn[:, 16 * (j // 4) + 4 * g + j % 4] = dG[:, j, g]
+    _close(dGn, taps['G'].grad, 'd G')
