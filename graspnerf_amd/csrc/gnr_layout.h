@@ -151,7 +151,11 @@ constexpr int BASE2T = VIS1T + 1024;                         // base_fc.2^T : 32
 constexpr int BASE1XT = BASE2T + frag_floats(8, 4);          // base_fc.0[:,140:175]^T : 64 -> x slots                  16 x 3
 constexpr int BASE1ET = BASE1XT + frag_floats(16, 3);        // base_fc.0[:,175:207]^T : 64 -> 32                       16 x 2
 constexpr int V2_END = BASE1ET + frag_floats(16, 2);
-constexpr int TOTAL = V2_END;
+// hoisted base_fc.0 columns: base_fc.0[:, :140]^T, 64 (natural) -> the 36 statistic slots per lane group
+constexpr int HOISTT_A = V2_END;                             // slots  0..15   16 x 4
+constexpr int HOISTT_B = HOISTT_A + frag_floats(16, 4);      // slots 16..31   16 x 4
+constexpr int HOISTT_C = HOISTT_B + frag_floats(16, 4);      // slots 32..35   16 x 1
+constexpr int TOTAL = HOISTT_C + frag_floats(16, 1);
 }  // namespace pkb
 
 }  // namespace gnr

@@ -137,6 +137,14 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
         };
         pack_frag(p + pkb::BASE1XT, xt.data(), 64, 16, 3, natI, xout);
         pack_frag(p + pkb::BASE1ET, et.data(), 64, 16, 2, natI, natO);
+        // hoisted columns: statistic slot s (0..35) of lane group g <-> column 35*(s/9) + xfeat(s%9, g)
+        std::vector<float> ht(140 * 64);
+        for (int o = 0; o < 64; ++o)
+            for (int i = 0; i < 140; ++i) ht[i * 64 + o] = c[can::BASE0_W + o * 207 + i];
+        const auto sslot = [](int s, int g) { const int x = xfeat(s % 9, g); return x < 0 ? -1 : 35 * (s / 9) + x; };
+        pack_frag(p + pkb::HOISTT_A, ht.data(), 64, 16, 4, natI, [&](int nb, int i) { return sslot(4 * nb + (i & 3), i >> 2); });
+        pack_frag(p + pkb::HOISTT_B, ht.data(), 64, 16, 4, natI, [&](int nb, int i) { return sslot(16 + 4 * nb + (i & 3), i >> 2); });
+        pack_frag(p + pkb::HOISTT_C, ht.data(), 64, 16, 1, natI, [&](int, int i) { return sslot(32 + (i & 3), i >> 2); });
     }
     return GNR_OK;
 }

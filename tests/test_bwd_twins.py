@@ -168,3 +168,30 @@ def test_volume_bwd_second_view_loop(vol_bwd_case):
         for g in range(4):
             dGn[:, 16 * (j // 4) + 4 * g + j % 4] = dG[:, j, g]
     _close(dGn, taps['G'].grad, 'd G')
+
+
+def _xslots_to_channels(d9):
+    """[..., 9 slots, 4 groups] x-slot layout -> [..., 35] channels [r g b | img feats 32] (slot j<8: 3+8g+j; slot 8: g<3)."""
+    out = torch.zeros(*d9.shape[:-2], 35, dtype=d9.dtype, device=d9.device)
+    for g in range(4):
+        for j in range(8):
+            out[..., 3 + 8 * g + j] = d9[..., j, g]
+        if g < 3:
+            out[..., g] = d9[..., 8, g]
+    return out
+
+
+@pytest.mark.gpu
+def test_volume_bwd_hoist_and_first_reduction(vol_bwd_case):
+    c = vol_bwd_case
+    hp, res, taps, P = c['hp'], c['res'], c['taps'], c['P']
+    dcan, _, _ = hp.sample_volume_bwd(c['dvol'], c['can'], stages=16 | 8 | 4 | 2)
+    torch.cuda.synchronize()
+    scene = hp._train_ctx[0]
+    npts, tiles, V = res ** 3, res ** 3 // 16, scene.V
+    got = weights.split_canonical(dcan, 'coarse')
+    kk = 'agg_net.agg_impl.base_fc.0.weight'
+    _close(got[kk], P[kk].grad, kk)
+    d = _regs_to_feats(hp.train_ws_section('dS1', scene, res), tiles, V, 18, npts)           # [V,P,18,4]
+    _close(_xslots_to_channels(d[:, :, :9]), taps['x'].grad, 'd x_v (per-view + statistics paths)')
+    _close(d[:, :, 17, 0], taps['gate'].grad[..., 0], 'd gate_v')
