@@ -155,7 +155,19 @@ constexpr int V2_END = BASE1ET + frag_floats(16, 2);
 constexpr int HOISTT_A = V2_END;                             // slots  0..15   16 x 4
 constexpr int HOISTT_B = HOISTT_A + frag_floats(16, 4);      // slots 16..31   16 x 4
 constexpr int HOISTT_C = HOISTT_B + frag_floats(16, 4);      // slots 32..35   16 x 1
-constexpr int TOTAL = HOISTT_C + frag_floats(16, 1);
+// first view loop (k_view1_bwd), one contiguous section copied into LDS
+constexpr int V1_BEGIN = HOISTT_C + frag_floats(16, 1);
+constexpr int DEC2T = V1_BEGIN;                              // {mean,var,aw}_decoder.2^T                               3 x (8 x 2)
+constexpr int DEC1T = DEC2T + 3072;                          // {mean,var,aw}_decoder.0^T, rows in the gather layout    3 x (8 x 2)
+constexpr int V1_PE2F = DEC1T + 3072;                        // prob_embed.2 forward + bias (as PE2F / B_PE2)
+constexpr int V1_B_PE2 = V1_PE2F + 1024;
+constexpr int PE2T = V1_B_PE2 + 32;                          // prob_embed.2^T                                           8 x 2
+constexpr int PE0T = PE2T + 1024;                            // prob_embed.0[:, :32]^T, rows in the gather layout        8 x 2
+constexpr int T_PE0HV = PE0T + 1024;                         // prob_embed.0[:, 32], [:, 33] as [4][8] row tables
+constexpr int NR0T = T_PE0HV + 64;                           // neuray_fc.0^T : 8 (padded to 16) -> 32                  4 x 2
+constexpr int RDF2T = NR0T + frag_floats(4, 2);              // ray_dir_fc.2^T : 35 (x slots) -> 16                      9 x 1
+constexpr int V1_END = RDF2T + frag_floats(9, 1);
+constexpr int TOTAL = V1_END;
 }  // namespace pkb
 
 }  // namespace gnr

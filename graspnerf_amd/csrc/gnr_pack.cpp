@@ -146,6 +146,31 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
         pack_frag(p + pkb::HOISTT_B, ht.data(), 64, 16, 4, natI, [&](int nb, int i) { return sslot(16 + 4 * nb + (i & 3), i >> 2); });
         pack_frag(p + pkb::HOISTT_C, ht.data(), 64, 16, 1, natI, [&](int, int i) { return sslot(32 + (i & 3), i >> 2); });
     }
+    {   // first view loop
+        const int d0w[3] = {can::MEAN0_W, can::VAR0_W, can::AW0_W}, d2w[3] = {can::MEAN2_W, can::VAR2_W, can::AW2_W};
+        for (int br = 0; br < 3; ++br) {
+            const std::vector<float> t2 = transposed(c + d2w[br], 32, 32), t1 = transposed(c + d0w[br], 32, 32);
+            pack_frag(p + pkb::DEC2T + br * 1024, t2.data(), 32, 8, 2, natI, natO);
+            pack_frag(p + pkb::DEC1T + br * 1024, t1.data(), 32, 8, 2, natI, gatherO);
+        }
+        pack_frag(p + pkb::V1_PE2F, c + can::PE2_W, 32, 8, 2, natI, natO);
+        pack_bias(p + pkb::V1_B_PE2, c + can::PE2_B, 2, natO);
+        const std::vector<float> pe2t = transposed(c + can::PE2_W, 32, 32);
+        pack_frag(p + pkb::PE2T, pe2t.data(), 32, 8, 2, natI, natO);
+        std::vector<float> pe0t(32 * 32), hrow(32), vrow(32);
+        for (int o = 0; o < 32; ++o) {
+            for (int i = 0; i < 32; ++i) pe0t[i * 32 + o] = c[can::PE0_W + o * 34 + i];
+            hrow[o] = c[can::PE0_W + o * 34 + 32];
+            vrow[o] = c[can::PE0_W + o * 34 + 33];
+        }
+        pack_frag(p + pkb::PE0T, pe0t.data(), 32, 8, 2, natI, gatherO);
+        pack_row(p + pkb::T_PE0HV, hrow.data(), 8);
+        pack_row(p + pkb::T_PE0HV + 32, vrow.data(), 8);
+        const std::vector<float> nr0t = transposed(c + can::NR0_W, 8, 32);            // [32][8]
+        pack_frag(p + pkb::NR0T, nr0t.data(), 8, 4, 2, [](int j, int g) { const int f = 4 * g + j; return f < 8 ? f : -1; }, natO);
+        const std::vector<float> r2t = transposed(c + can::RDF2_W, 35, 16);           // [16][35]
+        pack_frag(p + pkb::RDF2T, r2t.data(), 35, 9, 1, [](int j, int g) { return xfeat(j, g); }, natO);
+    }
     return GNR_OK;
 }
 

@@ -195,3 +195,24 @@ def test_volume_bwd_hoist_and_first_reduction(vol_bwd_case):
     d = _regs_to_feats(hp.train_ws_section('dS1', scene, res), tiles, V, 18, npts)           # [V,P,18,4]
     _close(_xslots_to_channels(d[:, :, :9]), taps['x'].grad, 'd x_v (per-view + statistics paths)')
     _close(d[:, :, 17, 0], taps['gate'].grad[..., 0], 'd gate_v')
+
+
+@pytest.mark.gpu
+def test_volume_bwd_complete(vol_bwd_case):
+    """All five stages: every coarse-level parameter gradient and both feature-map gradients of sample_volume."""
+    c = vol_bwd_case
+    hp, P, tref = c['hp'], c['P'], c['tref']
+    dcan, dray, dimg = hp.sample_volume_bwd(c['dvol'], c['can'])
+    torch.cuda.synchronize()
+    got = weights.split_canonical(dcan, 'coarse')
+    checked = 0
+    for k, gv in got.items():
+        ref = P[k].grad
+        if ref is None:                                  # not on the volume path (rgb_fc, variance)
+            assert float(gv.abs().max()) == 0.0, k
+            continue
+        _close(gv, ref, k, rel=5e-4)
+        checked += 1
+    assert checked >= 50
+    _close(dray[0], tref['ray_feats'].grad, 'd ray_feats', rel=5e-4)
+    _close(dimg[0], tref['img_feats'].grad, 'd img_feats', rel=5e-4)
