@@ -102,7 +102,7 @@ def lib():
     L.gnr_depth_mean_bwd_workspace_bytes.argtypes = [C.POINTER(GnrScene)]
     L.gnr_depth_mean_bwd_workspace_bytes.restype = C.c_size_t
     L.gnr_depth_mean_bwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int] + [C.c_void_p] * 5 + \
-                                    [C.c_void_p, C.c_size_t, C.c_void_p]
+                                    [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_depth_mean_bwd.restype = C.c_int
     L.gnr_sample_volume_train_workspace_bytes.argtypes = [C.POINTER(GnrScene), C.c_int]
     L.gnr_sample_volume_train_workspace_bytes.restype = C.c_size_t

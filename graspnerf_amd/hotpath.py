@@ -178,9 +178,8 @@ class HotPath:
             raise _lib.GnrError('depth_mean_bwd: call set_bwd_weights() first')
         scene, keep, ws = prepared or self.prepare(ref, 1)
         need = self.L.gnr_depth_mean_bwd_workspace_bytes(C.byref(scene))
-        if ws.numel() < need:                      # keep region A (prepared feature maps): grow and re-prepare
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            scene, keep, ws = self.prepare(ref, 1)
+        if getattr(self, '_dm_scratch', None) is None or self._dm_scratch.numel() < need:
+            self._dm_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         coords = _f32(coords, self.device)
         dmean = _f32(dmean, self.device)
         B, pn, _ = coords.shape
@@ -190,7 +189,8 @@ class HotPath:
         w = self.wc if level == 'coarse' else self.wf
         _lib.check(self.L.gnr_depth_mean_bwd(C.byref(scene), coords.data_ptr(), pn, w.data_ptr(), self.wb[level].data_ptr(),
                                              dmean.data_ptr(), dcan.data_ptr(), dray.data_ptr() if want_feat_grad else None,
-                                             ws.data_ptr(), ws.numel(), self._stream()), 'gnr_depth_mean_bwd')
+                                             ws.data_ptr(), ws.numel(), self._dm_scratch.data_ptr(), self._dm_scratch.numel(),
+                                             self._stream()), 'gnr_depth_mean_bwd')
         return dcan, dray
 
     # ---- sample_volume for training: forward with saved states + staged backward (csrc/gnr_bwd.inc) --------------

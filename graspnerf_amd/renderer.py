@@ -114,6 +114,24 @@ class _DepthMeanFn(torch.autograd.Function):
         return (None, None, None, None, None, dray[0]) + tuple(g[dec + 'mean_decoder.' + n] for n in _DM_PARAMS)
 
 
+class _SampleVolumeFn(torch.autograd.Function):
+    """sample_volume of one scene on the HIP path in both directions (gnr_sample_volume_fwd_train / gnr_sample_volume_bwd,
+    csrc/gnr_bwd.inc).  Differentiable inputs: ray_feats, img_feats [V,32,fh,fw] and every coarse-level parameter in
+    state-dict order; the workspaces of `hot` must stay untouched between forward and backward."""
+
+    @staticmethod
+    def forward(ctx, hot, bref, prep, res, ray_feats, img_feats, *params):
+        ctx.hot = hot
+        return hot.sample_volume_train(bref, res, prepared=prep)
+
+    @staticmethod
+    def backward(ctx, dvol):
+        hot = ctx.hot
+        dcan, dray, dimg = hot.sample_volume_bwd(dvol.contiguous(), hot.can_dev['coarse'])
+        g = _w.split_canonical(dcan, 'coarse')
+        return (None, None, None, None, dray[0], dimg[0]) + tuple(g[k] for k, _ in _w.level_keys('coarse'))
+
+
 class NeuralRayRenderer(nn.Module):
     base_cfg = {
         'vis_encoder_type': 'default', 'vis_encoder_cfg': {}, 'dist_decoder_type': 'mixture_logistics',
@@ -168,14 +186,25 @@ class NeuralRayRenderer(nn.Module):
         the transposed fragments of the backward twins."""
         sd = self._params()
         dev = next(self.parameters()).device
-        can = {lvl: _w.canonical_blob_device(sd, lvl) for lvl in ('coarse', 'fine')}
+        can_dev = {lvl: _w.canonical_blob_device(sd, lvl, as_tensor=True) for lvl in ('coarse', 'fine')}
+        can = {lvl: t.cpu().numpy() for lvl, t in can_dev.items()}
         if self._hot is None:
             self._hot = HotPath(_w.pack(can['coarse']), _w.pack(can['fine']), device=dev)
         else:
             self._hot.wc.copy_(torch.from_numpy(_w.pack(can['coarse'])))
             self._hot.wf.copy_(torch.from_numpy(_w.pack(can['fine'])))
         self._hot.set_bwd_weights(_w.pack_bwd(can['coarse']), _w.pack_bwd(can['fine']))
+        self._hot.can_dev = can_dev
         return self._hot
+
+    def _train_prep(self, ref_imgs_info):
+        """Once per training forward on the GPU: re-packed weights and the prepared (channel-last) feature maps shared
+        by the HIP twin pairs of this forward."""
+        hot = self.hot_for_training()
+        bref = self._batched_ref({**ref_imgs_info, 'ray_feats': ref_imgs_info['ray_feats'].detach(),
+                                  'img_feats': ref_imgs_info['img_feats'].detach()})
+        prep = hot.prepare(bref, self.cfg.get('volume_resolution', 40))
+        return hot, bref, prep
 
     @staticmethod
     def _batched_ref(ref):
@@ -241,6 +270,11 @@ class NeuralRayRenderer(nn.Module):
     # ---- the reference's methods ------------------------------------------------------------------
     def sample_volume(self, ref_imgs_info, _prep=None, is_train=False):     # renderer.py:164-199
         if self._use_autograd(is_train):
+            if ref_imgs_info['imgs'].is_cuda and self.cfg.get('hip_volume_backward', True):
+                hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
+                P = self._params()
+                return _SampleVolumeFn.apply(hot, bref, prep, self.cfg['volume_resolution'], ref_imgs_info['ray_feats'],
+                                             ref_imgs_info['img_feats'], *[P[k] for k, _ in _w.level_keys('coarse')])
             return _ag.sample_volume(self._params(), ref_imgs_info, self.cfg['volume_resolution'])
         bref, prep = _prep or self._prepare(ref_imgs_info)
         return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
@@ -298,11 +332,8 @@ class NeuralRayRenderer(nn.Module):
         if self._use_autograd(is_train):
             P = self._params()
             if ref_imgs_info['imgs'].is_cuda:
-                # first backward twin: HIP forward + HIP backward behind an autograd.Function (csrc/gnr_bwd.inc)
-                hot = self.hot_for_training()
-                bref = self._batched_ref({**ref_imgs_info, 'ray_feats': ref_imgs_info['ray_feats'].detach(),
-                                          'img_feats': ref_imgs_info['img_feats'].detach()})
-                prep = hot.prepare(bref, 1)
+                # HIP forward + HIP backward behind an autograd.Function (csrc/gnr_bwd.inc)
+                hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
                 xy = coords.to(torch.float32)[None]
                 mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'],
                                              *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
@@ -329,8 +360,10 @@ class NeuralRayRenderer(nn.Module):
         ref['ray_feats'] = self.init_net(ref, data.get('src_imgs_info'), is_train)
         ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
         out = {}
-        prep = None if self._use_autograd(is_train) else \
-            self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
+        if self._use_autograd(is_train):
+            prep = self._train_prep(ref) if ref['imgs'].is_cuda else None
+        else:
+            prep = self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
         if self.cfg['render_rgb']:
             out = self.render(que, ref, is_train, _prep=prep)
         if self.cfg.get('sample_volume', False):

@@ -102,9 +102,10 @@ def split_canonical(flat, level, prefix=''):
     return out
 
 
-def canonical_blob_device(params, level, prefix=''):
-    """Same blob from live torch tensors with ONE device->host copy (the per-key path costs a sync per tensor)."""
+def canonical_blob_device(params, level, prefix='', as_tensor=False):
+    """Same blob from live torch tensors with ONE device->host copy (the per-key path costs a sync per tensor);
+    as_tensor=True returns the flat device tensor instead (the backward twins read the canonical weights on the device)."""
     import torch
     flat = torch.cat([params[k].detach().reshape(-1).to(torch.float32) for k, _ in level_keys(level, prefix)])
     assert flat.numel() == _lib.lib().gnr_canonical_weights_floats()
-    return flat.cpu().numpy()
+    return flat if as_tensor else flat.cpu().numpy()

@@ -159,14 +159,14 @@ const char* gnr_head_last_error(void);
  *   gnr_depth_mean_bwd:   dmean [B,V,pn,2] -> d_canonical [gnr_canonical_weights_floats()] (ACCUMULATED:
  *                         mean_decoder.{0,2,4}.{weight,bias} entries, state-dict order) and
  *                         d_ray_feats [B,V,32,fh,fw] (overwritten; NULL to skip).  Needs gnr_prepare's
- *                         workspace (feature maps in channel-last form) of at least
- *                         gnr_depth_mean_bwd_workspace_bytes(scene).                                          */
+ *                         workspace (feature maps in channel-last form) and a separate scratch buffer of
+ *                         gnr_depth_mean_bwd_workspace_bytes(scene) for the channel-last gradient.           */
 int gnr_packed_bwd_floats(void);
 int gnr_pack_weights_bwd(const float* canonical_host, float* packed_bwd_host);
 size_t gnr_depth_mean_bwd_workspace_bytes(const GnrScene* scene);
 int gnr_depth_mean_bwd(const GnrScene* scene, const float* coords, int pn, const float* level_weights,
                        const float* level_weights_bwd, const float* dmean, float* d_canonical, float* d_ray_feats,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
 
 /* sample_volume for training: the forward that also saves the per-view states, and its backward (in progress:
  * `stages` bit 4 = attention / LayerNorm / out_geometry_fc tail, bit 3 = geometry_fc + second cross-view reduction;
