@@ -1,8 +1,7 @@
 """End-to-end train step (BASELINE.json configs[4]): backbones + volumetric path + grasp head + losses, backward, one flat
 gradient all-reduce over RCCL, Adam.  `--scenes` scenes per GPU per step (default 8), full-size scenes (6 views 288x512,
-40^3 volume, 512 rays x (40+40) samples).  The backward of the volumetric path is PyTorch autograd over
-graspnerf_amd/autograd_path.py in this round (HIP `*_bwd` kernels are not built), so this measures the interim
-training path, not the HIP kernels.
+40^3 volume, 512 rays x (40+40) samples).  sample_volume and the depth-mean head run in HIP in both directions; the
+render path is differentiated by PyTorch autograd over graspnerf_amd/autograd_path.py.
     python tools/train_step_bench.py [--scenes 8] [--steps 3] [--warmup 1]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py ..."""
 import argparse, json, os, sys, time
@@ -78,7 +77,7 @@ if rank == 0:
     dt = float(tm)
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-                      'scenes_per_gpu': a.scenes, 'backward': 'torch autograd over graspnerf_amd/autograd_path.py for render / sample_volume (interim), HIP twin pair for the depth-mean head',
+                      'scenes_per_gpu': a.scenes, 'backward': 'HIP kernels for sample_volume and the depth-mean head (csrc/gnr_bwd.inc); torch autograd over graspnerf_amd/autograd_path.py for the render path',
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
 if dist is not None:
