@@ -141,10 +141,24 @@ def aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, rn, dn
     mean, var = _mean_var(h, w2)
     mean, var = _tap(taps, 'mean', mean), _tap(taps, 'var', var)
     nvalid = torch.sum(m, 0)[:, 0]
+    col = None
+    if want_rgb:
+        c = F.elu(_lin(torch.cat([h, v2, dd], -1), P, a + 'rgb_fc.0'))
+        c = _lin(F.elu(_lin(c, P, a + 'rgb_fc.2')), P, a + 'rgb_fc.4').masked_fill(m == 0, -1e9)
+        col = torch.sum(rgb * torch.softmax(c, 0), 0).reshape(rn, dn, 3)
+    sdf, grad = sdf_tail(P, agg, mean, var, torch.mean(w2, 0), nvalid, pts, rn, dn, want_grad, taps)
+    return sdf, grad, col
+
+
+def sdf_tail(P, agg, mean, var, wbar, nvalid, pts, rn, dn, want_grad, taps=None):
+    """The per-ray tail (ibrnet.py:485-504): geometry_fc on [mean, var, wbar, embed(p)], positional encoding, 40-token
+    self-attention, LayerNorm, out_geometry_fc, clip; with want_grad the in-forward gradient of sdf w.r.t. the points
+    (create_graph=True).  mean/var [N,32], wbar [N,1], nvalid [N] -> sdf [rn,dn], grad [rn,dn,3] | None."""
+    a = agg + 'agg_impl.'
     p = pts.detach().clone().requires_grad_(want_grad)
     with torch.enable_grad():
         emb = torch.cat([p] + [fn(p * f) for f in (1.0, 2.0, 4.0) for fn in (torch.sin, torch.cos)], -1)
-        z86 = torch.cat([mean, var, torch.mean(w2, 0), emb], -1)
+        z86 = torch.cat([mean, var, wbar, emb], -1)
         g = _tap(taps, 'g16', F.elu(_lin(F.elu(_lin(z86, P, a + 'geometry_fc.0')), P, a + 'geometry_fc.2')))
         t = g.reshape(rn, dn, 16) + sinusoid_table(dn).to(g.device)[None]
         heads = lambda name: _lin(t, P, a + 'ray_attention.' + name).reshape(rn, dn, 4, 4).transpose(1, 2)
@@ -158,12 +172,7 @@ def aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, rn, dn
         grad = None
         if want_grad:
             grad = torch.autograd.grad(sdf, p, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0].reshape(rn, dn, 3)
-    col = None
-    if want_rgb:
-        c = F.elu(_lin(torch.cat([h, v2, dd], -1), P, a + 'rgb_fc.0'))
-        c = _lin(F.elu(_lin(c, P, a + 'rgb_fc.2')), P, a + 'rgb_fc.4').masked_fill(m == 0, -1e9)
-        col = torch.sum(rgb * torch.softmax(c, 0), 0).reshape(rn, dn, 3)
-    return sdf, grad, col
+    return sdf, grad
 
 
 def _gather(ref, uv, mask):
@@ -189,16 +198,53 @@ def sample_volume(P, ref, res, dec='dist_decoder.', agg='agg_net.', taps=None):
     return torch.flip(sdf.reshape(1, 1, res, res, res), (-1,))
 
 
-def render_by_depth(P, ref, que, depth, dec, agg, cfg):
-    """renderer.py:90-138 for one scene; depth [rn,dn].  que: coords [rn,2], pose [3,4], K [3,3], depth_range [2]."""
-    rn, dn = depth.shape
-    h, w = ref['imgs'].shape[-2:]
+def ray_points(que, depth):
+    """render_ops.py:4-39: que coords [rn,2], pose [3,4], K [3,3]; depth [rn,dn] -> pts [rn*dn,3], qdir [rn,3]."""
+    rn = depth.shape[0]
     rot = que['pose'][:, :3].t()
     trans = -rot @ que['pose'][:, 3:]
     cam = torch.inverse(que['K']) @ torch.cat([que['coords'], que['coords'].new_ones(rn, 1)], 1).t()
     d = (rot @ cam + trans - trans).t()
     pts = (trans.t()[:, None] + d[:, None] * depth[..., None]).reshape(-1, 3)
-    qdir = -d / torch.linalg.norm(d, dim=1, keepdim=True)
+    return pts, -d / torch.linalg.norm(d, dim=1, keepdim=True)
+
+
+def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
+    """NeuS alpha (aggregate_net.py:105-121), exclusive-cumprod compositing (render_ops.py:72-80) and the output dict of
+    one render pass (renderer.py:110-138).  nvalid [rn,dn] = number of views that see each sample."""
+    h, w = ref_hw
+    variance = P[agg + 'deviation_network.variance']
+    inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
+    dists = torch.cat([depth[:, 1:] - depth[:, :-1], torch.full_like(depth[:, :1], 1e6)], -1)
+    iter_cos = -F.relu(-torch.sum(-qdir[:, None] * grad, -1))
+    pc = torch.sigmoid((sdf - iter_cos * dists * 0.5) * inv_s)
+    nc = torch.sigmoid((sdf + iter_cos * dists * 0.5) * inv_s)
+    alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)
+    hp = alpha * T[:, :-1]
+    out = {'sdf_values': sdf[None], 'alpha_values': alpha[None], 'colors_nr': col[None], 'hit_prob_nr': hp[None],
+           'pixel_colors_nr': torch.sum(hp[..., None] * col, 1)[None],
+           'sdf_gradient_error': torch.mean((torch.linalg.norm(grad, dim=-1) - 1.0) ** 2).reshape(1, 1),
+           's': variance.reshape(1, 1), 'render_depth': torch.sum(hp * depth, -1)[None],
+           'ray_mask': (torch.sum((nvalid > cfg['ray_mask_view_num']).int(), 1) > cfg['ray_mask_point_num'])[None]}
+    if 'imgs' in que:                                                     # renderer.py:125-127
+        gt = F.grid_sample(que['imgs'], (que['coords'] / torch.tensor([w - 1, h - 1], dtype=depth.dtype, device=depth.device)
+                                         * 2 - 1)[None, None], mode='bilinear', padding_mode='zeros', align_corners=True)
+        out['pixel_colors_gt'] = gt[0, :, 0].t()[None]
+    return out
+
+
+def render_by_depth(P, ref, que, depth, dec, agg, cfg, chain=None):
+    """renderer.py:90-138 for one scene; depth [rn,dn].  que: coords [rn,2], pose [3,4], K [3,3], depth_range [2].
+    `chain(depth) -> (stats [rn*dn,66], colours [rn*dn,3])` replaces the per-view part (everything up to the cross-view
+    statistics and the colour blend) with the HIP twin pair; the per-ray tail stays here."""
+    rn, dn = depth.shape
+    h, w = ref['imgs'].shape[-2:]
+    pts, qdir = ray_points(que, depth)
+    if chain is not None:
+        stats, col = chain(depth)
+        sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], stats[:, 65].detach(), pts, rn, dn, True)
+        return composite(P, agg, sdf, grad, col.reshape(rn, dn, 3), stats[:, 65].detach().reshape(rn, dn), qdir, depth, que, (h, w), cfg)
     uv, z, mask, dirv = project(pts, ref['poses'], ref['Ks'], h, w)
     f_ray, rgb, f_img = _gather(ref, uv, mask)
     near, far = -1 / que['depth_range'][0], -1 / que['depth_range'][1]
@@ -208,26 +254,8 @@ def render_by_depth(P, ref, que, depth, dec, agg, cfg):
     hit, vis = decode_hit_vis(P, dec, f_ray, z, mask, ref['depth_range'], ext[:, :-1].reshape(-1), ext[:, 1:].reshape(-1))
     qd = qdir[:, None].expand(rn, dn, 3).reshape(-1, 3)
     sdf, grad, col = aggregate(P, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qd, pts, rn, dn, True, True)
-    variance = P[agg + 'deviation_network.variance']
-    inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)                    # aggregate_net.py:105-121
-    dists = torch.cat([depth[:, 1:] - depth[:, :-1], torch.full_like(depth[:, :1], 1e6)], -1)
-    iter_cos = -F.relu(-torch.sum(-qdir[:, None] * grad, -1))
-    pc = torch.sigmoid((sdf - iter_cos * dists * 0.5) * inv_s)
-    nc = torch.sigmoid((sdf + iter_cos * dists * 0.5) * inv_s)
-    alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
-    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)
-    hp = alpha * T[:, :-1]                                                # render_ops.py:72-80
     nv = torch.sum(mask.reshape(-1, rn, dn).int(), 0)
-    out = {'sdf_values': sdf[None], 'alpha_values': alpha[None], 'colors_nr': col[None], 'hit_prob_nr': hp[None],
-           'pixel_colors_nr': torch.sum(hp[..., None] * col, 1)[None],
-           'sdf_gradient_error': torch.mean((torch.linalg.norm(grad, dim=-1) - 1.0) ** 2).reshape(1, 1),
-           's': variance.reshape(1, 1), 'render_depth': torch.sum(hp * depth, -1)[None],
-           'ray_mask': (torch.sum((nv > cfg['ray_mask_view_num']).int(), 1) > cfg['ray_mask_point_num'])[None]}
-    if 'imgs' in que:                                                     # renderer.py:125-127
-        gt = F.grid_sample(que['imgs'], (que['coords'] / torch.tensor([w - 1, h - 1], dtype=depth.dtype, device=depth.device)
-                                         * 2 - 1)[None, None], mode='bilinear', padding_mode='zeros', align_corners=True)
-        out['pixel_colors_gt'] = gt[0, :, 0].t()[None]
-    return out
+    return composite(P, agg, sdf, grad, col, nv, qdir, depth, que, (h, w), cfg)
 
 
 def sample_fine_depth(depth, hit_prob, depth_range, fdn, u):
@@ -249,8 +277,9 @@ def sample_fine_depth(depth, hit_prob, depth_range, fdn, u):
     return -1 / (fd * (far - near) + near)
 
 
-def render(P, ref, que, cfg, fine_u=None):
-    """renderer.py:140-162 for one chunk of rays of one scene -> dict with '' and '_fine' keys."""
+def render(P, ref, que, cfg, fine_u=None, chains=None):
+    """renderer.py:140-162 for one chunk of rays of one scene -> dict with '' and '_fine' keys.
+    chains = (coarse, fine) callables for the HIP per-view chain (see render_by_depth)."""
     dev = ref['imgs'].device
     rn, dn, fdn = que['coords'].shape[0], cfg['depth_sample_num'], cfg['fine_depth_sample_num']
     near, far = que['depth_range'][0], que['depth_range'][1]
@@ -258,11 +287,12 @@ def render(P, ref, que, cfg, fine_u=None):
     ticks = torch.cat([torch.zeros(1, device=dev), diff / (dn - 1) * torch.arange(1, dn - 1, dtype=torch.float32, device=dev),
                        diff.reshape(1)])
     depth = (1 / (1 / near + ticks))[None].expand(rn, dn).contiguous()    # render_ops.py:146-170
-    out = render_by_depth(P, ref, que, depth, 'dist_decoder.', 'agg_net.', cfg)
+    out = render_by_depth(P, ref, que, depth, 'dist_decoder.', 'agg_net.', cfg, chains[0] if chains else None)
     if fine_u is None:
         fine_u = ((0.5 + torch.arange(fdn, dtype=torch.float32, device=dev)) / fdn)[None].expand(rn, fdn)
     fd = sample_fine_depth(depth, out['hit_prob_nr'][0].detach(), que['depth_range'], fdn, fine_u.to(dev))
-    fine = render_by_depth(P, ref, que, torch.sort(fd, -1)[0], 'fine_dist_decoder.', 'fine_agg_net.', cfg)
+    fine = render_by_depth(P, ref, que, torch.sort(fd, -1)[0], 'fine_dist_decoder.', 'fine_agg_net.', cfg,
+                           chains[1] if chains else None)
     out.update({k + '_fine': v for k, v in fine.items()})
     return out
 

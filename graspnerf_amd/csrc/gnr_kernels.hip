@@ -271,8 +271,9 @@ struct ChainArgs {
     // training forward (backward twins): per-view state after each view loop and the hoisted pre-activation, in
     // register order [tile][..][64 lanes]; all null in inference
     float* save1;          // [tiles][V][19][64]  X[9], e1[8], gate, m
-    float* save2;          // [tiles][V][9][64]   h~[8], v2
+    float* save2;          // [tiles][V][9 | 11][64]   h~[8], v2 (, colour logit, raw rgb: RENDER)
     float* saveG;          // [tiles][17][64]     G[16] (log2e-scaled pre-activation incl. bias), 1/(sum m + 1e-8)
+    float* saveZ;          // [tiles][18][64]     mean~[8], var~[8] (log2e / log2e^2 scaled), wbar, number of valid views
 };
 
 struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
@@ -722,9 +723,10 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             Sv[9] = clog;
             Sv[10] = rgbraw;
             if (a.save2) {
-                float* sp = a.save2 + (((size_t)b * tps + ts) * V + v) * 9 * 64 + lane;
+                constexpr int S2W = RENDER ? 11 : 9;
+                float* sp = a.save2 + (((size_t)b * tps + ts) * V + v) * S2W * 64 + lane;
 #pragma unroll
-                for (int q = 0; q < 9; ++q) sp[q * 64] = Sv[q];
+                for (int q = 0; q < S2W; ++q) sp[q * 64] = Sv[q];
             }
 #if GNR_ROW_SWITCH
             row_store<0, V, 11>(S, v, Sv);
@@ -759,6 +761,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
 #pragma unroll
             for (int v = 0; v < V; ++v) { const float e = __expf(S[v][9] - cmax); den += e; num += S[v][10] * e; }
             if (g < 3 && row_ok) a.colors[pt * 3 + g] = num * rcp1(den);
+        }
+        if (a.saveZ) {
+            float* sp = a.saveZ + ((size_t)b * tps + ts) * 18 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sp[q * 64] = Z[q];
+            sp[16 * 64] = wbar; sp[17 * 64] = msum;
         }
         // ================= geometry_fc on [mean, var, wbar, embed(p)]  (ibrnet.py:487-489)
         {

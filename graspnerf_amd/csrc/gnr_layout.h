@@ -167,7 +167,11 @@ constexpr int T_PE0HV = PE0T + 1024;                         // prob_embed.0[:, 
 constexpr int NR0T = T_PE0HV + 64;                           // neuray_fc.0^T : 8 (padded to 16) -> 32                  4 x 2
 constexpr int RDF2T = NR0T + frag_floats(4, 2);              // ray_dir_fc.2^T : 35 (x slots) -> 16                      9 x 1
 constexpr int V1_END = RDF2T + frag_floats(9, 1);
-constexpr int TOTAL = V1_END;
+// colour head rgb_fc (render path), one contiguous section
+constexpr int RGB2T = V1_END;                                // rgb_fc.2^T : 8 (padded to 16) -> 16                      4 x 1
+constexpr int RGB0HT = RGB2T + frag_floats(4, 1);            // rgb_fc.0[:, :32]^T : 16 -> 32                            4 x 2
+constexpr int T_RGB0V = RGB0HT + frag_floats(4, 2);          // rgb_fc.0[:, 32] as a [4][4] row table
+constexpr int TOTAL = T_RGB0V + 16;
 }  // namespace pkb
 
 }  // namespace gnr

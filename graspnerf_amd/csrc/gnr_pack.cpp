@@ -171,6 +171,16 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
         const std::vector<float> r2t = transposed(c + can::RDF2_W, 35, 16);           // [16][35]
         pack_frag(p + pkb::RDF2T, r2t.data(), 35, 9, 1, [](int j, int g) { return xfeat(j, g); }, natO);
     }
+    {   // colour head
+        const std::vector<float> c2t = transposed(c + can::RGB2_W, 8, 16);            // [16][8]
+        pack_frag(p + pkb::RGB2T, c2t.data(), 8, 4, 1, [](int j, int g) { const int f = 4 * g + j; return f < 8 ? f : -1; }, natO);
+        std::vector<float> c0ht(32 * 16);
+        for (int o = 0; o < 16; ++o)
+            for (int i = 0; i < 32; ++i) c0ht[i * 16 + o] = c[can::RGB0_W + o * 37 + i];
+        pack_frag(p + pkb::RGB0HT, c0ht.data(), 16, 4, 2, natI, natO);
+        for (int g = 0; g < 4; ++g)
+            for (int r = 0; r < 4; ++r) p[pkb::T_RGB0V + g * 4 + r] = c[can::RGB0_W + (4 * g + r) * 37 + 32];
+    }
     return GNR_OK;
 }
 

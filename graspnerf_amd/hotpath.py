@@ -232,6 +232,42 @@ class HotPath:
                    'gnr_sample_volume_bwd')
         return dcan, dray, dimg
 
+    # ---- render path for training: the per-view chain of one pass in both directions (csrc/gnr_bwd.inc) ---------
+    def render_chain_train(self, que, depth, level, cfg, prepared):
+        """que: batched ray dict (coords [B,rn,2], pose, K, depth_range), depth [B,rn,dn] -> (stats [B,rn*dn,66],
+        colours [B,rn*dn,3], ctx for render_chain_bwd).  The training workspace of the pass travels in ctx."""
+        scene, keep, ws = prepared
+        depth = _f32(depth, self.device)
+        B, rn, dn = depth.shape
+        rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
+        need = self.L.gnr_workspace_bytes(C.byref(scene), 1, rn, dn)
+        if ws.numel() < need:
+            raise _lib.GnrError('render_chain_train: prepare() the workspace for the ray count first')
+        tws = torch.empty(self.L.gnr_render_chain_train_workspace_bytes(C.byref(scene), rn, dn), dtype=torch.uint8, device=self.device)
+        stats = torch.empty(B, rn * dn, 66, dtype=torch.float32, device=self.device)
+        colors = torch.empty(B, rn * dn, 3, dtype=torch.float32, device=self.device)
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_render_chain_fwd_train(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
+                                                     stats.data_ptr(), colors.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_chain_fwd_train')
+        return stats, colors, (scene, keep, ws, tws, rn, dn, level)
+
+    def render_chain_bwd(self, ctx, dstats, dcolors):
+        """-> (d_canonical [36958] of the pass's level, d_ray_feats, d_img_feats [B,V,32,fh,fw])."""
+        scene, keep, ws, tws, rn, dn, level = ctx
+        dstats = _f32(dstats, self.device)
+        dcolors = _f32(dcolors, self.device)
+        assert dstats.shape[-1] == 65 and dcolors.shape[-1] == 3
+        dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
+        shp = (scene.B, scene.V, 32, scene.fh, scene.fw)
+        dray = torch.empty(shp, dtype=torch.float32, device=self.device)
+        dimg = torch.empty(shp, dtype=torch.float32, device=self.device)
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_render_chain_bwd(C.byref(scene), rn, dn, w.data_ptr(), self.wb[level].data_ptr(), dstats.data_ptr(),
+                                               dcolors.data_ptr(), dcan.data_ptr(), dray.data_ptr(), dimg.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_chain_bwd')
+        return dcan, dray, dimg
+
     def set_bwd_weights(self, packed_bwd_coarse, packed_bwd_fine=None):
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
         self.wb = {'coarse': t(packed_bwd_coarse), 'fine': t(packed_bwd_fine)}

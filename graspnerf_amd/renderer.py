@@ -132,6 +132,25 @@ class _SampleVolumeFn(torch.autograd.Function):
         return (None, None, None, None, dray[0], dimg[0]) + tuple(g[k] for k, _ in _w.level_keys('coarse'))
 
 
+class _RenderChainFn(torch.autograd.Function):
+    """The per-view chain of one render pass of one scene on the HIP path in both directions
+    (gnr_render_chain_fwd_train / gnr_render_chain_bwd): everything up to the cross-view statistics and the colour blend.
+    Differentiable inputs: ray_feats, img_feats and every parameter of the pass's level in state-dict order; outputs
+    stats [P,66] (mean, var, wbar, n_valid) and colours [P,3]."""
+
+    @staticmethod
+    def forward(ctx, hot, prep, que, depth, level, cfg, ray_feats, img_feats, *params):
+        stats, colors, hctx = hot.render_chain_train(que, depth[None], level, cfg, prep)
+        ctx.hot, ctx.hctx, ctx.level = hot, hctx, level
+        return stats[0], colors[0]
+
+    @staticmethod
+    def backward(ctx, dstats, dcolors):
+        dcan, dray, dimg = ctx.hot.render_chain_bwd(ctx.hctx, dstats[None, :, :65].contiguous(), dcolors[None].contiguous())
+        g = _w.split_canonical(dcan, ctx.level)
+        return (None, None, None, None, None, None, dray[0], dimg[0]) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
+
+
 class NeuralRayRenderer(nn.Module):
     base_cfg = {
         'vis_encoder_type': 'default', 'vis_encoder_cfg': {}, 'dist_decoder_type': 'mixture_logistics',
@@ -197,13 +216,14 @@ class NeuralRayRenderer(nn.Module):
         self._hot.can_dev = can_dev
         return self._hot
 
-    def _train_prep(self, ref_imgs_info):
+    def _train_prep(self, ref_imgs_info, rn=0):
         """Once per training forward on the GPU: re-packed weights and the prepared (channel-last) feature maps shared
         by the HIP twin pairs of this forward."""
         hot = self.hot_for_training()
         bref = self._batched_ref({**ref_imgs_info, 'ray_feats': ref_imgs_info['ray_feats'].detach(),
                                   'img_feats': ref_imgs_info['img_feats'].detach()})
-        prep = hot.prepare(bref, self.cfg.get('volume_resolution', 40))
+        prep = hot.prepare(bref, self.cfg.get('volume_resolution', 40), min(rn, self.cfg['ray_batch_num']),
+                           max(self.cfg['depth_sample_num'], self.cfg['fine_depth_sample_num']))
         return hot, bref, prep
 
     @staticmethod
@@ -241,10 +261,14 @@ class NeuralRayRenderer(nn.Module):
     def _params(self):
         return dict(self.named_parameters())
 
-    def _render_autograd(self, que, ref):
+    def _render_autograd(self, que, ref, _prep=None):
         """renderer.py:201-220 with autograd: ray chunks of ray_batch_num, per-chunk random samples, outputs
-        concatenated along the ray axis (the [1,1] scalars become [1,n_chunks])."""
+        concatenated along the ray axis (the [1,1] scalars become [1,n_chunks]).  On the GPU the per-view chain of every
+        pass runs in HIP in both directions (_RenderChainFn); the per-ray tail (second order) stays in autograd."""
         c, P = self.cfg, self._params()
+        hip = ref['imgs'].is_cuda and c.get('hip_render_backward', True)
+        if hip:
+            hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref)
         rn, chunk, fdn = que['coords'].shape[1], self.cfg['ray_batch_num'], self.cfg['fine_depth_sample_num']
         parts = []
         for r0 in range(0, rn, chunk):
@@ -255,7 +279,17 @@ class NeuralRayRenderer(nn.Module):
                  'depth_range': que['depth_range'][0]}
             if 'imgs' in que:
                 q['imgs'] = que['imgs']
-            parts.append(_ag.render(P, ref, q, self._render_cfg(), u[0]))
+            chains = None
+            if hip:
+                bq = {'coords': q['coords'][None], 'pose': q['pose'][None], 'K': q['K'][None], 'depth_range': q['depth_range'][None]}
+                rc = self._render_cfg()
+
+                def chain_of(level, bq=bq, rc=rc):
+                    keys = [P[k] for k, _ in _w.level_keys(level)]
+                    return lambda depth: _RenderChainFn.apply(hot, prep, bq, depth.detach(), level, rc, ref['ray_feats'],
+                                                              ref['img_feats'], *keys)
+                chains = (chain_of('coarse'), chain_of('fine'))
+            parts.append(_ag.render(P, ref, q, self._render_cfg(), u[0], chains))
         out = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
         if not c['render_depth']:
             out.pop('render_depth', None), out.pop('render_depth_fine', None)
@@ -296,7 +330,7 @@ class NeuralRayRenderer(nn.Module):
     def render(self, que_imgs_info, ref_imgs_info, is_train, _prep=None):   # renderer.py:201-220 (+140-162)
         rn = que_imgs_info['coords'].shape[1]
         if self._use_autograd(is_train):
-            return self._render_autograd(que_imgs_info, ref_imgs_info)
+            return self._render_autograd(que_imgs_info, ref_imgs_info, _prep)
         bref, prep = _prep or self._prepare(ref_imgs_info, rn)
         bque = self._batched_que(que_imgs_info)
         if is_train:
@@ -361,7 +395,7 @@ class NeuralRayRenderer(nn.Module):
         ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
         out = {}
         if self._use_autograd(is_train):
-            prep = self._train_prep(ref) if ref['imgs'].is_cuda else None
+            prep = self._train_prep(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0) if ref['imgs'].is_cuda else None
         else:
             prep = self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
         if self.cfg['render_rgb']:

@@ -182,6 +182,19 @@ int gnr_sample_volume_bwd(const GnrScene* scene, int volume_res, const float* le
                           float* d_img_feats, void* workspace, size_t workspace_bytes, void* train_workspace,
                           size_t train_workspace_bytes, int stages, void* stream);
 
+/* Render path for training (hybrid): the per-view chain of one render pass in HIP in both directions; the per-ray tail
+ * (geometry_fc with the in-forward SDF gradient, attention, NeuS alpha, compositing: renderer.py:90-108,
+ * ibrnet.py:485-504) stays in PyTorch autograd, which supplies d stats / d colours.
+ *   stats_out [B, rn*dn, 66] = mean(32) var(32) wbar n_valid_views (true scale); colors_out [B, rn*dn, 3]           */
+size_t gnr_render_chain_train_workspace_bytes(const GnrScene* scene, int rn, int dn);
+int gnr_render_chain_fwd_train(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn, const float* level_weights,
+                               float* stats_out, float* colors_out, void* workspace, size_t workspace_bytes,
+                               void* train_workspace, size_t train_workspace_bytes, void* stream);
+int gnr_render_chain_bwd(const GnrScene* scene, int rn, int dn, const float* level_weights, const float* level_weights_bwd,
+                         const float* dstats, const float* dcolors, float* d_canonical, float* d_ray_feats, float* d_img_feats,
+                         void* workspace, size_t workspace_bytes, void* train_workspace, size_t train_workspace_bytes,
+                         void* stream);
+
 /* ---- grasp post-processing on the device -------------------------------------------------
  * Replaces the reference planner's `process` + `select` (src/nr/main.py:23-57, 60-84), which run
  * scipy.ndimage (gaussian_filter sigma=1 mode='nearest'; binary_dilation iterations=2 with mask;
