@@ -77,7 +77,7 @@ if rank == 0:
     dt = float(tm)
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-                      'scenes_per_gpu': a.scenes, 'backward': 'HIP kernels for sample_volume and the depth-mean head (csrc/gnr_bwd.inc); torch autograd over graspnerf_amd/autograd_path.py for the render path',
+                      'scenes_per_gpu': a.scenes, 'backward': 'HIP kernels for sample_volume, the render passes\' per-view chains and the depth-mean head (csrc/gnr_bwd.inc); torch autograd for the per-ray tail of the render path and the 2D backbones',
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
 if dist is not None:
