@@ -162,3 +162,28 @@ def test_train_step_on_gpu_matches_reference_gradients():
     losses.total_loss(terms).backward()
     torch.cuda.synchronize()
     check_against_golden(net, terms, G, rtol_loss=2e-4, rtol_grad=1e-2)
+
+
+@pytest.mark.gpu
+def test_hip_and_autograd_training_paths_agree():
+    """The same train-mode forward + backward with the HIP twins switched off (pure autograd over autograd_path.py) and
+    on: outputs and every parameter gradient."""
+    from graspnerf_amd.trainer import train_losses
+    from graspnerf_amd import losses
+    net = build('cuda').train()
+    data = scene_data('cuda')
+    res = {}
+    for hip in (False, True):
+        net.nr_net.cfg['hip_render_backward'] = net.nr_net.cfg['hip_volume_backward'] = hip
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(11)
+        out = net(data)
+        losses.total_loss(train_losses(out, data)).backward()
+        torch.cuda.synchronize()
+        res[hip] = ({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v) and v.dtype.is_floating_point},
+                    {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    for k, v in res[False][0].items():
+        assert (res[True][0][k] - v).abs().max() <= 2e-4 + 1e-3 * v.abs().max(), k
+    for k, g in res[False][1].items():
+        d = (res[True][1][k] - g).abs().max().item()
+        assert d <= 3e-3 * g.abs().max().item() + 1e-7, (k, d, g.abs().max().item())
