@@ -361,7 +361,8 @@ DEV void row_load(const float (&S)[V][SW], int v, float (&R)[SW]) {
 #ifndef GNR_CHAIN_THREADS
 #define GNR_CHAIN_THREADS 512     // 8 wavefronts = 2 per SIMD at <= 256 registers; 256 (1 per SIMD, 512 registers) was measured too
 #endif
-template <int V, bool RENDER>
+// SAVE: training forward (writes the states the backward twins need); compiled out of the inference kernels
+template <int V, bool RENDER, bool SAVE = false>
 __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
                 Sv[17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
             }
             Sv[18] = m;
-            if (a.save1) {
+            if (SAVE && a.save1) {
                 float* sp = a.save1 + (((size_t)b * tps + ts) * V + v) * 19 * 64 + lane;
 #pragma unroll
                 for (int q = 0; q < 19; ++q) sp[q * 64] = Sv[q];
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
         f4 G[4];
         load_bias<4, LF>(lds + pk::B_HOIST, g, G);
         mm<36, 4, 0, LF>(lds + pk::HOIST, lane, SV, G);
-        if (a.saveG) {
+        if (SAVE && a.saveG) {
             float* sp = a.saveG + ((size_t)b * tps + ts) * 17 * 64 + lane;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             Sv[8] = v2;
             Sv[9] = clog;
             Sv[10] = rgbraw;
-            if (a.save2) {
+            if (SAVE && a.save2) {
                 constexpr int S2W = RENDER ? 11 : 9;
                 float* sp = a.save2 + (((size_t)b * tps + ts) * V + v) * S2W * 64 + lane;
 #pragma unroll
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
             for (int v = 0; v < V; ++v) { const float e = __expf(S[v][9] - cmax); den += e; num += S[v][10] * e; }
             if (g < 3 && row_ok) a.colors[pt * 3 + g] = num * rcp1(den);
         }
-        if (a.saveZ) {
+        if (SAVE && a.saveZ) {
             float* sp = a.saveZ + ((size_t)b * tps + ts) * 18 * 64 + lane;
 #pragma unroll
             for (int q = 0; q < 16; ++q) sp[q * 64] = Z[q];
