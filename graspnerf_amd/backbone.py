@@ -185,4 +185,9 @@ class ConvNet(nn.Module):
 
     def forward(self, x):
         f = self.decoder(self.encoder(x))
-        return torch.sigmoid(self.conv_qual(f)), F.normalize(self.conv_rot(f), dim=1), self.conv_width(f)
+        # the three heads read the same 16-channel volume: one 16 -> 6 convolution (identical per output channel) so that
+        # autograd runs ONE conv3d backward instead of three (MIOpen: 9.4 ms each at 40^3)
+        w = torch.cat([self.conv_qual.weight, self.conv_rot.weight, self.conv_width.weight], 0)
+        b = torch.cat([self.conv_qual.bias, self.conv_rot.bias, self.conv_width.bias], 0)
+        y = F.conv3d(f, w, b, padding=2)
+        return torch.sigmoid(y[:, :1]), F.normalize(y[:, 1:5], dim=1), y[:, 5:6]
