@@ -44,8 +44,9 @@ def recorded_traffic(batch):
         import glob
         newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
         rec = json.load(open(newest))
-        return int(rec['kernels']['k_chain<6, false>']['hbm_bytes_corrected']) if batch == 32 else None
-    except (OSError, KeyError, ValueError, IndexError):
+        k = next(v for n, v in rec['kernels'].items() if n.startswith('k_chain<6, false'))
+        return int(k['hbm_bytes_corrected']) if batch == 32 else None
+    except (OSError, KeyError, ValueError, IndexError, StopIteration):
         return None
 
 
@@ -54,7 +55,7 @@ def recorded_counters(batch):
     try:
         import glob
         newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
-        k = json.load(open(newest))['kernels']['k_chain<6, false>']
+        k = next(v for n, v in json.load(open(newest))['kernels'].items() if n.startswith('k_chain<6, false'))
         if batch != 32:
             return None
         return {'source': os.path.relpath(newest, ROOT),
@@ -62,7 +63,7 @@ def recorded_counters(batch):
                 'mfma_pipe_busy': round(k['SQ_VALU_MFMA_BUSY_CYCLES'] / (k['GRBM_GUI_ACTIVE'] / 8 * 1024), 3),
                 'l2_hit_rate': round(k['TCC_HIT_sum'] / (k['TCC_HIT_sum'] + k['TCC_MISS_sum']), 3),
                 'mfma_per_launch': k['SQ_INSTS_MFMA'], 'valu_incl_mfma_per_launch': k['SQ_INSTS_VALU']}
-    except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError):
+    except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError, StopIteration):
         return None
 
 
