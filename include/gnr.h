@@ -152,9 +152,9 @@ int gnr_grasp_head_fwd(int B, int volume_res, const float* volume, const float* 
 const char* gnr_head_last_error(void);
 
 /* ---- backward twins ------------------------------------------------------------------------
- * Round 1 ships the first one: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss,
- * renderer.py:230-266, consumed by DepthLoss, loss.py:87-144).  The remaining *_bwd entry points
- * (sample_volume, render) are not built; training differentiates graspnerf_amd/autograd_path.py.
+ * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
+ * consumed by DepthLoss, loss.py:87-144).  sample_volume and the per-view chain of the render passes follow below;
+ * only the per-ray tail of the render path (second order) stays in graspnerf_amd/autograd_path.py.
  *   gnr_pack_weights_bwd: canonical blob -> transposed MFMA fragments [gnr_packed_bwd_floats()]
  *   gnr_depth_mean_bwd:   dmean [B,V,pn,2] -> d_canonical [gnr_canonical_weights_floats()] (ACCUMULATED:
  *                         mean_decoder.{0,2,4}.{weight,bias} entries, state-dict order) and
@@ -168,10 +168,14 @@ int gnr_depth_mean_bwd(const GnrScene* scene, const float* coords, int pn, const
                        const float* level_weights_bwd, const float* dmean, float* d_canonical, float* d_ray_feats,
                        void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
 
-/* sample_volume for training: the forward that also saves the per-view states, and its backward (in progress:
- * `stages` bit 4 = attention / LayerNorm / out_geometry_fc tail, bit 3 = geometry_fc + second cross-view reduction;
- * the view loops follow).  d_canonical is ACCUMULATED (state-dict order).  The training workspace must survive from
- * the forward to the backward; gnr_train_workspace_layout() exposes its sections to tests.                         */
+/* sample_volume for training: the forward that also saves the per-view states (same values and speed as
+ * gnr_sample_volume_fwd), and its backward in five stages (csrc/gnr_bwd.inc): bit 4 = attention / LayerNorm /
+ * out_geometry_fc tail, bit 3 = geometry_fc + second cross-view reduction, bit 2 = second view loop (base_fc, vis_fc,
+ * vis_fc2), bit 1 = hoisted base_fc.0 columns + first reduction, bit 0 = first view loop (decoder, prob_embed,
+ * ray_dir_fc, neuray gate) + feature-map gradients.  `stages` = 0x1f runs all of it; partial masks exist for the staged
+ * tests, which read the inter-stage gradients through gnr_train_workspace_layout().  d_canonical is ACCUMULATED
+ * (state-dict order, coarse level); d_ray_feats / d_img_feats [B,V,32,fh,fw] are overwritten (NULL to skip).  The
+ * training workspace and the regular workspace must survive untouched from the forward to the backward.              */
 size_t gnr_sample_volume_train_workspace_bytes(const GnrScene* scene, int volume_res);
 int gnr_train_workspace_layout(const GnrScene* scene, int volume_res, size_t* offsets_out9);
 int gnr_sample_volume_fwd_train(const GnrScene* scene, const float* bbox_min, int volume_res, const float* level_weights,
