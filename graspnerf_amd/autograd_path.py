@@ -259,7 +259,8 @@ def render_by_depth(P, ref, que, depth, dec, agg, cfg, chain=None):
 
 
 def sample_fine_depth(depth, hit_prob, depth_range, fdn, u):
-    """render_ops.py:172-229 (hit_prob arrives detached, renderer.py:141); u [rn,fdn]."""
+    """render_ops.py:172-229 (hit_prob arrives detached, renderer.py:141); u [rn,fdn].  depth_range: (near, far) scalars
+    or per-ray [rn,1] columns (rays of several scenes)."""
     near, far = -1 / depth_range[0], -1 / depth_range[1]
     d = (-1 / depth - near) / (far - near)
     centre = torch.cat([d[:, :1], (d[:, 1:] + d[:, :-1]) / 2, d[:, -1:]], -1)
@@ -305,3 +306,45 @@ def depth_mean(P, ref, coords_rc, dec):
     uv = coords_rc.to(torch.float32)[None].expand(V, -1, -1)
     f = bilinear_border(ref['ray_feats'], uv, h, w)
     return _mlp3(f, P, dec + 'mean_decoder', F.softplus)
+
+
+def render_scenes(P, que, hw, cfg, fine_u, chains):
+    """render() for B scenes at once around the batched HIP chains (training, GPU): the per-ray tail treats the rays of
+    all scenes as one long list.  que: coords [B,rn,2], pose [B,3,4], K [B,3,3], depth_range [B,2], optional imgs
+    [B,3,H,W]; fine_u [B,rn,fdn]; chains = (coarse, fine) with chain(depth [B,rn,dn]) -> (stats [B,P,66], colours [B,P,3]).
+    -> list of B per-scene output dicts (same keys and shapes as render())."""
+    dev = que['coords'].device
+    B, rn = que['coords'].shape[:2]
+    dn, fdn = cfg['depth_sample_num'], cfg['fine_depth_sample_num']
+    near, far = que['depth_range'][:, 0:1], que['depth_range'][:, 1:2]                  # [B,1]
+    diff = 1 / far - 1 / near
+    ar = torch.arange(1, dn - 1, dtype=torch.float32, device=dev)[None]
+    ticks = torch.cat([torch.zeros(B, 1, device=dev), diff / (dn - 1) * ar, diff], 1)   # [B,dn]
+    depth = (1 / (1 / near + ticks))[:, None].expand(B, rn, dn).contiguous()
+
+    def one_pass(depth, agg, chain):
+        d = depth.shape[-1]
+        geo = [ray_points({'coords': que['coords'][b], 'pose': que['pose'][b], 'K': que['K'][b]}, depth[b]) for b in range(B)]
+        pts = torch.cat([g[0] for g in geo])
+        qdir = torch.cat([g[1] for g in geo])
+        stats, col = chain(depth)
+        stats, col = stats.reshape(-1, 66), col.reshape(-1, 3)
+        nval = stats[:, 65].detach()
+        sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], nval, pts, B * rn, d, True)
+        outs = []
+        for b in range(B):                                                 # per-scene means / query images
+            sl = slice(b * rn, (b + 1) * rn)
+            q = {'coords': que['coords'][b]}
+            if 'imgs' in que:
+                q['imgs'] = que['imgs'][b:b + 1]
+            outs.append(composite(P, agg, sdf[sl], grad[sl], col.reshape(B * rn, d, 3)[sl], nval.reshape(B * rn, d)[sl], qdir[sl],
+                                  depth[b], q, hw, cfg))
+        return outs
+    coarse = one_pass(depth, 'agg_net.', chains[0])
+    hit = torch.cat([o['hit_prob_nr'][0].detach() for o in coarse])
+    dr = que['depth_range'][:, None].expand(B, rn, 2).reshape(-1, 2)
+    fd = sample_fine_depth(depth.reshape(-1, dn), hit, (dr[:, 0:1], dr[:, 1:2]), fdn, fine_u.reshape(-1, fdn).to(dev))
+    fine = one_pass(torch.sort(fd, -1)[0].reshape(B, rn, fdn), 'fine_agg_net.', chains[1])
+    for o, f in zip(coarse, fine):
+        o.update({k + '_fine': v for k, v in f.items()})
+    return coarse

@@ -57,8 +57,18 @@ class HotPath:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    generation = 0
+
+    def check_generation(self, gen):
+        """The backward twins recompute from the prepared feature maps and the saved states in this object's workspaces:
+        a later prepare() (= another forward) before the backward would silently corrupt them."""
+        if gen != self.generation:
+            raise _lib.GnrError('HIP backward after the workspaces were re-prepared: run forward and backward of a scene '
+                                '(or of one batch of scenes) before the next training forward')
+
     def prepare(self, ref, res=40, rn=0, dn=0):
         """Repack feature maps + per-view projection blocks (timed part of a forward)."""
+        self.generation += 1
         scene, keep = self._scene(ref)
         ws = self._workspace(scene, res, rn, dn)
         _lib.check(self.L.gnr_prepare(C.byref(scene), ws.data_ptr(), ws.numel(), self._stream()), 'gnr_prepare')

@@ -101,17 +101,19 @@ class _DepthMeanFn(torch.autograd.Function):
     mean_decoder parameters; `prep` must stay untouched between forward and backward."""
 
     @staticmethod
-    def forward(ctx, hot, bref, prep, xy, level, ray_feats, *params):
+    def forward(ctx, hot, bref, prep, xy, level, ray_feats, *params):      # xy [B,pn,2], ray_feats [B,V,32,fh,fw]
         ctx.args = (hot, bref, prep, xy, level)
-        return hot.depth_mean(bref, xy, level, prepared=prep)[0]
+        ctx.gen = hot.generation
+        return hot.depth_mean(bref, xy, level, prepared=prep)              # [B,V,pn,2]
 
     @staticmethod
     def backward(ctx, dmean):
         hot, bref, prep, xy, level = ctx.args
-        dcan, dray = hot.depth_mean_bwd(bref, xy, dmean.contiguous()[None], level, prepared=prep)
+        hot.check_generation(ctx.gen)
+        dcan, dray = hot.depth_mean_bwd(bref, xy, dmean.contiguous(), level, prepared=prep)
         dec = _w.LEVELS[level][0]
         g = _w.split_canonical(dcan, level)
-        return (None, None, None, None, None, dray[0]) + tuple(g[dec + 'mean_decoder.' + n] for n in _DM_PARAMS)
+        return (None, None, None, None, None, dray) + tuple(g[dec + 'mean_decoder.' + n] for n in _DM_PARAMS)
 
 
 class _SampleVolumeFn(torch.autograd.Function):
@@ -121,15 +123,16 @@ class _SampleVolumeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hot, bref, prep, res, ray_feats, img_feats, *params):
-        ctx.hot = hot
+        ctx.hot, ctx.gen = hot, hot.generation
         return hot.sample_volume_train(bref, res, prepared=prep)
 
     @staticmethod
     def backward(ctx, dvol):
         hot = ctx.hot
+        hot.check_generation(ctx.gen)
         dcan, dray, dimg = hot.sample_volume_bwd(dvol.contiguous(), hot.can_dev['coarse'])
         g = _w.split_canonical(dcan, 'coarse')
-        return (None, None, None, None, dray[0], dimg[0]) + tuple(g[k] for k, _ in _w.level_keys('coarse'))
+        return (None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys('coarse'))
 
 
 class _RenderChainFn(torch.autograd.Function):
@@ -139,16 +142,17 @@ class _RenderChainFn(torch.autograd.Function):
     stats [P,66] (mean, var, wbar, n_valid) and colours [P,3]."""
 
     @staticmethod
-    def forward(ctx, hot, prep, que, depth, level, cfg, ray_feats, img_feats, *params):
-        stats, colors, hctx = hot.render_chain_train(que, depth[None], level, cfg, prep)
-        ctx.hot, ctx.hctx, ctx.level = hot, hctx, level
-        return stats[0], colors[0]
+    def forward(ctx, hot, prep, que, depth, level, cfg, ray_feats, img_feats, *params):     # depth [B,rn,dn]
+        stats, colors, hctx = hot.render_chain_train(que, depth, level, cfg, prep)
+        ctx.hot, ctx.hctx, ctx.level, ctx.gen = hot, hctx, level, hot.generation
+        return stats, colors                                                # [B,P,66], [B,P,3]
 
     @staticmethod
     def backward(ctx, dstats, dcolors):
-        dcan, dray, dimg = ctx.hot.render_chain_bwd(ctx.hctx, dstats[None, :, :65].contiguous(), dcolors[None].contiguous())
+        ctx.hot.check_generation(ctx.gen)
+        dcan, dray, dimg = ctx.hot.render_chain_bwd(ctx.hctx, dstats[..., :65].contiguous(), dcolors.contiguous())
         g = _w.split_canonical(dcan, ctx.level)
-        return (None, None, None, None, None, None, dray[0], dimg[0]) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
+        return (None, None, None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
 
 
 class NeuralRayRenderer(nn.Module):
@@ -286,8 +290,12 @@ class NeuralRayRenderer(nn.Module):
 
                 def chain_of(level, bq=bq, rc=rc):
                     keys = [P[k] for k, _ in _w.level_keys(level)]
-                    return lambda depth: _RenderChainFn.apply(hot, prep, bq, depth.detach(), level, rc, ref['ray_feats'],
-                                                              ref['img_feats'], *keys)
+
+                    def run(depth):
+                        st, co = _RenderChainFn.apply(hot, prep, bq, depth.detach()[None], level, rc, ref['ray_feats'][None],
+                                                      ref['img_feats'][None], *keys)
+                        return st[0], co[0]
+                    return run
                 chains = (chain_of('coarse'), chain_of('fine'))
             parts.append(_ag.render(P, ref, q, self._render_cfg(), u[0], chains))
         out = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
@@ -307,8 +315,8 @@ class NeuralRayRenderer(nn.Module):
             if ref_imgs_info['imgs'].is_cuda and self.cfg.get('hip_volume_backward', True):
                 hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
                 P = self._params()
-                return _SampleVolumeFn.apply(hot, bref, prep, self.cfg['volume_resolution'], ref_imgs_info['ray_feats'],
-                                             ref_imgs_info['img_feats'], *[P[k] for k, _ in _w.level_keys('coarse')])
+                return _SampleVolumeFn.apply(hot, bref, prep, self.cfg['volume_resolution'], ref_imgs_info['ray_feats'][None],
+                                             ref_imgs_info['img_feats'][None], *[P[k] for k, _ in _w.level_keys('coarse')])
             return _ag.sample_volume(self._params(), ref_imgs_info, self.cfg['volume_resolution'])
         bref, prep = _prep or self._prepare(ref_imgs_info)
         return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
@@ -369,8 +377,8 @@ class NeuralRayRenderer(nn.Module):
                 # HIP forward + HIP backward behind an autograd.Function (csrc/gnr_bwd.inc)
                 hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
                 xy = coords.to(torch.float32)[None]
-                mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'],
-                                             *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
+                mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'][None],
+                                             *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])[0]
                           for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
             else:
                 mc = _ag.depth_mean(P, ref_imgs_info, coords, 'dist_decoder.')
@@ -405,6 +413,70 @@ class NeuralRayRenderer(nn.Module):
         if (self.cfg.get('use_depth_loss', False) and 'true_depth' in ref) or (not is_train):
             out.update(self.predict_mean_for_depth_loss(ref, _prep=prep, is_train=is_train))
         return out
+
+
+    def forward_scenes(self, datas):
+        """Training forward of several scenes in ONE pass (trainer-internal; the reference's API is one scene per forward):
+        batched backbones, one weight re-pack, batched HIP twin pairs, one per-ray tail over the rays of all scenes.  Same
+        values and the same RNG stream as `[self.forward(d) for d in datas]` (which it falls back to whenever the batch is
+        not uniform, off the GPU, or autograd is off).  -> list of per-scene output dicts, or None when the scenes cannot
+        be batched (the caller must then run forward + backward scene by scene: the HIP twin pairs keep their saved states
+        in per-module workspaces, so a second training forward before the first one's backward would overwrite them)."""
+        c = self.cfg
+        refs = [d['ref_imgs_info'] for d in datas]
+        ques = [d['que_imgs_info'] for d in datas]
+        same = all(r['imgs'].shape == refs[0]['imgs'].shape and q['coords'].shape == ques[0]['coords'].shape for r, q in zip(refs, ques))
+        if not (len(datas) > 1 and same and all('eval' not in d for d in datas) and self._use_autograd(True) and refs[0]['imgs'].is_cuda
+                and c['render_rgb'] and c.get('sample_volume', False) and c.get('hip_render_backward', True)
+                and c.get('hip_volume_backward', True) and ques[0]['coords'].shape[1] <= c['ray_batch_num']):
+            return None
+        B, V = len(datas), refs[0]['imgs'].shape[0]
+        h, w = refs[0]['imgs'].shape[-2:]
+        rn, fdn, R = ques[0]['coords'].shape[1], c['fine_depth_sample_num'], c['volume_resolution']
+        dev = refs[0]['imgs'].device
+        imgs = torch.cat([r['imgs'] for r in refs])
+        img_feats = self.image_encoder(imgs)
+        ray_feats = self.vis_encoder(self.init_net({'imgs': imgs}, None, True), img_feats)
+        img_feats, ray_feats = img_feats.reshape(B, V, *img_feats.shape[1:]), ray_feats.reshape(B, V, *ray_feats.shape[1:])
+        want_depth = c.get('use_depth_loss', False) and 'true_depth' in refs[0]
+        us, coords = [], []
+        for _ in range(B):                                                  # the per-scene draw order of forward()
+            us.append(torch.rand([1, rn, fdn]))
+            for net in (self.agg_net, self.fine_agg_net):
+                net.train_step_bookkeeping()
+            if want_depth:
+                coords.append(self.gen_depth_loss_coords(h, w, dev))
+        hot = self.hot_for_training()
+        stack = lambda k, src: torch.stack([torch.as_tensor(x[k], dtype=torch.float32, device=dev) for x in src])
+        bref = {'imgs': imgs.reshape(B, V, 3, h, w), 'img_feats': img_feats.detach(), 'ray_feats': ray_feats.detach(),
+                'poses': stack('poses', refs), 'Ks': stack('Ks', refs), 'depth_range': stack('depth_range', refs),
+                'bbox3d': stack('bbox3d', refs)}
+        prep = hot.prepare(bref, R, rn, max(c['depth_sample_num'], fdn))
+        P = self._params()
+        bq = {'coords': torch.cat([q['coords'] for q in ques]), 'pose': torch.cat([q['poses'] for q in ques]),
+              'K': torch.cat([q['Ks'] for q in ques]), 'depth_range': torch.cat([q['depth_range'] for q in ques])}
+        rc = self._render_cfg()
+
+        def chain_of(level):
+            keys = [P[k] for k, _ in _w.level_keys(level)]
+            return lambda depth: _RenderChainFn.apply(hot, prep, bq, depth.detach(), level, rc, ray_feats, img_feats, *keys)
+        que_b = dict(bq)
+        if 'imgs' in ques[0]:
+            que_b['imgs'] = torch.cat([q['imgs'] for q in ques])
+        outs = _ag.render_scenes(P, que_b, (h, w), rc, torch.cat(us), (chain_of('coarse'), chain_of('fine')))
+        vol = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
+        if want_depth:
+            xy = torch.stack(coords).to(torch.float32)
+            mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
+                      for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
+        for b, o in enumerate(outs):
+            if not c['render_depth']:
+                o.pop('render_depth', None), o.pop('render_depth_fine', None)
+            o['volume'] = vol[b:b + 1]
+            if want_depth:
+                o.update({'depth_mean': mc[b, ..., 0], 'depth_coords': coords[b][None].repeat(V, 1, 1), 'depth_mean_2': mc[b, ..., 1],
+                          'depth_mean_fine': mf[b, ..., 0], 'depth_mean_fine_2': mf[b, ..., 1]})
+        return outs
 
 
 class GraspNeRF(nn.Module):
@@ -446,6 +518,17 @@ class GraspNeRF(nn.Module):
         vgn_pred = self.grasp_head(render_outputs['volume'])
         render_outputs['vgn_pred'] = vgn_pred if 'full_vol' in data else self.select(vgn_pred, data['grasp_info'][0])
         return render_outputs
+
+    def forward_scenes(self, datas):
+        """Several scenes in one training forward (NeuralRayRenderer.forward_scenes + one batched grasp-head call)."""
+        outs = self.nr_net.forward_scenes(datas)
+        if outs is None:
+            return None
+        q, r, w = self.grasp_head(torch.cat([o['volume'] for o in outs]))
+        for b, (o, d) in enumerate(zip(outs, datas)):
+            pred = (q[b:b + 1], r[b:b + 1], w[b:b + 1])
+            o['vgn_pred'] = pred if 'full_vol' in d else self.select(pred, d['grasp_info'][0])
+        return outs
 
 
 name2network = {'grasp_nerf': GraspNeRF}

@@ -30,8 +30,9 @@ def exp_decay_lr(step, lr_init=1e-4, decay_step=100000, decay_rate=0.5, lr_min=1
 
 
 class Trainer:
-    def __init__(self, net, lr_cfg=None):
+    def __init__(self, net, lr_cfg=None, batched=True):
         self.net = net
+        self.batched = batched
         self.lr_cfg = lr_cfg or {}
         self.params = [p for p in net.parameters()]
         self.optimizer = torch.optim.Adam(self.params, lr=1e-3)            # lr_common_manager.py:9-13
@@ -76,11 +77,20 @@ class Trainer:
             g['lr'] = lr
         self.optimizer.zero_grad(set_to_none=True)
         log = {}
-        for data in scenes:
-            data = dict(data, step=self.step_id)
-            out = self.net(data)
-            terms = train_losses(out, data)
-            losses.total_loss(terms).backward()                           # accumulates into .grad
+        datas = [dict(d, step=self.step_id) for d in scenes]
+        outs = None
+        if self.batched and hasattr(self.net, 'forward_scenes') and len(datas) > 1:
+            outs = self.net.forward_scenes(datas)          # all scenes of the rank in one forward (None: cannot batch)
+        if outs is not None:
+            all_terms = [train_losses(o, d) for o, d in zip(outs, datas)]
+            sum(losses.total_loss(t) for t in all_terms).backward()
+        else:
+            all_terms = []
+            for data in datas:
+                terms = train_losses(self.net(data), data)
+                losses.total_loss(terms).backward()                       # accumulates into .grad
+                all_terms.append(terms)
+        for terms in all_terms:
             for k, v in terms.items():
                 log[k] = log.get(k, 0.0) + float(v.detach().mean()) / len(scenes)
         self._allreduce_grads(len(scenes))

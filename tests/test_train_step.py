@@ -187,3 +187,56 @@ def test_hip_and_autograd_training_paths_agree():
     for k, g in res[False][1].items():
         d = (res[True][1][k] - g).abs().max().item()
         assert d <= 3e-3 * g.abs().max().item() + 1e-7, (k, d, g.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_batched_training_forward_equals_per_scene_loop():
+    """Trainer: all scenes of a rank in one forward / backward (forward_scenes) against the reference-style loop of
+    per-scene forwards -- same RNG stream, same losses, same accumulated gradients."""
+    from graspnerf_amd.trainer import train_losses
+    from graspnerf_amd import losses
+    net = build('cuda').train()
+    datas = [scene_data('cuda', 0), scene_data('cuda', 1), scene_data('cuda', 2)]
+    assert net.forward_scenes(datas) is None                   # 64 rays > ray_batch_num 40: several chunks, not batchable
+    net.nr_net.cfg['ray_batch_num'] = 4096
+    res = {}
+    for batched in (False, True):
+        net.zero_grad(set_to_none=True)
+        for a in (net.nr_net.agg_net, net.nr_net.fine_agg_net):
+            a.step = 0
+        torch.manual_seed(21)
+        if batched:
+            outs = net.forward_scenes(datas)
+            assert outs is not None
+            terms = [train_losses(o, d) for o, d in zip(outs, datas)]
+            sum(losses.total_loss(t) for t in terms).backward()
+        else:
+            terms = []
+            for d in datas:
+                t = train_losses(net(d), d)
+                losses.total_loss(t).backward()
+                terms.append(t)
+        torch.cuda.synchronize()
+        res[batched] = ([{k: float(v.detach().mean()) for k, v in t.items() if k.startswith('loss')} for t in terms],
+                        {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    for la, lb in zip(res[False][0], res[True][0]):
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-4 * abs(la[k]) + 1e-7, (k, la[k], lb[k])
+    for k, g in res[False][1].items():
+        d = (res[True][1][k] - g).abs().max().item()
+        assert d <= 3e-3 * g.abs().max().item() + 1e-6, (k, d, g.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_backward_after_another_forward_is_refused():
+    """The HIP twin pairs keep their states in per-module workspaces: a second training forward before the first
+    backward must be reported, not silently produce wrong gradients."""
+    from graspnerf_amd.trainer import train_losses
+    from graspnerf_amd import losses, _lib
+    net = build('cuda').train()
+    d0, d1 = scene_data('cuda', 0), scene_data('cuda', 1)
+    l0 = losses.total_loss(train_losses(net(d0), d0))
+    l1 = losses.total_loss(train_losses(net(d1), d1))
+    with pytest.raises((_lib.GnrError, RuntimeError)):
+        l0.backward()
+    net.zero_grad(set_to_none=True)
