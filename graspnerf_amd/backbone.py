@@ -177,6 +177,44 @@ class _Decoder(nn.Module):
         return F.interpolate(F.relu(self.conv3(x)), 40)
 
 
+class _Conv3dSame(torch.autograd.Function):
+    """F.conv3d(x, w, b, padding=k//2) whose weight gradient comes from the HIP kernel gnr_conv3d_bwd_weight on the GPU
+    (MIOpen's weight-gradient path is a 75 ms batched GEMM for the head convolution at 40^3, batch 8); input gradient and
+    forward stay with PyTorch."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.conv3d(x, w, b, padding=w.shape[-1] // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from . import _lib
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        k = w.shape[-1]
+        dx = torch.nn.grad.conv3d_input(x.shape, w, dy, padding=k // 2) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            xc = x.contiguous()
+            rc = _lib.lib().gnr_conv3d_bwd_weight(xc.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.shape[0], x.shape[1], w.shape[0],
+                                                  x.shape[2], x.shape[3], x.shape[4], k,
+                                                  C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc:
+                raise _lib.GnrError(f'gnr_conv3d_bwd_weight failed: {rc}')
+        db = dy.sum((0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def conv3d_same(x, w, b):
+    """Stride-1 same-padding conv3d; on the GPU under autograd the weight gradient runs in HIP."""
+    if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _Conv3dSame.apply(x, w, b)
+    return F.conv3d(x, w, b, padding=w.shape[-1] // 2)
+
+
 class ConvNet(nn.Module):
     def __init__(self):
         super().__init__()
@@ -189,5 +227,5 @@ class ConvNet(nn.Module):
         # autograd runs ONE conv3d backward instead of three (MIOpen: 9.4 ms each at 40^3)
         w = torch.cat([self.conv_qual.weight, self.conv_rot.weight, self.conv_width.weight], 0)
         b = torch.cat([self.conv_qual.bias, self.conv_rot.bias, self.conv_width.bias], 0)
-        y = F.conv3d(f, w, b, padding=2)
+        y = conv3d_same(f, w, b)
         return torch.sigmoid(y[:, :1]), F.normalize(y[:, 1:5], dim=1), y[:, 5:6]

@@ -46,3 +46,21 @@ def test_head_matches_pytorch(R, B):
     np.testing.assert_allclose(w.cpu().numpy(), w0.numpy(), rtol=1e-3, atol=2e-5)
     np.testing.assert_allclose(r.cpu().numpy(), r0.numpy(), rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(np.linalg.norm(r.cpu().numpy(), axis=1), 1.0, atol=1e-5)     # unit quaternions
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Cin,Cout,D,H,W,K', [(2, 16, 6, 9, 7, 10, 5), (1, 32, 16, 6, 6, 6, 5), (3, 20, 33, 5, 4, 7, 3), (1, 16, 6, 40, 40, 40, 5)])
+def test_conv3d_weight_gradient_kernel(B, Cin, Cout, D, H, W, K):
+    """gnr_conv3d_bwd_weight against PyTorch's own conv3d backward (ragged channel counts, non-cubic volumes)."""
+    from graspnerf_amd.backbone import conv3d_same
+    g = torch.Generator().manual_seed(B * 100 + Cin)
+    x = torch.randn(B, Cin, D, H, W, generator=g).cuda().requires_grad_(True)
+    w = (0.1 * torch.randn(Cout, Cin, K, K, K, generator=g)).cuda().requires_grad_(True)
+    b = torch.randn(Cout, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(B, Cout, D, H, W, generator=g).cuda()
+    (conv3d_same(x, w, b) * dy).sum().backward()
+    got = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    (torch.nn.functional.conv3d(x, w, b, padding=K // 2) * dy).sum().backward()
+    for a, r, name in zip(got, (x.grad, w.grad, b.grad), ('dx', 'dw', 'db')):
+        assert (a - r).abs().max() <= 2e-4 * r.abs().max() + 1e-5, name
