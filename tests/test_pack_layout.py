@@ -239,3 +239,82 @@ def test_pack_rejects_bad_input():
     with pytest.raises(ValueError):
         weights.pack(np.zeros(10, np.float32))
     assert L.gnr_layout_offset(b'NOPE') == -1
+
+
+# ---- backward blob (gnr_pack_weights_bwd): transposed fragments, emulated like the forward ones -------------------
+BWD_OFF = {}
+
+
+def _bwd_offsets():
+    """Offsets of the backward blob, mirrored from gnr_layout.h namespace pkb (checked against the blob size)."""
+    if BWD_OFF:
+        return BWD_OFF
+    ff = lambda J, NB: (-(-J // 4)) * 256 if NB == 1 else (J * 256 if NB == 3 else J * 64 * NB)
+    o, order = 0, [('DM_W2T', 1024), ('DM_W1T', 1024), ('GEO2T', ff(4, 4)), ('GEO1T_A', ff(16, 4)), ('GEO1T_B', ff(16, 1)),
+                   ('PE2F', 1024), ('B_PE2', 32), ('VISB1T', 1024), ('VIS2T', 1024), ('VIS1T', 1024), ('BASE2T', ff(8, 4)),
+                   ('BASE1XT', ff(16, 3)), ('BASE1ET', ff(16, 2)), ('HOISTT_A', ff(16, 4)), ('HOISTT_B', ff(16, 4)),
+                   ('HOISTT_C', ff(16, 1)), ('DEC2T', 3072), ('DEC1T', 3072), ('V1_PE2F', 1024), ('V1_B_PE2', 32), ('PE2T', 1024),
+                   ('PE0T', 1024), ('T_PE0HV', 64), ('NR0T', ff(4, 2)), ('RDF2T', ff(9, 1)), ('RGB2T', ff(4, 1)),
+                   ('RGB0HT', ff(4, 2)), ('T_RGB0V', 16)]
+    for name, n in order:
+        BWD_OFF[name] = o
+        o += n
+    assert o == _lib.lib().gnr_packed_bwd_floats()
+    return BWD_OFF
+
+
+def test_bwd_fragments_compute_transposed_products(weights_np):
+    """dX = W^T dY through every transposed fragment, on one random 16-point tile, against numpy."""
+    can = weights.canonical_blob(weights_np, 'coarse')
+    pb = weights.pack_bwd(can)
+    O = _bwd_offsets()
+    rng = np.random.default_rng(0)
+    W = lambda k: weights_np['agg_net.agg_impl.' + k]
+    gather = lambda nb, i: 8 * (i // 4) + 4 * nb + (i % 4)
+    natO = lambda nb, i: 16 * nb + i
+    xout = lambda nb, i: (3 + 8 * (i >> 2) + (i & 3)) if nb == 0 else ((3 + 8 * (i >> 2) + 4 + (i & 3)) if nb == 1 else ((i >> 2) if (i & 3) == 0 and (i >> 2) < 3 else -1))
+    first8 = lambda j, g: (4 * g + j) if 4 * g + j < 8 else -1
+
+    def zslot(j, g):
+        if j < 8:
+            return nat(j, g)
+        if j < 16:
+            return 32 + nat(j - 8, g)
+        return (64 if j == 16 else -1) if g == 0 else 65 + 3 * (j - 16) + (g - 1)
+    sslot = lambda s, g: -1 if xfeat(s % 9, g) < 0 else 35 * (s // 9) + xfeat(s % 9, g)
+    cases = [   # name, W^T as [out][in], J, NB, phi (input layout), psi (output layout), n_out
+        ('DM_W2T', weights_np['dist_decoder.mean_decoder.2.weight'].T, 8, 2, nat, natO, 32),
+        ('DM_W1T', weights_np['dist_decoder.mean_decoder.0.weight'].T, 8, 2, nat, gather, 32),
+        ('GEO2T', W('geometry_fc.2.weight').T, 4, 4, nat, natO, 64),
+        ('VISB1T', W('vis_fc2.0.weight').T, 8, 2, nat, natO, 32),
+        ('VIS2T', W('vis_fc.2.weight')[:32].T, 8, 2, nat, natO, 32),
+        ('VIS1T', W('vis_fc.0.weight').T, 8, 2, nat, natO, 32),
+        ('BASE2T', W('base_fc.2.weight').T, 8, 4, nat, natO, 64),
+        ('BASE1XT', W('base_fc.0.weight')[:, 140:175].T, 16, 3, nat, xout, 35),
+        ('BASE1ET', W('base_fc.0.weight')[:, 175:].T, 16, 2, nat, natO, 32),
+        ('PE2T', weights_np['agg_net.prob_embed.2.weight'].T, 8, 2, nat, natO, 32),
+        ('PE0T', weights_np['agg_net.prob_embed.0.weight'][:, :32].T, 8, 2, nat, gather, 32),
+        ('NR0T', W('neuray_fc.0.weight').T, 4, 2, first8, natO, 32),
+        ('RDF2T', W('ray_dir_fc.2.weight').T, 9, 1, xfeat, natO, 16),
+        ('RGB2T', W('rgb_fc.2.weight').T, 4, 1, first8, natO, 16),
+        ('RGB0HT', W('rgb_fc.0.weight')[:, :32].T, 4, 2, nat, natO, 32),
+        ('GEO1T_A', W('geometry_fc.0.weight').T, 16, 4, nat, lambda nb, i: zslot(4 * nb + (i & 3), i >> 2), 86),
+        ('HOISTT_A', W('base_fc.0.weight')[:, :140].T, 16, 4, nat, lambda nb, i: sslot(4 * nb + (i & 3), i >> 2), 140),
+        ('HOISTT_C', W('base_fc.0.weight')[:, :140].T, 16, 1, nat, lambda nb, i: sslot(32 + (i & 3), i >> 2), 140),
+    ]
+    for name, WT, J, NB, phi, psi, nout in cases:
+        nin = WT.shape[1]
+        dy = rng.standard_normal((16, nin)).astype(np.float32)
+        B_in = to_B(dy, J, phi)
+        acc = emulate(pb, O[name], J, NB, B_in)
+        want = dy.astype(np.float64) @ WT.T.astype(np.float64)           # [16][out]
+        got = np.full((16, nout), np.nan)
+        for nb in range(NB):
+            for t in range(4):
+                for l in range(64):
+                    o = psi(nb, 4 * (l >> 4) + t)
+                    if o is not None and o >= 0:
+                        got[l & 15, o] = acc[nb, t, l]
+        seen = ~np.isnan(got[0])
+        assert seen.sum() >= min(nout, 16 * NB) - 8, name                 # the fragment covers its block of rows
+        assert np.abs(got[:, seen] - want[:, seen]).max() < 1e-4, name
