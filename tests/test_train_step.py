@@ -149,6 +149,18 @@ def test_optimizer_step_changes_parameters_and_reduces_loss():
     assert tr.step_id == 2 and l0['lr'] == 1e-3
 
 
+def test_trainer_with_several_scenes_on_cpu_uses_the_per_scene_loop():
+    """Off the GPU forward_scenes() declines (None) and the trainer runs forward + backward scene by scene."""
+    from graspnerf_amd.trainer import Trainer
+    net = build()
+    assert net.forward_scenes([scene_data(scene_id=0), scene_data(scene_id=1)]) is None
+    tr = Trainer(net, {'lr_init': 1e-3})
+    torch.manual_seed(3)
+    log = tr.step([scene_data(scene_id=0), scene_data(scene_id=1)])
+    assert np.isfinite(sum(v for k, v in log.items() if k.startswith('loss'))) and tr.step_id == 1
+    assert all(p.grad is not None for p in net.parameters())
+
+
 @pytest.mark.gpu
 def test_train_step_on_gpu_matches_reference_gradients():
     """Same check with the model on the MI355X (autograd path + MIOpen backbones on the device)."""
