@@ -398,15 +398,18 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_
         const int b = tile / tps;
         int ts = tile - b * tps;
         if (a.vol_res > 0) {
-            // Volume points are stored column-major (x, y, then z top->down).  Visit them in bricks of 4x4
-            // columns instead of whole x-planes: the feature-map footprint of the ~256 tiles in flight on an
-            // XCD then fits its 4 MiB L2 (an x-plane of the 40^3 grid covers ~8 MB of feature lines).
+            // Volume points are stored column-major (x, y, then z top->down).  Visit them in bricks of
+            // (R/4) x (R/4) columns instead of whole x-planes: at R = 40 a brick (100 columns, 250 tiles) is what the
+            // 256 wavefronts of an XCD have in flight, and a compact block of columns projects to the smallest union
+            // of feature-map lines (an x-plane covers ~8 MB of them, an XCD's L2 holds 4 MiB).  Measured L2 fill per
+            // launch: x-planes 2.45 GB, 4x4-column bricks 1.83 GB, 8x8 1.50 GB, 10x10 1.44 GB, 20x20 1.54 GB.
             // Bijection on 2-column groups (2R points = R/8 tiles); requires R % 8 == 0 (host checks).
-            const int R = a.vol_res, tpg = R >> 3, gpr = R >> 1, bpb = R >> 2;
+            const int R = a.vol_res, tpg = R >> 3, gpr = R >> 1;
+            const int BX = R >> 2, GY = R >> 3, GB = BX * GY;             // a plane = 4 x 4 bricks of (R/4) x (R/4) columns
             const int sidx = ts / tpg, tin = ts - sidx * tpg;
-            const int brick = sidx >> 3, wi = sidx & 7;
-            const int bx = brick / bpb, by = brick - bx * bpb;
-            ts = ((4 * bx + (wi >> 1)) * gpr + 2 * by + (wi & 1)) * tpg + tin;
+            const int brick = sidx / GB, wi = sidx - brick * GB;
+            const int bx = brick >> 2, by = brick & 3;
+            ts = ((BX * bx + wi / GY) * gpr + GY * by + wi % GY) * tpg + tin;
         }
         const int n_raw = ts * 16 + r;
         const bool row_ok = n_raw < a.P;
