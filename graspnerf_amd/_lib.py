@@ -124,6 +124,12 @@ def lib():
     L.gnr_render_chain_bwd.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_render_chain_bwd.restype = C.c_int
+    L.gnr_render_tail_fwd_train.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_int] + [C.c_void_p] * 4 + \
+                                           [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_render_tail_fwd_train.restype = C.c_int
+    L.gnr_ray_tail_grad_floats.restype = C.c_int
+    L.gnr_ray_tail_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]
+    L.gnr_ray_tail_dual_bwd.restype = C.c_int
     L.gnr_grasp_select_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.gnr_grasp_select_workspace_bytes.restype = C.c_size_t
     L.gnr_grasp_select_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.POINTER(GnrSelectParams)] + \
@@ -150,7 +156,8 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_grasp_select_fwd', 'gnr_post_last_error', 'gnr_packed_bwd_floats', 'gnr_pack_weights_bwd',
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
-            'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight']
+            'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight',
+            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd']
 
 
 def check(rc, what):

@@ -236,14 +236,17 @@ def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
 
 def render_by_depth(P, ref, que, depth, dec, agg, cfg, chain=None):
     """renderer.py:90-138 for one scene; depth [rn,dn].  que: coords [rn,2], pose [3,4], K [3,3], depth_range [2].
-    `chain(depth) -> (stats [rn*dn,66], colours [rn*dn,3])` replaces the per-view part (everything up to the cross-view
+    `chain(depth) -> (stats [rn*dn,66], colours [rn*dn,3][, tail])` replaces the per-view part (everything up to the cross-view
     statistics and the colour blend) with the HIP twin pair; the per-ray tail stays here."""
     rn, dn = depth.shape
     h, w = ref['imgs'].shape[-2:]
     pts, qdir = ray_points(que, depth)
     if chain is not None:
-        stats, col = chain(depth)
-        sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], stats[:, 65].detach(), pts, rn, dn, True)
+        stats, col, *tail = chain(depth)
+        if tail and tail[0] is not None:                                   # HIP tail in both directions (renderer._RayTailFn)
+            sdf, grad = tail[0](agg, stats, pts, rn, dn)
+        else:
+            sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], stats[:, 65].detach(), pts, rn, dn, True)
         return composite(P, agg, sdf, grad, col.reshape(rn, dn, 3), stats[:, 65].detach().reshape(rn, dn), qdir, depth, que, (h, w), cfg)
     uv, z, mask, dirv = project(pts, ref['poses'], ref['Ks'], h, w)
     f_ray, rgb, f_img = _gather(ref, uv, mask)
@@ -327,10 +330,13 @@ def render_scenes(P, que, hw, cfg, fine_u, chains):
         geo = [ray_points({'coords': que['coords'][b], 'pose': que['pose'][b], 'K': que['K'][b]}, depth[b]) for b in range(B)]
         pts = torch.cat([g[0] for g in geo])
         qdir = torch.cat([g[1] for g in geo])
-        stats, col = chain(depth)
+        stats, col, *tail = chain(depth)
         stats, col = stats.reshape(-1, 66), col.reshape(-1, 3)
         nval = stats[:, 65].detach()
-        sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], nval, pts, B * rn, d, True)
+        if tail and tail[0] is not None:
+            sdf, grad = tail[0](agg, stats, pts, B * rn, d)
+        else:
+            sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], nval, pts, B * rn, d, True)
         outs = []
         for b in range(B):                                                 # per-scene means / query images
             sl = slice(b * rn, (b + 1) * rn)

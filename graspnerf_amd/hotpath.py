@@ -278,6 +278,34 @@ class HotPath:
                                                ws.numel(), tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_chain_bwd')
         return dcan, dray, dimg
 
+    # ---- per-ray tail of a training render pass (k_ray<true> forward, k_ray_dual_bwd backward) -----------------
+    def render_tail_train(self, ctx, que, depth, colors, cfg):
+        """Right after render_chain_train (same `ctx`): -> sdf [B,rn,dn] (clipped / masked), grad [B,rn,dn,3]."""
+        scene, keep, ws, tws, rn, dn, level = ctx
+        depth = _f32(depth, self.device)
+        rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
+        sdf = torch.empty(scene.B, rn, dn, dtype=torch.float32, device=self.device)
+        grad = torch.empty(scene.B, rn, dn, 3, dtype=torch.float32, device=self.device)
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_render_tail_fwd_train(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
+                                                    _f32(colors, self.device).data_ptr(), sdf.data_ptr(), grad.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), tws.data_ptr(), tws.numel(), self._stream()),
+                   'gnr_render_tail_fwd_train')
+        return sdf, grad
+
+    def ray_tail_dual_bwd(self, level, g, gd, a, nvalid):
+        """Attention / LayerNorm core of the tail's backward incl. the second-order path (ray_tail.attn_core in HIP).
+        g, gd [R,dn,16]; a, nvalid [R,dn] -> gbar, gdbar [R,dn,16], dtail [gnr_ray_tail_grad_floats()]."""
+        g, gd, a, nvalid = (_f32(x, self.device) for x in (g, gd, a, nvalid))
+        R, dn, _ = g.shape
+        gbar, gdbar = torch.empty_like(g), torch.empty_like(g)
+        dtail = torch.empty(self.L.gnr_ray_tail_grad_floats(), dtype=torch.float32, device=self.device)
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_ray_tail_dual_bwd(w.data_ptr(), g.data_ptr(), gd.data_ptr(), a.data_ptr(), nvalid.data_ptr(),
+                                                gbar.data_ptr(), gdbar.data_ptr(), dtail.data_ptr(), R, dn, self._stream()),
+                   'gnr_ray_tail_dual_bwd')
+        return gbar, gdbar, dtail
+
     def set_bwd_weights(self, packed_bwd_coarse, packed_bwd_fine=None):
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
         self.wb = {'coarse': t(packed_bwd_coarse), 'fine': t(packed_bwd_fine)}

@@ -16,6 +16,7 @@ from .backbone import ResUNetLight, CostVolumeInitNet, DefaultVisEncoder, ConvNe
 from .hotpath import HotPath
 from .grasp_head import GraspHead
 from . import autograd_path as _ag
+from . import ray_tail as _rt
 
 
 def _kaiming(mods):
@@ -145,14 +146,45 @@ class _RenderChainFn(torch.autograd.Function):
     def forward(ctx, hot, prep, que, depth, level, cfg, ray_feats, img_feats, *params):     # depth [B,rn,dn]
         stats, colors, hctx = hot.render_chain_train(que, depth, level, cfg, prep)
         ctx.hot, ctx.hctx, ctx.level, ctx.gen = hot, hctx, level, hot.generation
-        return stats, colors                                                # [B,P,66], [B,P,3]
+        # forward of the per-ray tail on the records the chain just left in the workspace (inputs of _RayTailFn)
+        sdf, grad = hot.render_tail_train(hctx, que, depth, colors, cfg)
+        ctx.mark_non_differentiable(sdf, grad)
+        return stats, colors, sdf, grad                                     # [B,P,66], [B,P,3], [B,rn,dn], [B,rn,dn,3]
 
     @staticmethod
-    def backward(ctx, dstats, dcolors):
+    def backward(ctx, dstats, dcolors, _dsdf, _dgrad):
         ctx.hot.check_generation(ctx.gen)
         dcan, dray, dimg = ctx.hot.render_chain_bwd(ctx.hctx, dstats[..., :65].contiguous(), dcolors.contiguous())
         g = _w.split_canonical(dcan, ctx.level)
         return (None, None, None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
+
+
+class _RayTailFn(torch.autograd.Function):
+    """The per-ray tail of one training render pass (geometry_fc on [stats, embed(p)], attention, LayerNorm,
+    out_geometry_fc, clip, and the in-forward gradient of sdf w.r.t. the points; ibrnet.py:485-504).  Forward values are
+    k_ray<true>'s (computed next to the chain, _RenderChainFn); the backward takes dL/d sdf AND dL/d grad: a reverse pass
+    on dual numbers (ray_tail.py) whose attention / LayerNorm core is k_ray_dual_bwd, no double-backward graph.
+    Differentiable inputs: stats [N,66] and the 14 tail parameters of the level (ray_tail.TAIL_KEYS order)."""
+
+    @staticmethod
+    def forward(ctx, hot, level, agg, pts, rn, dn, sdf, grad, hip_core, stats, *params):
+        ctx.save_for_backward(stats, pts, *params)
+        ctx.meta = (hot, level, agg, rn, dn, hip_core, hot.generation)
+        return sdf.reshape(rn, dn).clone(), grad.reshape(rn, dn, 3).clone()
+
+    @staticmethod
+    def backward(ctx, a, gamma):
+        hot, level, agg, rn, dn, hip_core, gen = ctx.meta
+        hot.check_generation(gen)
+        stats, pts, *params = ctx.saved_tensors
+        P = {agg + 'agg_impl.' + k: p for k, p in zip(_rt.TAIL_KEYS, params)}
+        a = torch.zeros(rn, dn, device=stats.device) if a is None else a
+        gamma = torch.zeros(rn, dn, 3, device=stats.device) if gamma is None else gamma
+        core = _rt.hip_core(hot, level) if hip_core else _rt.attn_core
+        with torch.no_grad():
+            dstats, G = _rt.tail_backward(P, agg, stats[:, :65], stats[:, 65], pts, rn, dn, a.contiguous(), gamma.contiguous(), core)
+            dstats = torch.cat([dstats, torch.zeros_like(dstats[:, :1])], 1)
+        return (None,) * 9 + (dstats,) + tuple(G[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS)
 
 
 class NeuralRayRenderer(nn.Module):
@@ -265,6 +297,16 @@ class NeuralRayRenderer(nn.Module):
     def _params(self):
         return dict(self.named_parameters())
 
+    def _hip_tail(self, hot, level, sdf, grad, P):
+        """The per-ray tail of a training pass as tail(agg, stats [N,66], pts, rn, dn) -> (sdf, grad) through _RayTailFn,
+        or None (autograd_path.sdf_tail with create_graph) when cfg['hip_ray_tail'] is off.  cfg['hip_ray_tail'] = 'torch'
+        keeps the dual-number backward but runs its attention core in tensor algebra."""
+        mode = self.cfg.get('hip_ray_tail', True)
+        if not mode:
+            return None
+        return lambda agg, stats, pts, rn, dn: _RayTailFn.apply(
+            hot, level, agg, pts, rn, dn, sdf, grad, mode != 'torch', stats, *[P[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS])
+
     def _render_autograd(self, que, ref, _prep=None):
         """renderer.py:201-220 with autograd: ray chunks of ray_batch_num, per-chunk random samples, outputs
         concatenated along the ray axis (the [1,1] scalars become [1,n_chunks]).  On the GPU the per-view chain of every
@@ -292,9 +334,9 @@ class NeuralRayRenderer(nn.Module):
                     keys = [P[k] for k, _ in _w.level_keys(level)]
 
                     def run(depth):
-                        st, co = _RenderChainFn.apply(hot, prep, bq, depth.detach()[None], level, rc, ref['ray_feats'][None],
-                                                      ref['img_feats'][None], *keys)
-                        return st[0], co[0]
+                        st, co, sdf, grad = _RenderChainFn.apply(hot, prep, bq, depth.detach()[None], level, rc,
+                                                                 ref['ray_feats'][None], ref['img_feats'][None], *keys)
+                        return st[0], co[0], self._hip_tail(hot, level, sdf, grad, P)
                     return run
                 chains = (chain_of('coarse'), chain_of('fine'))
             parts.append(_ag.render(P, ref, q, self._render_cfg(), u[0], chains))
@@ -459,7 +501,11 @@ class NeuralRayRenderer(nn.Module):
 
         def chain_of(level):
             keys = [P[k] for k, _ in _w.level_keys(level)]
-            return lambda depth: _RenderChainFn.apply(hot, prep, bq, depth.detach(), level, rc, ray_feats, img_feats, *keys)
+
+            def run(depth):
+                st, co, sdf, grad = _RenderChainFn.apply(hot, prep, bq, depth.detach(), level, rc, ray_feats, img_feats, *keys)
+                return st, co, self._hip_tail(hot, level, sdf, grad, P)
+            return run
         que_b = dict(bq)
         if 'imgs' in ques[0]:
             que_b['imgs'] = torch.cat([q['imgs'] for q in ques])

@@ -191,8 +191,8 @@ int gnr_sample_volume_bwd(const GnrScene* scene, int volume_res, const float* le
                           size_t train_workspace_bytes, int stages, void* stream);
 
 /* Render path for training (hybrid): the per-view chain of one render pass in HIP in both directions; the per-ray tail
- * (geometry_fc with the in-forward SDF gradient, attention, NeuS alpha, compositing: renderer.py:90-108,
- * ibrnet.py:485-504) stays in PyTorch autograd, which supplies d stats / d colours.
+ * (renderer.py:90-108, ibrnet.py:485-504) has its own twin pair below; NeuS alpha / compositing / losses (element-wise on
+ * [rn,dn]) stay in PyTorch autograd, which supplies d stats / d colours.
  *   stats_out [B, rn*dn, 66] = mean(32) var(32) wbar n_valid_views (true scale); colors_out [B, rn*dn, 3]           */
 size_t gnr_render_chain_train_workspace_bytes(const GnrScene* scene, int rn, int dn);
 int gnr_render_chain_fwd_train(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn, const float* level_weights,
@@ -202,6 +202,23 @@ int gnr_render_chain_bwd(const GnrScene* scene, int rn, int dn, const float* lev
                          const float* dstats, const float* dcolors, float* d_canonical, float* d_ray_feats, float* d_img_feats,
                          void* workspace, size_t workspace_bytes, void* train_workspace, size_t train_workspace_bytes,
                          void* stream);
+
+/* Per-ray tail of a training render pass (ibrnet.py:485-504: geometry_fc, positional encoding, 40-token attention,
+ * LayerNorm, out_geometry_fc, clip, and the in-forward gradient of sdf w.r.t. the ray points, create_graph=True).
+ * Forward: gnr_render_tail_fwd_train runs the inference tail kernel on the records gnr_render_chain_fwd_train just left in
+ * `workspace` (call it right after that chain): sdf_out [B,rn,dn], grad_out [B,rn,dn,3].
+ * Backward: with a = dL/d sdf and gamma = dL/d grad the gradients are those of  sum a*sdf + <gamma, grad>  =  a reverse
+ * pass over the tail evaluated on dual numbers (value, derivative along gamma).  gnr_ray_tail_dual_bwd is its attention /
+ * LayerNorm / out_geometry_fc core for a flat list of rays: g, gd [nrays*dn,16] value and tangent of geometry_fc's output,
+ * a, nvalid [nrays*dn] -> gbar, gdbar [nrays*dn,16] and dtail [gnr_ray_tail_grad_floats()] = dWq, dWk, dWv, dWfc [16][16],
+ * dLNw, dLNb [16], d w_eff [16], d b_eff (out_geometry_fc folded into one row; unfolded by the caller).  The two ELU
+ * layers of geometry_fc around it are plain tensor algebra in graspnerf_amd/ray_tail.py.                              */
+int gnr_render_tail_fwd_train(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn, const float* level_weights,
+                              const float* colors, float* sdf_out, float* grad_out, void* workspace, size_t workspace_bytes,
+                              void* train_workspace, size_t train_workspace_bytes, void* stream);
+int gnr_ray_tail_grad_floats(void);
+int gnr_ray_tail_dual_bwd(const float* level_weights, const float* g, const float* gd, const float* a, const float* nvalid,
+                          float* gbar, float* gdbar, float* dtail, int nrays, int dn, void* stream);
 
 /* ---- grasp post-processing on the device -------------------------------------------------
  * Replaces the reference planner's `process` + `select` (src/nr/main.py:23-57, 60-84), which run

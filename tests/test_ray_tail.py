@@ -1,0 +1,140 @@
+"""Per-ray tail of the render path in training: the dual-number backward (graspnerf_amd/ray_tail.py, k_ray_dual_bwd) against
+autograd's double backward of autograd_path.sdf_tail (second order through the in-forward SDF gradient, ibrnet.py:497-504)."""
+import numpy as np
+import pytest
+import torch
+
+from graspnerf_amd import autograd_path as ag, ray_tail as rt, weights
+from graspnerf_amd.synth import make_scene
+
+AGG = 'agg_net.'
+
+
+def _tail_params(weights_np, dtype, device='cpu', agg=AGG):
+    return {agg + 'agg_impl.' + k: torch.from_numpy(weights_np[agg + 'agg_impl.' + k]).to(device=device, dtype=dtype).requires_grad_(True)
+            for k in rt.TAIL_KEYS}
+
+
+def _case(seed, rn, dn, dtype, device='cpu'):
+    g = torch.Generator().manual_seed(seed)
+    N = rn * dn
+    stats = torch.randn(N, 65, generator=g).to(device=device, dtype=dtype)
+    nvalid = torch.randint(0, 4, (N,), generator=g).to(device=device, dtype=dtype)
+    pts = (0.3 * torch.randn(N, 3, generator=g)).to(device=device, dtype=dtype)
+    a = torch.randn(rn, dn, generator=g).to(device=device, dtype=dtype)
+    gamma = torch.randn(rn, dn, 3, generator=g).to(device=device, dtype=dtype)
+    return stats, nvalid, pts, a, gamma
+
+
+def _autograd_reference(P, stats, nvalid, pts, rn, dn, a, gamma, agg=AGG):
+    stats = stats.clone().requires_grad_(True)
+    sdf, grad = ag.sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], nvalid, pts, rn, dn, True)
+    names = list(P)
+    gs = torch.autograd.grad((a * sdf).sum() + (gamma * grad).sum(), [stats] + [P[k] for k in names])
+    return sdf.detach(), grad.detach(), gs[0], dict(zip(names, gs[1:]))
+
+
+def _rel(x, y):
+    return float((x - y).abs().max() / (y.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('rn,dn', [(5, 12), (2, 40)])
+def test_dual_backward_equals_double_backward_fp64(rn, dn, weights_np, monkeypatch):
+    """Exact algebra: every gradient of Phi = <a, sdf> + <gamma, grad> to 1e-12 in float64."""
+    tab = ag.sinusoid_table
+    monkeypatch.setattr(ag, 'sinusoid_table', lambda n, d=16: tab(n, d).double())
+    monkeypatch.setattr(rt, 'sinusoid_table', lambda n, d=16: tab(n, d).double())
+    P = _tail_params(weights_np, torch.float64)
+    stats, nvalid, pts, a, gamma = _case(rn, rn, dn, torch.float64)
+    sdf, _, dstats_ref, G_ref = _autograd_reference(P, stats, nvalid, pts, rn, dn, a, gamma)
+    assert 0 < float((sdf.abs() < 1).double().mean()) < 1 or dn < 40      # both clipped and live samples in the case
+    with torch.no_grad():
+        dstats, G = rt.tail_backward(P, AGG, stats, nvalid, pts, rn, dn, a, gamma)
+    assert _rel(dstats, dstats_ref) < 1e-12
+    for k, g in G_ref.items():
+        assert _rel(G[k], g) < 1e-12, k
+
+
+class _FakeHot:
+    generation = 0
+
+    def check_generation(self, g):
+        assert g == self.generation
+
+
+def test_tail_function_wiring_cpu(weights_np):
+    """_RayTailFn (tensor-algebra core) inside autograd: same gradients as sdf_tail with create_graph, float32."""
+    from graspnerf_amd.renderer import _RayTailFn
+    rn, dn = 4, 16
+    P = _tail_params(weights_np, torch.float32)
+    stats, nvalid, pts, a, gamma = _case(3, rn, dn, torch.float32)
+    sdf_ref, grad_ref, dstats_ref, G_ref = _autograd_reference(P, stats, nvalid, pts, rn, dn, a, gamma)
+    st66 = torch.cat([stats, nvalid[:, None]], 1).requires_grad_(True)
+    sdf, grad = _RayTailFn.apply(_FakeHot(), 'coarse', AGG, pts, rn, dn, sdf_ref, grad_ref, False, st66,
+                                 *[P[AGG + 'agg_impl.' + k] for k in rt.TAIL_KEYS])
+    assert torch.equal(sdf, sdf_ref) and torch.equal(grad, grad_ref)
+    for p in P.values():
+        p.grad = None
+    ((a * sdf).sum() + (gamma * grad).sum()).backward()
+    assert _rel(st66.grad[:, :65], dstats_ref) < 2e-4 and float(st66.grad[:, 65].abs().max()) == 0
+    for k, g in G_ref.items():
+        assert _rel(P[k].grad, g) < 2e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,dn,level', [(33, 40, 'coarse'), (7, 16, 'fine'), (300, 40, 'fine'), (3, 64, 'coarse'), (11, 5, 'coarse')])
+def test_dual_core_kernel_matches_tensor_algebra(R, dn, level, weights_np):
+    """k_ray_dual_bwd through the C ABI against ray_tail.attn_core on the same inputs (masked rows, clipped samples,
+    rays straddling wavefronts, more rays than one workgroup holds)."""
+    from graspnerf_amd.hotpath import HotPath
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    agg = 'agg_net.' if level == 'coarse' else 'fine_agg_net.'
+    P = {k: torch.from_numpy(v).cuda() for k, v in weights_np.items()}
+    W = rt.tail_weights(P, agg)
+    g = torch.Generator().manual_seed(R * dn)
+    gg = torch.randn(R, dn, 16, generator=g).cuda()
+    gd = torch.randn(R, dn, 16, generator=g).cuda()
+    a = torch.randn(R, dn, generator=g).cuda()
+    nvalid = torch.randint(0, 4, (R, dn), generator=g).float().cuda()
+    tb, tdb, G = rt.attn_core(W, gg, gd, a, nvalid)
+    hb, hdb, H = rt.hip_core(hp, level)(W, gg, gd, a, nvalid)
+    torch.cuda.synchronize()
+    assert _rel(hb, tb) < 5e-4 and _rel(hdb, tdb) < 5e-4
+    for k in G:
+        assert _rel(H[k], G[k]) < 1e-3, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('V,rn,dn', [(4, 5, 7), (6, 33, 40)])
+def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
+    """After the HIP chain of a pass: k_ray<true>'s sdf / gradient against sdf_tail on the chain's statistics, then the
+    whole tail backward (HIP core) against autograd's double backward for random upstream (a, gamma)."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    from graspnerf_amd.synth import CONFIGS
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    ref, que = make_scene(70 + V, dict(CONFIGS['cfg1'], V=V, rn=rn))
+    bref, bque = batch_scenes([(ref, que)])
+    prep = hp.prepare(bref, 1, rn, dn)
+    rng = np.random.default_rng(rn)
+    depth = torch.sort(torch.from_numpy(rng.uniform(0.25, 0.75, (rn, dn)).astype(np.float32)), -1)[0].cuda()
+    cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+    bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
+    stats, colors, ctx = hp.render_chain_train(bq, depth[None], 'fine', cfg, prep)
+    sdf, grad = hp.render_tail_train(ctx, bq, depth[None], colors, cfg)
+    agg = 'fine_agg_net.'
+    P = _tail_params(weights_np, torch.float32, 'cuda', agg)
+    q1 = {'coords': bq['coords'][0], 'pose': bq['pose'][0], 'K': bq['K'][0]}
+    pts, _ = ag.ray_points(q1, depth)
+    a = torch.from_numpy(rng.standard_normal((rn, dn)).astype(np.float32)).cuda()
+    gamma = torch.from_numpy(rng.standard_normal((rn, dn, 3)).astype(np.float32)).cuda()
+    st = stats[0]
+    sdf_ref, grad_ref, dstats_ref, G_ref = _autograd_reference(P, st[:, :65], st[:, 65], pts, rn, dn, a, gamma, agg)
+    torch.cuda.synchronize()
+    assert float((sdf[0] - sdf_ref).abs().max()) < 1e-3 * max(1.0, float(sdf_ref.abs().max()))
+    assert _rel(grad[0], grad_ref) < 1e-3
+    with torch.no_grad():
+        dstats, G = rt.tail_backward(P, agg, st[:, :65], st[:, 65], pts, rn, dn, a, gamma, rt.hip_core(hp, 'fine'))
+    torch.cuda.synchronize()
+    assert _rel(dstats, dstats_ref) < 1e-3
+    for k, g in G_ref.items():
+        assert _rel(G[k], g) < 2e-3, k

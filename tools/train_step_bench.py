@@ -36,6 +36,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--scenes', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--warmup', type=int, default=1)
+ap.add_argument('--tail', default='hip', choices=['hip', 'torch', 'autograd'], help='per-ray tail backward: HIP dual-number core, the same in tensor algebra, or autograd double backward')
 a = ap.parse_args()
 world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
 torch.cuda.set_device(local)
@@ -44,6 +45,7 @@ dist = None
 if 'TORCHELASTIC_RUN_ID' in os.environ or world > 1:
     import torch.distributed as dist
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+CFG['hip_ray_tail'] = {'hip': True, 'torch': 'torch', 'autograd': False}[a.tail]
 net = GraspNeRF(CFG)
 syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
 net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
@@ -77,7 +79,7 @@ if rank == 0:
     dt = float(tm)
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-                      'scenes_per_gpu': a.scenes, 'backward': 'HIP kernels for sample_volume, the render passes\' per-view chains and the depth-mean head (csrc/gnr_bwd.inc); torch autograd for the per-ray tail of the render path and the 2D backbones',
+                      'scenes_per_gpu': a.scenes, 'ray_tail': a.tail, 'backward': 'HIP kernels for sample_volume, the render passes\' per-view chains and the depth-mean head (csrc/gnr_bwd.inc); torch autograd for the per-ray tail of the render path and the 2D backbones',
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
 if dist is not None:
