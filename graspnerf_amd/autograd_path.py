@@ -100,6 +100,18 @@ def sinusoid_table(n, d=16):
     return torch.from_numpy(tab).float()
 
 
+_PE_CACHE = {}
+
+
+def sinusoid_on(n, like):
+    """sinusoid_table(n) on `like`'s device / dtype, uploaded once (a host->device copy per call would serialise the
+    host with the GPU queue in every training pass)."""
+    key = (n, like.device, like.dtype)
+    if key not in _PE_CACHE:
+        _PE_CACHE[key] = sinusoid_table(n).to(like)
+    return _PE_CACHE[key]
+
+
 def _mean_var(x, w):
     mean = torch.sum(x * w, 0)
     return mean, torch.sum(w * (x - mean[None]) ** 2, 0)
@@ -160,7 +172,7 @@ def sdf_tail(P, agg, mean, var, wbar, nvalid, pts, rn, dn, want_grad, taps=None)
         emb = torch.cat([p] + [fn(p * f) for f in (1.0, 2.0, 4.0) for fn in (torch.sin, torch.cos)], -1)
         z86 = torch.cat([mean, var, wbar, emb], -1)
         g = _tap(taps, 'g16', F.elu(_lin(F.elu(_lin(z86, P, a + 'geometry_fc.0')), P, a + 'geometry_fc.2')))
-        t = g.reshape(rn, dn, 16) + sinusoid_table(dn).to(g.device)[None]
+        t = g.reshape(rn, dn, 16) + sinusoid_on(dn, g)[None]
         heads = lambda name: _lin(t, P, a + 'ray_attention.' + name).reshape(rn, dn, 4, 4).transpose(1, 2)
         q, k, v = heads('w_qs'), heads('w_ks'), heads('w_vs')
         logits = ((q / 2.0) @ k.transpose(2, 3)).masked_fill(~(nvalid.reshape(rn, 1, dn, 1) > 1), -1e9)
@@ -228,8 +240,8 @@ def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
            's': variance.reshape(1, 1), 'render_depth': torch.sum(hp * depth, -1)[None],
            'ray_mask': (torch.sum((nvalid > cfg['ray_mask_view_num']).int(), 1) > cfg['ray_mask_point_num'])[None]}
     if 'imgs' in que:                                                     # renderer.py:125-127
-        gt = F.grid_sample(que['imgs'], (que['coords'] / torch.tensor([w - 1, h - 1], dtype=depth.dtype, device=depth.device)
-                                         * 2 - 1)[None, None], mode='bilinear', padding_mode='zeros', align_corners=True)
+        xy = torch.stack([que['coords'][:, 0] / (w - 1), que['coords'][:, 1] / (h - 1)], -1)     # no host-built tensor: no sync
+        gt = F.grid_sample(que['imgs'], (xy * 2 - 1)[None, None], mode='bilinear', padding_mode='zeros', align_corners=True)
         out['pixel_colors_gt'] = gt[0, :, 0].t()[None]
     return out
 

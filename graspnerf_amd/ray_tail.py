@@ -16,7 +16,7 @@ autograd_path.sdf_tail (tests/test_ray_tail.py)."""
 import torch
 import torch.nn.functional as F
 
-from .autograd_path import sinusoid_table
+from .autograd_path import sinusoid_on
 
 TAIL_KEYS = ('geometry_fc.0.weight', 'geometry_fc.0.bias', 'geometry_fc.2.weight', 'geometry_fc.2.bias',
              'ray_attention.w_qs.weight', 'ray_attention.w_ks.weight', 'ray_attention.w_vs.weight', 'ray_attention.fc.weight',
@@ -46,7 +46,7 @@ def attn_core(W, g, gd, a, nvalid):
     geometry_fc output; a [R,dn]; nvalid [R,dn].
     -> gbar, gdbar [R,dn,16] and a dict of gradients for the entries of W."""
     R, dn, _ = g.shape
-    t = g + sinusoid_table(dn).to(g)[None]
+    t = g + sinusoid_on(dn, g)[None]
     td = gd
     heads = lambda x, w: (x @ w.t()).reshape(R, dn, 4, 4).transpose(1, 2)           # [R,4,dn,4]
     merge = lambda x: x.transpose(1, 2).reshape(R, dn, 16)

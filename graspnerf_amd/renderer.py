@@ -402,12 +402,13 @@ class NeuralRayRenderer(nn.Module):
                                        'fine' if is_fine else 'coarse', self._render_cfg())
         return self._out_dict(o, '', self.fine_agg_net if is_fine else self.agg_net)
 
-    def gen_depth_loss_coords(self, h, w, device):                          # renderer.py:222-228
+    def gen_depth_loss_coords(self, h, w, device, keep_on_host=False):      # renderer.py:222-228
         # default: CPU generator like the reference (same RNG stream -> identical coordinates for a given seed);
-        # cfg['depth_coords_rng'] = 'device' draws on the GPU instead (randperm of 147 456 costs ~15 ms on the host)
+        # cfg['depth_coords_rng'] = 'device' draws on the GPU instead (randperm of 147 456 costs 5-15 ms on the host)
         gen_dev = device if self.cfg.get('depth_coords_rng', 'cpu') == 'device' else 'cpu'
         idx = torch.randperm(h * w, device=gen_dev)[:self.cfg['depth_loss_coords_num']]
-        return torch.stack([idx // w, idx % w], -1).to(device)              # (row, col)
+        rc = torch.stack([idx // w, idx % w], -1)                           # (row, col)
+        return rc if keep_on_host else rc.to(device)
 
     def predict_mean_for_depth_loss(self, ref_imgs_info, _prep=None, is_train=False):       # renderer.py:230-266
         h, w = ref_imgs_info['imgs'].shape[-2:]
@@ -476,6 +477,10 @@ class NeuralRayRenderer(nn.Module):
         h, w = refs[0]['imgs'].shape[-2:]
         rn, fdn, R = ques[0]['coords'].shape[1], c['fine_depth_sample_num'], c['volume_resolution']
         dev = refs[0]['imgs'].device
+        # Host-side order matters (the step is host-bound): the weight re-pack first, while the GPU is idle (its
+        # device<->host copies wait for the queue); then the backbones are queued; the reference's CPU random draws run
+        # while the GPU works on them and reach the device in one pinned, non-blocking copy each.
+        hot = self.hot_for_training()
         imgs = torch.cat([r['imgs'] for r in refs])
         img_feats = self.image_encoder(imgs)
         ray_feats = self.vis_encoder(self.init_net({'imgs': imgs}, None, True), img_feats)
@@ -487,8 +492,11 @@ class NeuralRayRenderer(nn.Module):
             for net in (self.agg_net, self.fine_agg_net):
                 net.train_step_bookkeeping()
             if want_depth:
-                coords.append(self.gen_depth_loss_coords(h, w, dev))
-        hot = self.hot_for_training()
+                coords.append(self.gen_depth_loss_coords(h, w, dev, keep_on_host=True))
+        upload = lambda x: x if x.is_cuda else x.pin_memory().to(dev, non_blocking=True)
+        fine_u = upload(torch.cat(us))
+        if want_depth:
+            coords = upload(torch.stack(coords))                            # [B,8192,2]
         stack = lambda k, src: torch.stack([torch.as_tensor(x[k], dtype=torch.float32, device=dev) for x in src])
         bref = {'imgs': imgs.reshape(B, V, 3, h, w), 'img_feats': img_feats.detach(), 'ray_feats': ray_feats.detach(),
                 'poses': stack('poses', refs), 'Ks': stack('Ks', refs), 'depth_range': stack('depth_range', refs),
@@ -509,10 +517,10 @@ class NeuralRayRenderer(nn.Module):
         que_b = dict(bq)
         if 'imgs' in ques[0]:
             que_b['imgs'] = torch.cat([q['imgs'] for q in ques])
-        outs = _ag.render_scenes(P, que_b, (h, w), rc, torch.cat(us), (chain_of('coarse'), chain_of('fine')))
+        outs = _ag.render_scenes(P, que_b, (h, w), rc, fine_u, (chain_of('coarse'), chain_of('fine')))
         vol = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
         if want_depth:
-            xy = torch.stack(coords).to(torch.float32)
+            xy = coords.to(torch.float32)
             mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
                       for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
         for b, o in enumerate(outs):

@@ -37,34 +37,23 @@ class Trainer:
         self.params = [p for p in net.parameters()]
         self.optimizer = torch.optim.Adam(self.params, lr=1e-3)            # lr_common_manager.py:9-13
         self.step_id = 0
-        self._flat = None
 
     def _allreduce_grads(self, n_local):
-        """Sum of per-scene gradients over all ranks / global scene count, through one flat buffer."""
+        """Sum of per-scene gradients over all ranks / global scene count, through one flat buffer: one concatenation,
+        one all-reduce, one multi-tensor copy back (parameters without a gradient on this rank count as zeros)."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        if self._flat is None or self._flat.numel() != n + 1 or self._flat.device != dev:
-            self._flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
-        flat = self._flat
-        flat.zero_()
-        off = 0
         for p in self.params:
-            if p.grad is not None:
-                flat[off:off + p.numel()] = p.grad.reshape(-1)
-            off += p.numel()
-        flat[n] = float(n_local)                                          # scene count rides along
-        if world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        total = flat[n].clamp(min=1.0)
-        off = 0
-        for p in self.params:
-            g = (flat[off:off + p.numel()] / total).reshape(p.shape)
             if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += p.numel()
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in self.params]
+        if world == 1:
+            torch._foreach_div_(grads, float(max(n_local, 1)))
+            return world
+        flat = torch.cat([g.reshape(-1) for g in grads] + [torch.full((1,), float(n_local), dtype=torch.float32, device=dev)])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat = flat[:-1] / flat[-1].clamp(min=1.0)
+        torch._foreach_copy_(grads, [v.reshape(g.shape) for v, g in zip(torch.split(flat, [g.numel() for g in grads]), grads)])
         return world
 
     def step(self, scenes):
@@ -76,7 +65,6 @@ class Trainer:
         for g in self.optimizer.param_groups:
             g['lr'] = lr
         self.optimizer.zero_grad(set_to_none=True)
-        log = {}
         datas = [dict(d, step=self.step_id) for d in scenes]
         outs = None
         if self.batched and hasattr(self.net, 'forward_scenes') and len(datas) > 1:
@@ -90,11 +78,13 @@ class Trainer:
                 terms = train_losses(self.net(data), data)
                 losses.total_loss(terms).backward()                       # accumulates into .grad
                 all_terms.append(terms)
-        for terms in all_terms:
-            for k, v in terms.items():
-                log[k] = log.get(k, 0.0) + float(v.detach().mean()) / len(scenes)
         self._allreduce_grads(len(scenes))
         self.optimizer.step()
         self.step_id += 1
+        # loss terms leave the device in ONE copy after the whole step is queued (a float() per term and scene would
+        # stall the host 80 times in front of the all-reduce and the optimiser)
+        keys = list(all_terms[0])
+        means = torch.stack([torch.stack([t[k].detach().float().mean() for k in keys]) for t in all_terms]).mean(0).tolist()
+        log = dict(zip(keys, means))
         log['lr'] = lr
         return log

@@ -39,11 +39,8 @@ def _rel(x, y):
 
 
 @pytest.mark.parametrize('rn,dn', [(5, 12), (2, 40)])
-def test_dual_backward_equals_double_backward_fp64(rn, dn, weights_np, monkeypatch):
+def test_dual_backward_equals_double_backward_fp64(rn, dn, weights_np):
     """Exact algebra: every gradient of Phi = <a, sdf> + <gamma, grad> to 1e-12 in float64."""
-    tab = ag.sinusoid_table
-    monkeypatch.setattr(ag, 'sinusoid_table', lambda n, d=16: tab(n, d).double())
-    monkeypatch.setattr(rt, 'sinusoid_table', lambda n, d=16: tab(n, d).double())
     P = _tail_params(weights_np, torch.float64)
     stats, nvalid, pts, a, gamma = _case(rn, rn, dn, torch.float64)
     sdf, _, dstats_ref, G_ref = _autograd_reference(P, stats, nvalid, pts, rn, dn, a, gamma)

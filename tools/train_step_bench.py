@@ -37,6 +37,8 @@ ap.add_argument('--scenes', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--warmup', type=int, default=1)
 ap.add_argument('--tail', default='hip', choices=['hip', 'torch', 'autograd'], help='per-ray tail backward: HIP dual-number core, the same in tensor algebra, or autograd double backward')
+ap.add_argument('--coords-rng', default='cpu', choices=['cpu', 'device'], help="depth-loss pixel draw: the reference's CPU randperm stream, or the GPU generator")
+ap.add_argument('--profile', default=None, help='write torch.profiler tables of one extra step to this file')
 a = ap.parse_args()
 world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
 torch.cuda.set_device(local)
@@ -46,6 +48,7 @@ if 'TORCHELASTIC_RUN_ID' in os.environ or world > 1:
     import torch.distributed as dist
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 CFG['hip_ray_tail'] = {'hip': True, 'torch': 'torch', 'autograd': False}[a.tail]
+CFG['depth_coords_rng'] = a.coords_rng
 net = GraspNeRF(CFG)
 syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
 net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
@@ -79,8 +82,18 @@ if rank == 0:
     dt = float(tm)
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-                      'scenes_per_gpu': a.scenes, 'ray_tail': a.tail, 'backward': 'HIP kernels for sample_volume, the render passes\' per-view chains and the depth-mean head (csrc/gnr_bwd.inc); torch autograd for the per-ray tail of the render path and the 2D backbones',
+                      'scenes_per_gpu': a.scenes, 'ray_tail': a.tail, 'depth_coords_rng': a.coords_rng, 'backward': 'HIP kernels for sample_volume, the render passes\' per-view chains and the depth-mean head (csrc/gnr_bwd.inc); torch autograd for the per-ray tail of the render path and the 2D backbones',
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
+if a.profile and rank == 0:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        tr.step(scenes)
+        torch.cuda.synchronize()
+    ka = prof.key_averages()
+    with open(a.profile, 'w') as f:
+        f.write(ka.table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=70))
+        f.write('\n')
+        f.write(ka.table(sort_by='self_cpu_time_total', row_limit=35, max_name_column_width=70))
 if dist is not None:
     dist.destroy_process_group()
