@@ -215,10 +215,29 @@ def ray_points(que, depth):
     rn = depth.shape[0]
     rot = que['pose'][:, :3].t()
     trans = -rot @ que['pose'][:, 3:]
-    cam = torch.inverse(que['K']) @ torch.cat([que['coords'], que['coords'].new_ones(rn, 1)], 1).t()
+    # linalg.inv_ex = torch.inverse without the singularity check (a device->host read per call)
+    cam = torch.linalg.inv_ex(que['K']).inverse @ torch.cat([que['coords'], que['coords'].new_ones(rn, 1)], 1).t()
     d = (rot @ cam + trans - trans).t()
     pts = (trans.t()[:, None] + d[:, None] * depth[..., None]).reshape(-1, 3)
     return pts, -d / torch.linalg.norm(d, dim=1, keepdim=True)
+
+
+class _CumprodPositive(torch.autograd.Function):
+    """torch.cumprod along the last axis for strictly positive factors.  Same forward values; the backward is the
+    closed form autograd itself uses when no factor is zero (reverse cumulative sum of grad*out, divided by the
+    input) -- without its `(input == 0).any()` check, a device->host read in the middle of every backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.cumprod(x, -1)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        w = g * y
+        return (w + torch.sum(w, -1, keepdim=True) - torch.cumsum(w, -1)) / x
 
 
 def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
@@ -232,7 +251,7 @@ def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
     pc = torch.sigmoid((sdf - iter_cos * dists * 0.5) * inv_s)
     nc = torch.sigmoid((sdf + iter_cos * dists * 0.5) * inv_s)
     alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
-    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)
+    T = _CumprodPositive.apply(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1))   # factors >= 1e-10
     hp = alpha * T[:, :-1]
     out = {'sdf_values': sdf[None], 'alpha_values': alpha[None], 'colors_nr': col[None], 'hit_prob_nr': hp[None],
            'pixel_colors_nr': torch.sum(hp[..., None] * col, 1)[None],

@@ -94,7 +94,7 @@ def vgn_loss(vgn_pred, grasp_info, weight=1e-2):
     num = torch.count_nonzero(label)
     pr_m = _quat_to_rot(rot_pred)
     err = torch.min(_geodesic_deg(_quat_to_rot(rots[:, 0]), pr_m), _geodesic_deg(_quat_to_rot(rots[:, 1]), pr_m))
-    out['vgn_rot_err'] = ((label * err).sum() / num)[None] if num else torch.zeros(1, device=label.device)
+    out['vgn_rot_err'] = ((label * err).sum() / num.clamp(min=1))[None]          # 0 when no positive label; no host sync
     return out
 
 

@@ -563,7 +563,7 @@ class GraspNeRF(nn.Module):
     @staticmethod
     def select(out, index):                                                 # renderer.py:305-311
         qual, rot, width = out
-        b = torch.arange(qual.shape[0])
+        b = torch.arange(qual.shape[0], device=qual.device)                 # on the device: a host index tensor is a blocking copy
         i, j, k = index[:, 0], index[:, 1], index[:, 2]
         return qual[b, :, i, j, k].squeeze(), rot[b, :, i, j, k], width[b, :, i, j, k].squeeze()
 

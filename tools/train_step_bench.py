@@ -38,6 +38,7 @@ ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--warmup', type=int, default=1)
 ap.add_argument('--tail', default='hip', choices=['hip', 'torch', 'autograd'], help='per-ray tail backward: HIP dual-number core, the same in tensor algebra, or autograd double backward')
 ap.add_argument('--coords-rng', default='cpu', choices=['cpu', 'device'], help="depth-loss pixel draw: the reference's CPU randperm stream, or the GPU generator")
+ap.add_argument('--sync-debug', action='store_true')
 ap.add_argument('--profile', default=None, help='write torch.profiler tables of one extra step to this file')
 a = ap.parse_args()
 world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
@@ -85,6 +86,12 @@ if rank == 0:
                       'scenes_per_gpu': a.scenes, 'ray_tail': a.tail, 'depth_coords_rng': a.coords_rng, 'backward': 'HIP kernels for sample_volume, the render passes\' per-view chains and the depth-mean head (csrc/gnr_bwd.inc); torch autograd for the per-ray tail of the render path and the 2D backbones',
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
+if a.sync_debug and rank == 0:                      # list every host<->device synchronisation of one step (stderr)
+    import warnings
+    warnings.simplefilter('always')
+    torch.cuda.set_sync_debug_mode(1)
+    tr.step(scenes)
+    torch.cuda.set_sync_debug_mode(0)
 if a.profile and rank == 0:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
