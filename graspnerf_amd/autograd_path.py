@@ -265,6 +265,21 @@ def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
     return out
 
 
+def _scene_outputs(P, agg, sdf, col, o, B, rn):
+    """Per-scene output dicts (renderer.py:110-138 keys) from the batched results of a HIP composite callable."""
+    outs = []
+    var = P[agg + 'deviation_network.variance'].reshape(1, 1)
+    for b in range(B):
+        sl = slice(b * rn, (b + 1) * rn)
+        out = {'sdf_values': sdf[sl][None], 'alpha_values': o['alpha'][sl][None], 'colors_nr': col[sl][None],
+               'hit_prob_nr': o['hit'][sl][None], 'pixel_colors_nr': o['pix'][sl][None], 'sdf_gradient_error': o['gerr'][b:b + 1],
+               's': var, 'render_depth': o['rdepth'][sl][None], 'ray_mask': o['rmask'][sl][None]}
+        if o.get('gt') is not None:
+            out['pixel_colors_gt'] = o['gt'][sl][None]
+        outs.append(out)
+    return outs
+
+
 def render_by_depth(P, ref, que, depth, dec, agg, cfg, chain=None):
     """renderer.py:90-138 for one scene; depth [rn,dn].  que: coords [rn,2], pose [3,4], K [3,3], depth_range [2].
     `chain(depth) -> (stats [rn*dn,66], colours [rn*dn,3][, tail])` replaces the per-view part (everything up to the cross-view
@@ -273,11 +288,15 @@ def render_by_depth(P, ref, que, depth, dec, agg, cfg, chain=None):
     h, w = ref['imgs'].shape[-2:]
     pts, qdir = ray_points(que, depth)
     if chain is not None:
-        stats, col, *tail = chain(depth)
-        if tail and tail[0] is not None:                                   # HIP tail in both directions (renderer._RayTailFn)
-            sdf, grad = tail[0](agg, stats, pts, rn, dn)
+        stats, col, *ex = chain(depth)
+        tail, comp = (ex + [None, None])[:2]
+        if tail is not None:                                               # HIP tail in both directions (renderer._RayTailFn)
+            sdf, grad = tail(agg, stats, pts, rn, dn)
         else:
             sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], stats[:, 65].detach(), pts, rn, dn, True)
+        if comp is not None:                                               # ... and NeuS alpha / compositing (renderer._CompositeFn)
+            col = col.reshape(rn, dn, 3)
+            return _scene_outputs(P, agg, sdf, col, comp(agg, sdf, grad, col, qdir, depth), 1, rn)[0]
         return composite(P, agg, sdf, grad, col.reshape(rn, dn, 3), stats[:, 65].detach().reshape(rn, dn), qdir, depth, que, (h, w), cfg)
     uv, z, mask, dirv = project(pts, ref['poses'], ref['Ks'], h, w)
     f_ray, rgb, f_img = _gather(ref, uv, mask)
@@ -361,13 +380,17 @@ def render_scenes(P, que, hw, cfg, fine_u, chains):
         geo = [ray_points({'coords': que['coords'][b], 'pose': que['pose'][b], 'K': que['K'][b]}, depth[b]) for b in range(B)]
         pts = torch.cat([g[0] for g in geo])
         qdir = torch.cat([g[1] for g in geo])
-        stats, col, *tail = chain(depth)
+        stats, col, *ex = chain(depth)
+        tail, comp = (ex + [None, None])[:2]
         stats, col = stats.reshape(-1, 66), col.reshape(-1, 3)
         nval = stats[:, 65].detach()
-        if tail and tail[0] is not None:
-            sdf, grad = tail[0](agg, stats, pts, B * rn, d)
+        if tail is not None:
+            sdf, grad = tail(agg, stats, pts, B * rn, d)
         else:
             sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], nval, pts, B * rn, d, True)
+        if comp is not None:
+            col = col.reshape(B * rn, d, 3)
+            return _scene_outputs(P, agg, sdf, col, comp(agg, sdf, grad, col, qdir, depth.reshape(B * rn, d)), B, rn)
         outs = []
         for b in range(B):                                                 # per-scene means / query images
             sl = slice(b * rn, (b + 1) * rn)

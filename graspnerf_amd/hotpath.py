@@ -280,18 +280,43 @@ class HotPath:
 
     # ---- per-ray tail of a training render pass (k_ray<true> forward, k_ray_dual_bwd backward) -----------------
     def render_tail_train(self, ctx, que, depth, colors, cfg):
-        """Right after render_chain_train (same `ctx`): -> sdf [B,rn,dn] (clipped / masked), grad [B,rn,dn,3]."""
+        """Right after render_chain_train (same `ctx`): the per-ray tail, NeuS alpha and compositing of the pass (k_ray<true>).
+        -> dict of device tensors: sdf_values, alpha_values, hit_prob_nr [B,rn,dn], sdf_gradient [B,rn,dn,3],
+        pixel_colors_nr [B,rn,3], render_depth [B,rn], ray_mask [B,rn] bool, sdf_gradient_error [B,n_chunks]
+        (+ pixel_colors_gt [B,rn,3] when `que` carries the query images)."""
         scene, keep, ws, tws, rn, dn, level = ctx
         depth = _f32(depth, self.device)
         rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
-        sdf = torch.empty(scene.B, rn, dn, dtype=torch.float32, device=self.device)
-        grad = torch.empty(scene.B, rn, dn, 3, dtype=torch.float32, device=self.device)
+        o_s, o = self._alloc_out(scene.B, rn, dn, 'imgs' in que, True, rays.ray_batch_num or rn)
+        o['colors_nr'] = _f32(colors, self.device).reshape(scene.B, rn, dn, 3)
+        o_s.colors_nr = o['colors_nr'].data_ptr()
+        o_s.depth = None
+        o_s.view_mask = None
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_render_tail_fwd_train(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
-                                                    _f32(colors, self.device).data_ptr(), sdf.data_ptr(), grad.data_ptr(),
+        _lib.check(self.L.gnr_render_tail_fwd_train(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(), C.byref(o_s),
                                                     ws.data_ptr(), ws.numel(), tws.data_ptr(), tws.numel(), self._stream()),
                    'gnr_render_tail_fwd_train')
-        return sdf, grad
+        o['ray_mask'] = o['ray_mask'].bool()
+        o.pop('depth'), o.pop('view_mask')
+        return o
+
+    def composite_bwd(self, level, sdf, grad, col, depth, qdir, dpix, ddepth=None, wgerr=None, dalpha=None, dhit=None):
+        """Backward of NeuS alpha + compositing for R rays (k_composite_bwd): sdf, depth [R,dn], grad, col [R,dn,3],
+        qdir [R,3]; upstream dpix [R,3], ddepth, wgerr [R], dalpha, dhit [R,dn] (None = zero).
+        -> a = dL/d sdf [R,dn], gamma = dL/d grad [R,dn,3], dcol [R,dn,3], dvar [1]."""
+        f = lambda x: None if x is None else _f32(x, self.device)
+        sdf, grad, col, depth, qdir, dpix, ddepth, wgerr, dalpha, dhit = (f(x) for x in (sdf, grad, col, depth, qdir, dpix, ddepth,
+                                                                                        wgerr, dalpha, dhit))
+        R, dn = sdf.shape
+        a, gamma, dcol = torch.empty_like(sdf), torch.empty_like(grad), torch.empty_like(col)
+        dvar = torch.empty(1, dtype=torch.float32, device=self.device)
+        ptr = lambda x: None if x is None else x.data_ptr()
+        w = self.wc if level == 'coarse' else self.wf
+        _lib.check(self.L.gnr_composite_bwd(w.data_ptr(), sdf.data_ptr(), grad.data_ptr(), col.data_ptr(), depth.data_ptr(),
+                                            qdir.data_ptr(), dpix.data_ptr(), ptr(ddepth), ptr(wgerr), ptr(dalpha), ptr(dhit),
+                                            a.data_ptr(), gamma.data_ptr(), dcol.data_ptr(), dvar.data_ptr(), R, dn, self._stream()),
+                   'gnr_composite_bwd')
+        return a, gamma, dcol, dvar
 
     def ray_tail_dual_bwd(self, level, g, gd, a, nvalid):
         """Attention / LayerNorm core of the tail's backward incl. the second-order path (ray_tail.attn_core in HIP).

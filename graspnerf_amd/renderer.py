@@ -146,17 +146,51 @@ class _RenderChainFn(torch.autograd.Function):
     def forward(ctx, hot, prep, que, depth, level, cfg, ray_feats, img_feats, *params):     # depth [B,rn,dn]
         stats, colors, hctx = hot.render_chain_train(que, depth, level, cfg, prep)
         ctx.hot, ctx.hctx, ctx.level, ctx.gen = hot, hctx, level, hot.generation
-        # forward of the per-ray tail on the records the chain just left in the workspace (inputs of _RayTailFn)
-        sdf, grad = hot.render_tail_train(hctx, que, depth, colors, cfg)
-        ctx.mark_non_differentiable(sdf, grad)
-        return stats, colors, sdf, grad                                     # [B,P,66], [B,P,3], [B,rn,dn], [B,rn,dn,3]
+        # forward of the per-ray tail, NeuS alpha and compositing on the records the chain just left in the workspace:
+        # values only, they become the outputs of _RayTailFn / _CompositeFn, which own the backward
+        fw = hot.render_tail_train(hctx, que, depth, colors, cfg)
+        extra = tuple(fw[k] for k in _FW_KEYS) + ((fw['pixel_colors_gt'],) if 'pixel_colors_gt' in fw else ())
+        ctx.mark_non_differentiable(*extra)
+        return (stats, colors) + extra                                      # [B,P,66], [B,P,3], forward values of the pass
 
     @staticmethod
-    def backward(ctx, dstats, dcolors, _dsdf, _dgrad):
+    def backward(ctx, dstats, dcolors, *_):
         ctx.hot.check_generation(ctx.gen)
         dcan, dray, dimg = ctx.hot.render_chain_bwd(ctx.hctx, dstats[..., :65].contiguous(), dcolors.contiguous())
         g = _w.split_canonical(dcan, ctx.level)
         return (None, None, None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
+
+
+_FW_KEYS = ('sdf_values', 'sdf_gradient', 'alpha_values', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth', 'ray_mask',
+            'sdf_gradient_error')
+
+
+class _CompositeFn(torch.autograd.Function):
+    """NeuS alpha + compositing of one training render pass (aggregate_net.py:105-121, render_ops.py:72-80,
+    renderer.py:110-123) for R = B*rn rays.  Forward values are k_ray<true>'s (computed next to the chain); the backward is
+    k_composite_bwd and hands a = dL/d sdf and gamma = dL/d grad to _RayTailFn.  Differentiable inputs: sdf [R,dn],
+    grad [R,dn,3], colours [R,dn,3], deviation_network.variance; outputs alpha, hit_prob [R,dn], pixel colours [R,3],
+    render depth [R], sdf_gradient_error [B,1]."""
+
+    @staticmethod
+    def forward(ctx, hot, level, depth, qdir, fw, sdf, grad, col, variance):
+        ctx.save_for_backward(sdf, grad, col, depth, qdir)
+        ctx.meta = (hot, level, fw['sdf_gradient_error'].shape[0], hot.generation, variance.shape)
+        R, dn = sdf.shape
+        return (fw['alpha_values'].reshape(R, dn).clone(), fw['hit_prob_nr'].reshape(R, dn).clone(),
+                fw['pixel_colors_nr'].reshape(R, 3).clone(), fw['render_depth'].reshape(R).clone(), fw['sdf_gradient_error'].clone())
+
+    @staticmethod
+    def backward(ctx, dalpha, dhit, dpix, ddepth, dgerr):
+        hot, level, B, gen, vshape = ctx.meta
+        hot.check_generation(gen)
+        sdf, grad, col, depth, qdir = ctx.saved_tensors
+        R, dn = sdf.shape
+        if dpix is None:
+            dpix = torch.zeros(R, 3, device=sdf.device)
+        wgerr = None if dgerr is None else (dgerr.reshape(B, -1)[:, 0] / float((R // B) * dn)).repeat_interleave(R // B)
+        a, gamma, dcol, dvar = hot.composite_bwd(level, sdf, grad, col, depth, qdir, dpix, ddepth, wgerr, dalpha, dhit)
+        return None, None, None, None, None, a, gamma, dcol, dvar.reshape(vshape)
 
 
 class _RayTailFn(torch.autograd.Function):
@@ -297,20 +331,35 @@ class NeuralRayRenderer(nn.Module):
     def _params(self):
         return dict(self.named_parameters())
 
-    def _hip_tail(self, hot, level, sdf, grad, P):
-        """The per-ray tail of a training pass as tail(agg, stats [N,66], pts, rn, dn) -> (sdf, grad) through _RayTailFn,
-        or None (autograd_path.sdf_tail with create_graph) when cfg['hip_ray_tail'] is off.  cfg['hip_ray_tail'] = 'torch'
-        keeps the dual-number backward but runs its attention core in tensor algebra."""
+    def _hip_pass(self, hot, level, extra, P):
+        """What follows the per-view chain of a training pass, as callables for autograd_path.render_by_depth / render_scenes:
+        tail(agg, stats [N,66], pts, R, dn) -> (sdf, grad) through _RayTailFn and comp(agg, sdf, grad, col, qdir, depth) ->
+        dict of the pass's outputs for all R rays through _CompositeFn.  `extra` = the forward values _RenderChainFn returned
+        after (stats, colours).  cfg['hip_ray_tail']: True (default) = both in HIP; 'torch' = the dual-number backward with
+        its attention core in tensor algebra; False = autograd_path.sdf_tail / composite (autograd double backward)."""
         mode = self.cfg.get('hip_ray_tail', True)
         if not mode:
-            return None
-        return lambda agg, stats, pts, rn, dn: _RayTailFn.apply(
-            hot, level, agg, pts, rn, dn, sdf, grad, mode != 'torch', stats, *[P[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS])
+            return None, None
+        fw = dict(zip(_FW_KEYS, extra))
+        gt = extra[len(_FW_KEYS)] if len(extra) > len(_FW_KEYS) else None
+
+        def tail(agg, stats, pts, R, dn):
+            return _RayTailFn.apply(hot, level, agg, pts, R, dn, fw['sdf_values'], fw['sdf_gradient'], mode != 'torch', stats,
+                                    *[P[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS])
+
+        def comp(agg, sdf, grad, col, qdir, depth):
+            R = sdf.shape[0]
+            alpha, hit, pix, rdepth, gerr = _CompositeFn.apply(hot, level, depth.contiguous(), qdir.contiguous(), fw, sdf, grad, col,
+                                                               P[agg + 'deviation_network.variance'])
+            return {'alpha': alpha, 'hit': hit, 'pix': pix, 'rdepth': rdepth, 'gerr': gerr, 'rmask': fw['ray_mask'].reshape(R),
+                    'gt': None if gt is None else gt.reshape(R, 3)}
+        return tail, (comp if mode != 'torch' else None)
 
     def _render_autograd(self, que, ref, _prep=None):
         """renderer.py:201-220 with autograd: ray chunks of ray_batch_num, per-chunk random samples, outputs
         concatenated along the ray axis (the [1,1] scalars become [1,n_chunks]).  On the GPU the per-view chain of every
-        pass runs in HIP in both directions (_RenderChainFn); the per-ray tail (second order) stays in autograd."""
+        pass, its per-ray tail (second order, _RayTailFn) and NeuS alpha / compositing (_CompositeFn) run in HIP in both
+        directions; autograd only connects them."""
         c, P = self.cfg, self._params()
         hip = ref['imgs'].is_cuda and c.get('hip_render_backward', True)
         if hip:
@@ -328,15 +377,17 @@ class NeuralRayRenderer(nn.Module):
             chains = None
             if hip:
                 bq = {'coords': q['coords'][None], 'pose': q['pose'][None], 'K': q['K'][None], 'depth_range': q['depth_range'][None]}
+                if 'imgs' in q:
+                    bq['imgs'] = q['imgs']
                 rc = self._render_cfg()
 
                 def chain_of(level, bq=bq, rc=rc):
                     keys = [P[k] for k, _ in _w.level_keys(level)]
 
                     def run(depth):
-                        st, co, sdf, grad = _RenderChainFn.apply(hot, prep, bq, depth.detach()[None], level, rc,
-                                                                 ref['ray_feats'][None], ref['img_feats'][None], *keys)
-                        return st[0], co[0], self._hip_tail(hot, level, sdf, grad, P)
+                        st, co, *extra = _RenderChainFn.apply(hot, prep, bq, depth.detach()[None], level, rc,
+                                                              ref['ray_feats'][None], ref['img_feats'][None], *keys)
+                        return (st[0], co[0]) + self._hip_pass(hot, level, extra, P)
                     return run
                 chains = (chain_of('coarse'), chain_of('fine'))
             parts.append(_ag.render(P, ref, q, self._render_cfg(), u[0], chains))
@@ -506,17 +557,17 @@ class NeuralRayRenderer(nn.Module):
         bq = {'coords': torch.cat([q['coords'] for q in ques]), 'pose': torch.cat([q['poses'] for q in ques]),
               'K': torch.cat([q['Ks'] for q in ques]), 'depth_range': torch.cat([q['depth_range'] for q in ques])}
         rc = self._render_cfg()
+        que_b = dict(bq)
+        if 'imgs' in ques[0]:
+            que_b['imgs'] = torch.cat([q['imgs'] for q in ques])
 
         def chain_of(level):
             keys = [P[k] for k, _ in _w.level_keys(level)]
 
             def run(depth):
-                st, co, sdf, grad = _RenderChainFn.apply(hot, prep, bq, depth.detach(), level, rc, ray_feats, img_feats, *keys)
-                return st, co, self._hip_tail(hot, level, sdf, grad, P)
+                st, co, *extra = _RenderChainFn.apply(hot, prep, que_b, depth.detach(), level, rc, ray_feats, img_feats, *keys)
+                return (st, co) + self._hip_pass(hot, level, extra, P)
             return run
-        que_b = dict(bq)
-        if 'imgs' in ques[0]:
-            que_b['imgs'] = torch.cat([q['imgs'] for q in ques])
         outs = _ag.render_scenes(P, que_b, (h, w), rc, fine_u, (chain_of('coarse'), chain_of('fine')))
         vol = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
         if want_depth:

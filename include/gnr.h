@@ -205,8 +205,9 @@ int gnr_render_chain_bwd(const GnrScene* scene, int rn, int dn, const float* lev
 
 /* Per-ray tail of a training render pass (ibrnet.py:485-504: geometry_fc, positional encoding, 40-token attention,
  * LayerNorm, out_geometry_fc, clip, and the in-forward gradient of sdf w.r.t. the ray points, create_graph=True).
- * Forward: gnr_render_tail_fwd_train runs the inference tail kernel on the records gnr_render_chain_fwd_train just left in
- * `workspace` (call it right after that chain): sdf_out [B,rn,dn], grad_out [B,rn,dn,3].
+ * Forward: gnr_render_tail_fwd_train runs the inference tail kernel (tail + NeuS alpha + compositing) on the records
+ * gnr_render_chain_fwd_train just left in `workspace` (call it right after that chain): out->colors_nr is the INPUT (the
+ * chain's colours), every other non-null member of `out` is written as by gnr_render_by_depth_fwd.
  * Backward: with a = dL/d sdf and gamma = dL/d grad the gradients are those of  sum a*sdf + <gamma, grad>  =  a reverse
  * pass over the tail evaluated on dual numbers (value, derivative along gamma).  gnr_ray_tail_dual_bwd is its attention /
  * LayerNorm / out_geometry_fc core for a flat list of rays: g, gd [nrays*dn,16] value and tangent of geometry_fc's output,
@@ -214,9 +215,18 @@ int gnr_render_chain_bwd(const GnrScene* scene, int rn, int dn, const float* lev
  * dLNw, dLNb [16], d w_eff [16], d b_eff (out_geometry_fc folded into one row; unfolded by the caller).  The two ELU
  * layers of geometry_fc around it are plain tensor algebra in graspnerf_amd/ray_tail.py.                              */
 int gnr_render_tail_fwd_train(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn, const float* level_weights,
-                              const float* colors, float* sdf_out, float* grad_out, void* workspace, size_t workspace_bytes,
+                              GnrRenderOut* out, void* workspace, size_t workspace_bytes,
                               void* train_workspace, size_t train_workspace_bytes, void* stream);
 int gnr_ray_tail_grad_floats(void);
+/* Backward of NeuS alpha + compositing (aggregate_net.py:105-121, render_ops.py:72-80, renderer.py:110-123) for a flat list
+ * of rays, forward values taken from the tensors the forward wrote: sdf [nrays*dn], grad, col [nrays*dn,3], depth
+ * [nrays*dn], qdir [nrays,3].  Upstream: dpix [nrays,3]; ddepth [nrays], wgerr [nrays] (d L / d sum_k (|grad_k|-1)^2 of the
+ * ray), dalpha, dhit [nrays*dn] may be null.  Out: a_out = dL/d sdf, gamma_out = dL/d grad (the upstreams of
+ * gnr_ray_tail_dual_bwd), dcol_out, dvar_out[0] = dL/d deviation_network.variance (all overwritten).               */
+int gnr_composite_bwd(const float* level_weights, const float* sdf, const float* grad, const float* col, const float* depth,
+                      const float* qdir, const float* dpix, const float* ddepth, const float* wgerr, const float* dalpha,
+                      const float* dhit, float* a_out, float* gamma_out, float* dcol_out, float* dvar_out, int nrays, int dn,
+                      void* stream);
 int gnr_ray_tail_dual_bwd(const float* level_weights, const float* g, const float* gd, const float* a, const float* nvalid,
                           float* gbar, float* gdbar, float* dtail, int nrays, int dn, void* stream);
 

@@ -135,3 +135,35 @@ def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
     assert _rel(dstats, dstats_ref) < 1e-3
     for k, g in G_ref.items():
         assert _rel(G[k], g) < 2e-3, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,dn,level', [(70, 40, 'coarse'), (5, 7, 'fine'), (130, 64, 'coarse')])
+def test_composite_backward_kernel(R, dn, level, weights_np):
+    """k_composite_bwd against autograd over autograd_path.composite (NeuS alpha, cumprod compositing, eikonal term) for a
+    random upstream on every output, including the gradient of deviation_network.variance."""
+    from graspnerf_amd.hotpath import HotPath
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    agg = 'agg_net.' if level == 'coarse' else 'fine_agg_net.'
+    key = agg + 'deviation_network.variance'
+    P = {key: torch.from_numpy(np.asarray(weights_np[key])).cuda().requires_grad_(True)}
+    g = torch.Generator().manual_seed(R + dn)
+    rnd = lambda *s: torch.randn(*s, generator=g).cuda()
+    sdf = (0.05 * rnd(R, dn)).requires_grad_(True)
+    grad = rnd(R, dn, 3).requires_grad_(True)
+    col = torch.rand(R, dn, 3, generator=g).cuda().requires_grad_(True)
+    qdir = torch.nn.functional.normalize(rnd(R, 3), dim=1)
+    depth = torch.sort(0.25 + 0.5 * torch.rand(R, dn, generator=g), -1)[0].cuda()
+    nvalid = torch.full((R, dn), 3.0).cuda()
+    cfg = {'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+    out = ag.composite(P, agg, sdf, grad, col, nvalid, qdir, depth, {}, (96, 128), cfg)
+    up = {'pixel_colors_nr': rnd(1, R, 3), 'render_depth': rnd(1, R), 'sdf_gradient_error': rnd(1, 1), 'alpha_values': rnd(1, R, dn),
+          'hit_prob_nr': rnd(1, R, dn)}
+    ref = torch.autograd.grad(sum((out[k] * v).sum() for k, v in up.items()), [sdf, grad, col, P[key]])
+    wg = (up['sdf_gradient_error'][0, 0] / (R * dn)).expand(R).contiguous()
+    a, gamma, dcol, dvar = hp.composite_bwd(level, sdf.detach(), grad.detach(), col.detach(), depth, qdir, up['pixel_colors_nr'][0],
+                                            up['render_depth'][0], wg, up['alpha_values'][0], up['hit_prob_nr'][0])
+    torch.cuda.synchronize()
+    assert 0.05 < float(((out['alpha_values'] > 0) & (out['alpha_values'] < 1)).float().mean())      # unsaturated samples exist
+    for got, want, name in ((a, ref[0], 'd sdf'), (gamma, ref[1], 'd grad'), (dcol, ref[2], 'd colours'), (dvar.reshape(()), ref[3], 'd variance')):
+        assert _rel(got, want) < 1e-3, name

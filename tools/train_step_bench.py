@@ -1,7 +1,8 @@
 """End-to-end train step (BASELINE.json configs[4]): backbones + volumetric path + grasp head + losses, backward, one flat
 gradient all-reduce over RCCL, Adam.  `--scenes` scenes per GPU per step (default 8), full-size scenes (6 views 288x512,
-40^3 volume, 512 rays x (40+40) samples).  sample_volume and the depth-mean head run in HIP in both directions; the
-render path is differentiated by PyTorch autograd over graspnerf_amd/autograd_path.py.
+40^3 volume, 512 rays x (40+40) samples).  The volumetric path runs in HIP in both directions (--tail selects how the
+per-ray tail's second-order backward runs); --coords-rng cpu draws the depth-loss pixels with the reference's CPU
+randperm stream (5-7 ms per scene on the host), device (default) on the GPU.
     python tools/train_step_bench.py [--scenes 8] [--steps 3] [--warmup 1]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py ..."""
 import argparse, json, os, sys, time
@@ -37,12 +38,14 @@ ap.add_argument('--scenes', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--warmup', type=int, default=1)
 ap.add_argument('--tail', default='hip', choices=['hip', 'torch', 'autograd'], help='per-ray tail backward: HIP dual-number core, the same in tensor algebra, or autograd double backward')
-ap.add_argument('--coords-rng', default='cpu', choices=['cpu', 'device'], help="depth-loss pixel draw: the reference's CPU randperm stream, or the GPU generator")
+ap.add_argument('--coords-rng', default='device', choices=['cpu', 'device'], help="depth-loss pixel draw: the reference's CPU randperm stream, or the GPU generator")
 ap.add_argument('--sync-debug', action='store_true')
+ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark: let MIOpen search its convolution solvers')
 ap.add_argument('--profile', default=None, help='write torch.profiler tables of one extra step to this file')
 a = ap.parse_args()
 world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
 torch.cuda.set_device(local)
+torch.backends.cudnn.benchmark = bool(a.miopen_find)
 dev = torch.device('cuda', local)
 dist = None
 if 'TORCHELASTIC_RUN_ID' in os.environ or world > 1:
@@ -83,7 +86,7 @@ if rank == 0:
     dt = float(tm)
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-                      'scenes_per_gpu': a.scenes, 'ray_tail': a.tail, 'depth_coords_rng': a.coords_rng, 'backward': 'HIP kernels for sample_volume, the render passes\' per-view chains and the depth-mean head (csrc/gnr_bwd.inc); torch autograd for the per-ray tail of the render path and the 2D backbones',
+                      'scenes_per_gpu': a.scenes, 'ray_tail': a.tail, 'depth_coords_rng': a.coords_rng, 'miopen_find': bool(a.miopen_find), 'backward': {'hip': 'HIP kernels for sample_volume, the per-view chains and the per-ray tails (second order, dual numbers) of both render passes, the depth-mean head, the grasp head weight gradient; torch autograd for NeuS alpha / compositing / losses, the 2D backbones, the grasp head data gradient', 'torch': 'as hip, the dual-number tail core in tensor algebra', 'autograd': 'as hip, the per-ray tail by autograd double backward'}[a.tail],
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
 if a.sync_debug and rank == 0:                      # list every host<->device synchronisation of one step (stderr)
