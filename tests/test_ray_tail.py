@@ -117,7 +117,8 @@ def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
     cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
     bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
     stats, colors, ctx = hp.render_chain_train(bq, depth[None], 'fine', cfg, prep)
-    sdf, grad = hp.render_tail_train(ctx, bq, depth[None], colors, cfg)
+    fw = hp.render_tail_train(ctx, bq, depth[None], colors, cfg)
+    sdf, grad = fw['sdf_values'], fw['sdf_gradient']
     agg = 'fine_agg_net.'
     P = _tail_params(weights_np, torch.float32, 'cuda', agg)
     q1 = {'coords': bq['coords'][0], 'pose': bq['pose'][0], 'K': bq['K'][0]}
