@@ -1,13 +1,12 @@
 """Differentiable PyTorch statement of the volumetric path, for TRAINING ONLY.
 
-The backward of `sample_volume` and of the depth-mean head is built in HIP (csrc/gnr_bwd.inc).  The render path is not:
-its eikonal and NeuS-alpha terms need the second-order path through the in-forward SDF gradient (`ibrnet.py:497-504`,
-`create_graph=True`).  Until that exists, a train step differentiates the render path through this module with autograd
-on the GPU: same algebra and the same parameter tensors as the kernels (live `nn.Parameter`s of the mirror modules,
-reference state-dict names), nothing detached, the in-forward VJP taken with `create_graph=True`.  It also serves as the
-reference the backward kernels are tested against (`taps`), and as the CPU / fallback path of `sample_volume` in
-training.  Inference and evaluation never come here (`NeuralRayRenderer.forward` routes to the HIP path whenever autograd
-is off).
+On the GPU every piece of the path has a HIP twin pair behind an autograd.Function (renderer.py: _SampleVolumeFn,
+_DepthMeanFn, _RenderChainFn, _RayTailFn, _CompositeFn; csrc/gnr_bwd.inc); this module then only supplies the glue between
+them (ray geometry, fine-depth resampling, the per-scene output dicts).  Its full statement of the math -- same algebra and
+the same parameter tensors as the kernels (live `nn.Parameter`s of the mirror modules, reference state-dict names), nothing
+detached, the in-forward VJP taken with `create_graph=True` (`ibrnet.py:497-504`) -- is the reference the backward kernels
+are tested against (`taps`), the training path off the GPU, and what the cfg['hip_*'] switches fall back to.  Inference and
+evaluation never come here (`NeuralRayRenderer.forward` routes to the HIP path whenever autograd is off).
 
 Layout: one scene per call, view-major flat arrays [V, N, C] with N = rn*dn points.
 ref: src/nr/network/renderer.py:62-220, render_ops.py, dist_decoder.py, aggregate_net.py, ibrnet.py:447-513.

@@ -4,8 +4,9 @@ and `GraspNeRF(cfg).forward / select` with the reference's names, dict schemas, 
 state-dict keys (ref: src/nr/network/renderer.py:13-335), so `src/gd`'s consumers and reference
 checkpoints plug in unchanged.  The 2D backbones and the grasp head are PyTorch-ROCm modules
 (backbone.py); everything between `ray_feats` and `volume` / the render dict runs in the HIP
-kernels behind libgnr.so (hotpath.py).  The kernels are forward-only: with autograd enabled in training mode the
-same parameters are differentiated through autograd_path.py instead.
+kernels behind libgnr.so (hotpath.py).  With autograd enabled in training mode the same kernels run behind
+autograd.Functions whose backward calls the backward twins (csrc/gnr_bwd.inc); off the GPU, or with the
+cfg['hip_*'] switches off, the same parameters are differentiated through autograd_path.py instead.
 """
 import numpy as np
 import torch
@@ -324,8 +325,8 @@ class NeuralRayRenderer(nn.Module):
                 'ray_batch_num': c['ray_batch_num']}
 
     def _use_autograd(self, is_train):
-        """Training (autograd on, parameters trainable) goes through the differentiable PyTorch statement of the path
-        (autograd_path.py); the HIP kernels have no backward yet."""
+        """Training (autograd on, parameters trainable): the HIP twin pairs behind autograd.Functions on the GPU, the
+        differentiable PyTorch statement of the path (autograd_path.py) elsewhere."""
         return bool(is_train) and torch.is_grad_enabled()
 
     def _params(self):

@@ -158,7 +158,7 @@ int gnr_conv3d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
 /* ---- backward twins ------------------------------------------------------------------------
  * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
  * consumed by DepthLoss, loss.py:87-144).  sample_volume and the per-view chain of the render passes follow below;
- * only the per-ray tail of the render path (second order) stays in graspnerf_amd/autograd_path.py.
+ * the render path's twin pairs (per-view chain, per-ray tail, compositing) follow further down.
  *   gnr_pack_weights_bwd: canonical blob -> transposed MFMA fragments [gnr_packed_bwd_floats()]
  *   gnr_depth_mean_bwd:   dmean [B,V,pn,2] -> d_canonical [gnr_canonical_weights_floats()] (ACCUMULATED:
  *                         mean_decoder.{0,2,4}.{weight,bias} entries, state-dict order) and
