@@ -300,6 +300,28 @@ class HotPath:
         o.pop('depth'), o.pop('view_mask')
         return o
 
+    def geo_dual_fwd(self, canon, stats, pts, gamma):
+        """geometry_fc on dual numbers (k_geo_dual_fwd): canon = the level's canonical blob on the device, stats [P,66],
+        pts, gamma [P,3] -> g, gd [P,16] (value / tangent of geometry_fc's output)."""
+        stats, pts, gamma = (_f32(x, self.device) for x in (stats, pts, gamma))
+        P = stats.shape[0]
+        assert stats.shape == (P, 66) and pts.shape == (P, 3) and gamma.shape == (P, 3)
+        g = torch.empty(P, 16, dtype=torch.float32, device=self.device)
+        gd = torch.empty_like(g)
+        _lib.check(self.L.gnr_geo_dual_fwd(canon.data_ptr(), stats.data_ptr(), pts.data_ptr(), gamma.data_ptr(), g.data_ptr(),
+                                           gd.data_ptr(), P, self._stream()), 'gnr_geo_dual_fwd')
+        return g, gd
+
+    def geo_dual_bwd(self, canon, stats, pts, gamma, gbar, gdbar):
+        """-> d stats [P,66] and d_canonical [36958] holding the gradients of geometry_fc.{0,2} (k_geo_dual_bwd)."""
+        stats, pts, gamma, gbar, gdbar = (_f32(x, self.device) for x in (stats, pts, gamma, gbar, gdbar))
+        P = stats.shape[0]
+        dstats = torch.empty(P, 66, dtype=torch.float32, device=self.device)
+        dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.gnr_geo_dual_bwd(canon.data_ptr(), stats.data_ptr(), pts.data_ptr(), gamma.data_ptr(), gbar.data_ptr(),
+                                           gdbar.data_ptr(), dstats.data_ptr(), dcan.data_ptr(), P, self._stream()), 'gnr_geo_dual_bwd')
+        return dstats, dcan
+
     def composite_bwd(self, level, sdf, grad, col, depth, qdir, dpix, ddepth=None, wgerr=None, dalpha=None, dhit=None):
         """Backward of NeuS alpha + compositing for R rays (k_composite_bwd): sdf, depth [R,dn], grad, col [R,dn,3],
         qdir [R,3]; upstream dpix [R,3], ddepth, wgerr [R], dalpha, dhit [R,dn] (None = zero).

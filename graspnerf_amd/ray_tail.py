@@ -120,6 +120,30 @@ def hip_core(hot, level):
     return core
 
 
+def hip_geo(hot, level, canon, split):
+    """geometry_fc's two layers on dual numbers on the device: (fwd, bwd) around the attention core.  canon = the level's
+    canonical blob on the device, split(dcan) -> {state-dict name without the 'nr_net.' prefix: gradient}."""
+    return (lambda st66, pts, gamma: hot.geo_dual_fwd(canon, st66, pts, gamma),
+            lambda st66, pts, gamma, gbar, gdbar: hot.geo_dual_bwd(canon, st66, pts, gamma, gbar, gdbar), split)
+
+
+def _tail_backward_device(P, agg, stats, nvalid, pts, rn, dn, a, gamma, core, geo):
+    fwd, bwd, split = geo
+    pre = agg + 'agg_impl.'
+    st66 = torch.cat([stats, nvalid[:, None]], 1) if stats.shape[1] == 65 else stats
+    gm = gamma.reshape(-1, 3)
+    g, gd = fwd(st66, pts, gm)
+    gbar, gdbar, G = core(tail_weights(P, agg), g.reshape(rn, dn, 16), gd.reshape(rn, dn, 16), a, nvalid.reshape(rn, dn))
+    dstats, dcan = bwd(st66, pts, gm, gbar.reshape(-1, 16), gdbar.reshape(-1, 16))
+    got = split(dcan)
+    grads = {pre + k: got[pre + k] for k in TAIL_KEYS[:4]}
+    for k, name in (('wq', 'w_qs'), ('wk', 'w_ks'), ('wv', 'w_vs'), ('wfc', 'fc')):
+        grads[pre + 'ray_attention.' + name + '.weight'] = G[k]
+    grads[pre + 'ray_attention.layer_norm.weight'], grads[pre + 'ray_attention.layer_norm.bias'] = G['lnw'], G['lnb']
+    grads.update(unfold_out_geometry(P, agg, G['weff'], G['beff']))
+    return dstats[:, :65], grads
+
+
 def tail_weights(P, agg):
     """The tail's parameters under the names attn_core uses (out_geometry_fc folded: two linears, no activation)."""
     a = agg + 'agg_impl.'
@@ -139,10 +163,13 @@ def unfold_out_geometry(P, agg, dweff, dbeff):
             a + 'out_geometry_fc.1.weight': (wa @ dweff + ba * dbeff)[None], a + 'out_geometry_fc.1.bias': dbeff.reshape(1)}
 
 
-def tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, core=attn_core):
+def tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, core=attn_core, geo=None):
     """stats [N,65] = (mean 32, var 32, wbar), nvalid [N], pts [N,3] (N = rn*dn), a [rn,dn], gamma [rn,dn,3].
     -> d stats [N,65] and {state-dict name: gradient} for geometry_fc, ray_attention, out_geometry_fc of `agg`.
-    `core` = attn_core or the HIP kernel's wrapper (same signature)."""
+    `core` = attn_core or the HIP kernel's wrapper (same signature); `geo` = None (the two geometry_fc layers in tensor
+    algebra, below) or hip_geo(...): k_geo_dual_fwd / k_geo_dual_bwd."""
+    if geo is not None:
+        return _tail_backward_device(P, agg, stats, nvalid, pts, rn, dn, a, gamma, core, geo)
     pre = agg + 'agg_impl.'
     W1, b1 = P[pre + 'geometry_fc.0.weight'], P[pre + 'geometry_fc.0.bias']
     W2, b2 = P[pre + 'geometry_fc.2.weight'], P[pre + 'geometry_fc.2.bias']

@@ -175,6 +175,7 @@ class _CompositeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hot, level, depth, qdir, fw, sdf, grad, col, variance):
+        assert fw['sdf_gradient_error'].shape[1] == 1, 'one ray chunk per training call (renderer.py:207-215 loops outside)'
         ctx.save_for_backward(sdf, grad, col, depth, qdir)
         ctx.meta = (hot, level, fw['sdf_gradient_error'].shape[0], hot.generation, variance.shape)
         R, dn = sdf.shape
@@ -198,7 +199,7 @@ class _RayTailFn(torch.autograd.Function):
     """The per-ray tail of one training render pass (geometry_fc on [stats, embed(p)], attention, LayerNorm,
     out_geometry_fc, clip, and the in-forward gradient of sdf w.r.t. the points; ibrnet.py:485-504).  Forward values are
     k_ray<true>'s (computed next to the chain, _RenderChainFn); the backward takes dL/d sdf AND dL/d grad: a reverse pass
-    on dual numbers (ray_tail.py) whose attention / LayerNorm core is k_ray_dual_bwd, no double-backward graph.
+    on dual numbers (ray_tail.py): k_geo_dual_fwd -> k_ray_dual_bwd -> k_geo_dual_bwd, no double-backward graph.
     Differentiable inputs: stats [N,66] and the 14 tail parameters of the level (ray_tail.TAIL_KEYS order)."""
 
     @staticmethod
@@ -216,8 +217,9 @@ class _RayTailFn(torch.autograd.Function):
         a = torch.zeros(rn, dn, device=stats.device) if a is None else a
         gamma = torch.zeros(rn, dn, 3, device=stats.device) if gamma is None else gamma
         core = _rt.hip_core(hot, level) if hip_core else _rt.attn_core
+        geo = _rt.hip_geo(hot, level, hot.can_dev[level], lambda d: _w.split_canonical(d, level)) if hip_core else None
         with torch.no_grad():
-            dstats, G = _rt.tail_backward(P, agg, stats[:, :65], stats[:, 65], pts, rn, dn, a.contiguous(), gamma.contiguous(), core)
+            dstats, G = _rt.tail_backward(P, agg, stats[:, :65], stats[:, 65], pts, rn, dn, a.contiguous(), gamma.contiguous(), core, geo)
             dstats = torch.cat([dstats, torch.zeros_like(dstats[:, :1])], 1)
         return (None,) * 9 + (dstats,) + tuple(G[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS)
 

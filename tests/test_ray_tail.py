@@ -168,3 +168,30 @@ def test_composite_backward_kernel(R, dn, level, weights_np):
     assert 0.05 < float(((out['alpha_values'] > 0) & (out['alpha_values'] < 1)).float().mean())      # unsaturated samples exist
     for got, want, name in ((a, ref[0], 'd sdf'), (gamma, ref[1], 'd grad'), (dcol, ref[2], 'd colours'), (dvar.reshape(()), ref[3], 'd variance')):
         assert _rel(got, want) < 1e-3, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('P_,level', [(700, 'coarse'), (129, 'fine'), (5, 'coarse')])
+def test_geometry_dual_kernels(P_, level, weights_np):
+    """k_geo_dual_fwd / k_geo_dual_bwd (the two ELU layers of geometry_fc on dual numbers) inside tail_backward against the
+    tensor-algebra statement: same d stats and the same gradients for all 14 tail parameters."""
+    from graspnerf_amd.hotpath import HotPath
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    agg = 'agg_net.' if level == 'coarse' else 'fine_agg_net.'
+    canon = torch.from_numpy(weights.canonical_blob(weights_np, level)).cuda()
+    P = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in weights_np.items()}
+    rn, dn = 1, P_
+    if P_ > 64:
+        dn = 7 if P_ % 7 == 0 else 43 if P_ % 43 == 0 else 1
+        rn = P_ // dn
+    if dn < 3:
+        rn, dn = 1, P_
+    stats, nvalid, pts, a, gamma = _case(P_, rn, dn, torch.float32, 'cuda')
+    with torch.no_grad():
+        want_ds, want = rt.tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, rt.hip_core(hp, level))
+        geo = rt.hip_geo(hp, level, canon, lambda d: weights.split_canonical(d, level))
+        got_ds, got = rt.tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, rt.hip_core(hp, level), geo)
+    torch.cuda.synchronize()
+    assert _rel(got_ds, want_ds) < 1e-3
+    for k in want:
+        assert _rel(got[k], want[k]) < 1e-3, k
