@@ -359,11 +359,13 @@ DEV void row_load(const float (&S)[V][SW], int v, float (&R)[SW]) {
 }
 
 #ifndef GNR_CHAIN_THREADS
-#define GNR_CHAIN_THREADS 512     // 8 wavefronts = 2 per SIMD at <= 256 registers; 256 (1 per SIMD, 512 registers) was measured too
+#define GNR_CHAIN_THREADS 512     // 8 wavefronts = 2 per SIMD at 250 registers; 256 (1 per SIMD, 512 registers) was measured too;
+                                  // 768 / 1024 (3 / 4 per SIMD) would spill 356 / 524 B per lane: S[V][20] alone is 120 registers
 #endif
+#define GNR_CHAIN_MIN_BLOCKS (GNR_CHAIN_THREADS >= 1024 ? 1 : GNR_CHAIN_THREADS / 256)
 // SAVE: training forward (writes the states the backward twins need); compiled out of the inference kernels
 template <int V, bool RENDER, bool SAVE = false>
-__global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_THREADS / 256) void k_chain(ChainArgs a) {
+__global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
     // ---- stage the CHAIN section of the packed weights into LDS (once per workgroup)
