@@ -189,7 +189,7 @@ def main():
                                          'traffic_GBps_dominant_kernel': None if recorded_traffic(B) is None else
                                          round(recorded_traffic(B) / (ms * 1e-3) / 1e9, 1)}
         out['roofline']['counters'] = recorded_counters(B)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only (the other ranks would wait)
             out['cpu_baseline'] = cpu_baseline(wnp)
         print(json.dumps(out), flush=True)
     if dist is not None:
