@@ -402,8 +402,6 @@ def render_scenes(P, que, hw, cfg, fine_u, chains):
     coarse = one_pass(depth, 'agg_net.', chains[0])
     hit = torch.cat([o['hit_prob_nr'][0].detach() for o in coarse])
     dr = que['depth_range'][:, None].expand(B, rn, 2).reshape(-1, 2)
-    if callable(fine_u):                                                   # drawn on a helper thread, fetched when first needed
-        fine_u = fine_u()
     fd = sample_fine_depth(depth.reshape(-1, dn), hit, (dr[:, 0:1], dr[:, 1:2]), fdn, fine_u.reshape(-1, fdn).to(dev))
     fine = one_pass(torch.sort(fd, -1)[0].reshape(B, rn, fdn), 'fine_agg_net.', chains[1])
     for o, f in zip(coarse, fine):

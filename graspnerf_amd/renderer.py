@@ -8,8 +8,6 @@ kernels behind libgnr.so (hotpath.py).  With autograd enabled in training mode t
 autograd.Functions whose backward calls the backward twins (csrc/gnr_bwd.inc); off the GPU, or with the
 cfg['hip_*'] switches off, the same parameters are differentiated through autograd_path.py instead.
 """
-import threading
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -534,47 +532,25 @@ class NeuralRayRenderer(nn.Module):
         rn, fdn, R = ques[0]['coords'].shape[1], c['fine_depth_sample_num'], c['volume_resolution']
         dev = refs[0]['imgs'].device
         # Host-side order matters (the step is host-bound): the weight re-pack first, while the GPU is idle (its
-        # device<->host copies wait for the queue); the reference's CPU random draws (a 147 456-element randperm per
-        # scene: 5-7 ms each) run on a helper thread -- same generator, same order -- while this thread queues the
-        # backbones and the coarse render pass, and reach the device in one pinned, non-blocking copy each.
+        # device<->host copies wait for the queue); then the backbones are queued; the reference's CPU random draws run
+        # while the GPU works on them and reach the device in one pinned, non-blocking copy each.
         hot = self.hot_for_training()
-        want_depth = c.get('use_depth_loss', False) and 'true_depth' in refs[0]
-        us, coords = [], []
-
-        failed = []
-
-        def draw():                                                         # the per-scene draw order of forward()
-            try:
-                for _ in range(B):
-                    us.append(torch.rand([1, rn, fdn]))
-                    if want_depth:
-                        coords.append(self.gen_depth_loss_coords(h, w, dev, keep_on_host=True))
-            except BaseException as e:                                      # re-raised on the calling thread at the join
-                failed.append(e)
-        drawer = None
-        if c.get('depth_coords_rng', 'cpu') == 'cpu' and want_depth:
-            drawer = threading.Thread(target=draw)
-            drawer.start()
-        else:
-            draw()
-        for _ in range(B):
-            for net in (self.agg_net, self.fine_agg_net):
-                net.train_step_bookkeeping()
         imgs = torch.cat([r['imgs'] for r in refs])
         img_feats = self.image_encoder(imgs)
         ray_feats = self.vis_encoder(self.init_net({'imgs': imgs}, None, True), img_feats)
         img_feats, ray_feats = img_feats.reshape(B, V, *img_feats.shape[1:]), ray_feats.reshape(B, V, *ray_feats.shape[1:])
+        want_depth = c.get('use_depth_loss', False) and 'true_depth' in refs[0]
+        us, coords = [], []
+        for _ in range(B):                                                  # the per-scene draw order of forward()
+            us.append(torch.rand([1, rn, fdn]))
+            for net in (self.agg_net, self.fine_agg_net):
+                net.train_step_bookkeeping()
+            if want_depth:
+                coords.append(self.gen_depth_loss_coords(h, w, dev, keep_on_host=True))
         upload = lambda x: x if x.is_cuda else x.pin_memory().to(dev, non_blocking=True)
-        drawn = {}
-
-        def fine_u():                                                       # first needed after the coarse pass is queued
-            if 'u' not in drawn:
-                if drawer is not None:
-                    drawer.join()
-                if failed:
-                    raise failed[0]
-                drawn['u'] = upload(torch.cat(us))
-            return drawn['u']
+        fine_u = upload(torch.cat(us))
+        if want_depth:
+            coords = upload(torch.stack(coords))                            # [B,8192,2]
         stack = lambda k, src: torch.stack([torch.as_tensor(x[k], dtype=torch.float32, device=dev) for x in src])
         bref = {'imgs': imgs.reshape(B, V, 3, h, w), 'img_feats': img_feats.detach(), 'ray_feats': ray_feats.detach(),
                 'poses': stack('poses', refs), 'Ks': stack('Ks', refs), 'depth_range': stack('depth_range', refs),
@@ -598,8 +574,6 @@ class NeuralRayRenderer(nn.Module):
         outs = _ag.render_scenes(P, que_b, (h, w), rc, fine_u, (chain_of('coarse'), chain_of('fine')))
         vol = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
         if want_depth:
-            fine_u()                                                        # (joins the helper thread)
-            coords = upload(torch.stack(coords))                            # [B,8192,2]
             xy = coords.to(torch.float32)
             mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
                       for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
