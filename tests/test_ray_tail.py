@@ -195,3 +195,15 @@ def test_geometry_dual_kernels(P_, level, weights_np):
     assert _rel(got_ds, want_ds) < 1e-3
     for k in want:
         assert _rel(got[k], want[k]) < 1e-3, k
+
+
+def test_positive_cumprod_backward_equals_autograd():
+    """autograd_path._CumprodPositive: torch.cumprod's values, and its gradient for strictly positive factors, without the
+    `(x == 0).any()` host read of the stock backward."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(7, 41, generator=g, dtype=torch.float64) + 1e-10).requires_grad_(True)
+    up = torch.randn(7, 41, generator=g, dtype=torch.float64)
+    want, = torch.autograd.grad((torch.cumprod(x, -1) * up).sum(), x)
+    y = ag._CumprodPositive.apply(x)
+    got, = torch.autograd.grad((y * up).sum(), x)
+    assert torch.equal(y, torch.cumprod(x, -1)) and _rel(got, want) < 1e-12
