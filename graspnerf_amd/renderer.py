@@ -162,6 +162,19 @@ class _RenderChainFn(torch.autograd.Function):
         return (None, None, None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
 
 
+_warned_host_training = False
+
+
+def _warn_host_training():
+    global _warned_host_training
+    if not _warned_host_training:
+        _warned_host_training = True
+        import warnings
+        warnings.warn('graspnerf_amd: training forward on host tensors differentiates the PyTorch statement of the path '
+                      '(autograd_path.py, the reference of the backward kernels\' tests); the HIP kernels run for CUDA tensors only',
+                      RuntimeWarning, stacklevel=3)
+
+
 _FW_KEYS = ('sdf_values', 'sdf_gradient', 'alpha_values', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth', 'ray_mask',
             'sdf_gradient_error')
 
@@ -500,6 +513,10 @@ class NeuralRayRenderer(nn.Module):
         ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
         out = {}
         if self._use_autograd(is_train):
+            if not ref['imgs'].is_cuda:
+                # not a fallback of the HIP path (inference has none and raises without a GPU): training on host tensors
+                # runs the PyTorch statement the backward kernels are tested against -- say so, once
+                _warn_host_training()
             prep = self._train_prep(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0) if ref['imgs'].is_cuda else None
         else:
             prep = self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
