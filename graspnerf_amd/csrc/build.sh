@@ -5,4 +5,4 @@
 set -e
 cd "$(dirname "$0")"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -fno-slp-vectorize \
-      -o libgnr.so gnr_kernels.hip gnr_head.hip gnr_post.hip gnr_pack.cpp "$@"
+      -o libgnr.so gnr_kernels.hip gnr_head.hip gnr_post.hip gnr_pack.cpp gnr_host_rng.cpp "$@"

@@ -162,6 +162,21 @@ class _RenderChainFn(torch.autograd.Function):
         return (None, None, None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
 
 
+def randperm_prefix(n, k):
+    """torch.randperm(n)[:k] on the default CPU generator -- same values, same generator state afterwards -- through
+    gnr_host_randperm_prefix (csrc/gnr_host_rng.cpp: k swaps on a sparse identity + skipping the other draws) instead of n
+    random-access swaps.  None when the helper does not know the generator's state layout (caller uses torch.randperm)."""
+    import ctypes
+    from . import _lib
+    st = torch.get_rng_state()
+    out = torch.empty(k, dtype=torch.int64)
+    rc = _lib.lib().gnr_host_randperm_prefix(ctypes.c_void_p(st.data_ptr()), st.numel(), n, k, ctypes.c_void_p(out.data_ptr()))
+    if rc != 0:
+        return None
+    torch.set_rng_state(st)
+    return out
+
+
 _warned_host_training = False
 
 
@@ -473,7 +488,11 @@ class NeuralRayRenderer(nn.Module):
         # default: CPU generator like the reference (same RNG stream -> identical coordinates for a given seed);
         # cfg['depth_coords_rng'] = 'device' draws on the GPU instead (randperm of 147 456 costs 5-15 ms on the host)
         gen_dev = device if self.cfg.get('depth_coords_rng', 'cpu') == 'device' else 'cpu'
-        idx = torch.randperm(h * w, device=gen_dev)[:self.cfg['depth_loss_coords_num']]
+        idx = None
+        if gen_dev == 'cpu':
+            idx = randperm_prefix(h * w, min(self.cfg['depth_loss_coords_num'], h * w))
+        if idx is None:
+            idx = torch.randperm(h * w, device=gen_dev)[:self.cfg['depth_loss_coords_num']]
         rc = torch.stack([idx // w, idx % w], -1)                           # (row, col)
         return rc if keep_on_host else rc.to(device)
 

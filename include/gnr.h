@@ -238,6 +238,14 @@ int gnr_composite_bwd(const float* level_weights, const float* sdf, const float*
 int gnr_ray_tail_dual_bwd(const float* level_weights, const float* g, const float* gd, const float* a, const float* nvalid,
                           float* gbar, float* gdbar, float* dtail, int nrays, int dn, void* stream);
 
+/* ---- host helper ---------------------------------------------------------------------------
+ * The first k entries of torch.randperm(n) on the CPU generator, bit-exact, in O(k + n/624) instead of n random-access swaps:
+ * the reference draws the depth-loss pixels as torch.randperm(h*w)[:8192] (src/nr/network/renderer.py:222-228), 5-15 ms per
+ * scene on the host.  torch_cpu_rng_state = the bytes of torch.get_rng_state() (5056), advanced in place exactly as
+ * torch.randperm(n) would advance the generator; out[k] int64.  Returns GNR_ERR_SHAPE for state layouts / sizes it does not
+ * know (the caller then falls back to torch.randperm).  No device work.                                          */
+int gnr_host_randperm_prefix(unsigned char* torch_cpu_rng_state, long long state_bytes, long long n, int k, long long* out);
+
 /* ---- grasp post-processing on the device -------------------------------------------------
  * Replaces the reference planner's `process` + `select` (src/nr/main.py:23-57, 60-84), which run
  * scipy.ndimage (gaussian_filter sigma=1 mode='nearest'; binary_dilation iterations=2 with mask;
