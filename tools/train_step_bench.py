@@ -1,8 +1,8 @@
 """End-to-end train step (BASELINE.json configs[4]): backbones + volumetric path + grasp head + losses, backward, one flat
 gradient all-reduce over RCCL, Adam.  `--scenes` scenes per GPU per step (default 8), full-size scenes (6 views 288x512,
 40^3 volume, 512 rays x (40+40) samples).  The volumetric path runs in HIP in both directions (--tail selects how the
-per-ray tail's second-order backward runs); --coords-rng cpu draws the depth-loss pixels with the reference's CPU
-randperm stream (5-7 ms per scene on the host), device (default) on the GPU.
+per-ray tail's second-order backward runs); --coords-rng cpu (default) draws the depth-loss pixels with the reference's CPU
+randperm stream (through gnr_host_randperm_prefix), device on the GPU generator.
     python tools/train_step_bench.py [--scenes 8] [--steps 3] [--warmup 1]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py ..."""
 import argparse, json, os, sys, time
@@ -38,7 +38,7 @@ ap.add_argument('--scenes', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--warmup', type=int, default=1)
 ap.add_argument('--tail', default='hip', choices=['hip', 'torch', 'autograd'], help='per-ray tail backward: HIP dual-number core, the same in tensor algebra, or autograd double backward')
-ap.add_argument('--coords-rng', default='device', choices=['cpu', 'device'], help="depth-loss pixel draw: the reference's CPU randperm stream, or the GPU generator")
+ap.add_argument('--coords-rng', default='cpu', choices=['cpu', 'device'], help="depth-loss pixel draw: the reference's CPU randperm stream, or the GPU generator")
 ap.add_argument('--sync-debug', action='store_true')
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark: let MIOpen search its convolution solvers')
 ap.add_argument('--profile', default=None, help='write torch.profiler tables of one extra step to this file')
