@@ -141,7 +141,7 @@ def _tail_backward_device(P, agg, stats, nvalid, pts, rn, dn, a, gamma, core, ge
         grads[pre + 'ray_attention.' + name + '.weight'] = G[k]
     grads[pre + 'ray_attention.layer_norm.weight'], grads[pre + 'ray_attention.layer_norm.bias'] = G['lnw'], G['lnb']
     grads.update(unfold_out_geometry(P, agg, G['weff'], G['beff']))
-    return dstats[:, :65], grads
+    return (dstats[:, :65] if stats.shape[1] == 65 else dstats), grads
 
 
 def tail_weights(P, agg):

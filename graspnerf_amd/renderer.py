@@ -247,8 +247,11 @@ class _RayTailFn(torch.autograd.Function):
         core = _rt.hip_core(hot, level) if hip_core else _rt.attn_core
         geo = _rt.hip_geo(hot, level, hot.can_dev[level], lambda d: _w.split_canonical(d, level)) if hip_core else None
         with torch.no_grad():
-            dstats, G = _rt.tail_backward(P, agg, stats[:, :65], stats[:, 65], pts, rn, dn, a.contiguous(), gamma.contiguous(), core, geo)
-            dstats = torch.cat([dstats, torch.zeros_like(dstats[:, :1])], 1)
+            # the device kernels read / write the 66-column layout directly (column 65 = n_valid, gradient 0)
+            dstats, G = _rt.tail_backward(P, agg, stats if geo is not None else stats[:, :65], stats[:, 65], pts, rn, dn,
+                                          a.contiguous(), gamma.contiguous(), core, geo)
+            if dstats.shape[1] == 65:
+                dstats = torch.cat([dstats, torch.zeros_like(dstats[:, :1])], 1)
         return (None,) * 9 + (dstats,) + tuple(G[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS)
 
 
