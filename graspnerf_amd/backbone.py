@@ -12,6 +12,35 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _InstanceNormFn(torch.autograd.Function):
+    """Instance norm (biased variance, eps inside the rsqrt, affine) with a hand-written backward: the same formula as
+    autograd's, evaluated in 6 reads + 2 writes of the activation instead of the ~13 + 8 the op-by-op graph of
+    var_mean / rsqrt / addcmul costs (the norms of the 2D backbones were ~15 % of a train step's GPU time).
+        dx = A dy + B x + C  per (image, channel), with  A = w rstd,  B = -A rstd <dy, xhat> / HW,  C = -A <dy> / HW - B mean."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        var, mean = torch.var_mean(x, dim=(2, 3), unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + eps)
+        scale = rstd * weight[None, :, None, None]
+        ctx.save_for_backward(x, mean, rstd, weight)
+        return torch.addcmul(bias[None, :, None, None] - mean * scale, x, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, weight = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = dy.contiguous()
+        s1 = dy.sum((2, 3), keepdim=True)                                              # <dy>
+        s2 = torch.bmm(dy.reshape(n * c, 1, h * w), x.reshape(n * c, h * w, 1)).reshape(n, c, 1, 1)      # <dy, x>
+        sxh = rstd * (s2 - mean * s1)                                                  # <dy, xhat>
+        a = weight[None, :, None, None] * rstd
+        b = -a * rstd * sxh / (h * w)
+        dx = torch.addcmul(-a * s1 / (h * w) - b * mean, dy, a)
+        dx.addcmul_(x, b)
+        return dx, sxh.sum(0).reshape(c), s1.sum(0).reshape(c), None
+
+
 class _InstanceNorm(nn.InstanceNorm2d):
     """nn.InstanceNorm2d(affine=True, track_running_stats=False) with the same parameters/keys.  On ROCm
     `torch.instance_norm` goes through a batch-norm path that blocks the host for ~0.23 ms per call (62 calls =
@@ -21,6 +50,8 @@ class _InstanceNorm(nn.InstanceNorm2d):
     def forward(self, x):
         if not x.is_cuda:
             return super().forward(x)
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return _InstanceNormFn.apply(x, self.weight, self.bias, self.eps)          # training: hand-written backward
         var, mean = torch.var_mean(x, dim=(2, 3), unbiased=False, keepdim=True)
         scale = torch.rsqrt(var + self.eps) * self.weight[None, :, None, None]
         return torch.addcmul(self.bias[None, :, None, None] - mean * scale, x, scale)

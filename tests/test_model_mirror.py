@@ -225,3 +225,17 @@ def test_planner_plan_runs_process_and_select_on_device():
         assert np.array_equal(g['index'], idx[p]) and np.array_equal(g['score'], score[p])
         np.testing.assert_allclose(g['pos'], idx[p] * (0.3 / 40))
         np.testing.assert_allclose(g['width'], wd[p] * np.float32(0.3 / 40), rtol=1e-6)
+
+
+def test_instance_norm_function_matches_autograd():
+    """backbone._InstanceNormFn (hand-written backward used in GPU training) against F.instance_norm and gradcheck, float64."""
+    from graspnerf_amd.backbone import _InstanceNormFn
+    g = torch.Generator().manual_seed(0)
+    x = (2.0 + torch.randn(3, 5, 7, 6, generator=g, dtype=torch.float64)).requires_grad_(True)
+    w = torch.randn(5, generator=g, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(5, generator=g, dtype=torch.float64).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda *a: _InstanceNormFn.apply(*a, 1e-5), (x, w, b))
+    y, ref = _InstanceNormFn.apply(x, w, b, 1e-5), torch.nn.functional.instance_norm(x, weight=w, bias=b, eps=1e-5)
+    up = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    got, want = torch.autograd.grad((y * up).sum(), (x, w, b)), torch.autograd.grad((ref * up).sum(), (x, w, b))
+    assert float((y - ref).abs().max()) < 1e-12 and all(float((u - v).abs().max()) < 1e-10 for u, v in zip(got, want))
