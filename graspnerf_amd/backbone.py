@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 class _InstanceNormFn(torch.autograd.Function):
     """Instance norm (biased variance, eps inside the rsqrt, affine) with a hand-written backward: the same formula as
-    autograd's, evaluated in 6 reads + 2 writes of the activation instead of the ~13 + 8 the op-by-op graph of
+    autograd's, evaluated in 7 reads + 3 writes of the activation instead of the ~13 + 8 the op-by-op graph of
     var_mean / rsqrt / addcmul costs (the norms of the 2D backbones were ~15 % of a train step's GPU time).
         dx = A dy + B x + C  per (image, channel), with  A = w rstd,  B = -A rstd <dy, xhat> / HW,  C = -A <dy> / HW - B mean."""
 
@@ -32,7 +32,7 @@ class _InstanceNormFn(torch.autograd.Function):
         n, c, h, w = x.shape
         dy = dy.contiguous()
         s1 = dy.sum((2, 3), keepdim=True)                                              # <dy>
-        s2 = torch.bmm(dy.reshape(n * c, 1, h * w), x.reshape(n * c, h * w, 1)).reshape(n, c, 1, 1)      # <dy, x>
+        s2 = (dy * x).sum((2, 3), keepdim=True)          # <dy, x>  (a batched dot through rocBLAS' bmm took 0.84 ms per layer)
         sxh = rstd * (s2 - mean * s1)                                                  # <dy, xhat>
         a = weight[None, :, None, None] * rstd
         b = -a * rstd * sxh / (h * w)
