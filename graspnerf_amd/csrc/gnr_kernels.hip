@@ -1229,23 +1229,28 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             const float near = __fdiv_rn(-1.f, a.que_dr[b * 2]), far = __fdiv_rn(-1.f, a.que_dr[b * 2 + 1]);
             const float span = __fsub_rn(far, near);
             float* Dn = sc + rt::DN; float* Pd = sc + rt::PD; float* Cd = sc + rt::CD; float* Ce = sc + rt::CE; float* Fd = sc + rt::FD;
-            float hsum = 0.f;
+            // torch.sum (render_ops.py:194) has no defined add order (vectorised cascade on the CPU): the sum is formed in
+            // fp64 and rounded once, i.e. the correctly rounded value every fp32 order is within 1-2 ulp of.
+            // torch.cumsum (render_ops.py:195) on the CPU accumulates fp32 inputs in double and rounds every prefix to
+            // fp32 (at::acc_type<float, false>): reproduced exactly.
+            double hsum_d = 0.0;
 #pragma unroll 8
-            for (int j = 0; j < dn; ++j) hsum = __fadd_rn(hsum, Hp[j]);
+            for (int j = 0; j < dn; ++j) hsum_d += (double)Hp[j];
+            const float hsum = (float)hsum_d;
             if (act) {
                 Dn[i] = __fdiv_rn(__fsub_rn(__fdiv_rn(-1.f, z), near), span);
                 Pd[i] = __fdiv_rn(hp, hsum);
             }
             __syncthreads();
             {
-                float c = 0.f;                                                   // sequential cumsum, same
+                double c = 0.0;
 #pragma unroll 8
-                for (int j = 0; j < dn; ++j) {                                   // add order on every lane
-                    const float pj = Pd[j];
-                    if (j <= i) c = __fadd_rn(c, pj);
+                for (int j = 0; j < dn; ++j) {
+                    const double pj = (double)Pd[j];
+                    if (j <= i) c += pj;
                 }
                 if (act) {
-                    Cd[i + 1] = c;
+                    Cd[i + 1] = (float)c;
                     Ce[i + 1] = (i + 1 < dn) ? __fmul_rn(__fadd_rn(Dn[i + 1], Dn[i]), 0.5f) : Dn[dn - 1];
                     if (i == 0) { Cd[0] = 0.f; Ce[0] = Dn[0]; }
                 }

@@ -70,7 +70,11 @@ def grasps_from_selection(sel, b=0, voxel_size=0.3 / 40, seed=None):
     """Scene b of a GraspSelector result -> numpy dict in the reference's conventions (main.py:79-84,201-209):
     `pos` = voxel index * voxel_size (metres, bbox-local), `quat` normalised (x,y,z,w; scipy Rotation.from_quat),
     `width` in metres, `score`, `index`; permuted with np.random.seed(seed) like the planner when seed is given."""
-    n = min(int(sel['count'][b].item()), sel['index'].shape[1])
+    n = int(sel['count'][b].item())
+    if n > sel['index'].shape[1]:
+        # the reference's select() returns EVERY non-maximum-suppression survivor (main.py:70-84); a truncated list (in
+        # index order, before the seeded permutation) would silently be a different result
+        raise _lib.GnrError(f'{n} grasps selected but the buffers hold {sel["index"].shape[1]}: raise GraspSelector(max_grasps=...)')
     idx = sel['index'][b, :n].cpu().numpy().astype(np.int64)
     quat = sel['quat'][b, :n].cpu().numpy().astype(np.float64)
     quat = quat / np.linalg.norm(quat, axis=1, keepdims=True) if n else quat

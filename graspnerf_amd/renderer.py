@@ -297,11 +297,26 @@ class NeuralRayRenderer(nn.Module):
         self._hot = None
         return super().load_state_dict(*a, **k)
 
+    def _hot_versions(self):
+        """Autograd version counters of the hot-path parameters: every in-place update (optimizer.step, copy_, load_state_dict)
+        bumps them, so a change means the packed copies in the HotPath are stale."""
+        P = self._params()
+        return tuple(P[k]._version for lvl in ('coarse', 'fine') for k, _ in _w.level_keys(lvl))
+
     def hot(self):
+        """The HIP path with weights packed from the CURRENT parameter values: re-packed whenever a parameter was updated in
+        place since the last packing (an eval forward after optimizer.step() must not run on the previous weights)."""
+        ver = self._hot_versions()
         if self._hot is None:
             sd = self.state_dict()
             dev = next(self.parameters()).device
             self._hot = HotPath(_w.pack_state_dict(sd, 'coarse'), _w.pack_state_dict(sd, 'fine'), device=dev)
+            self._hot_ver = ver
+        elif getattr(self, '_hot_ver', None) != ver:
+            sd = self._params()
+            self._hot.wc.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'coarse'))))
+            self._hot.wf.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'fine'))))
+            self._hot_ver = ver
         return self._hot
 
     def hot_for_training(self):
@@ -318,6 +333,7 @@ class NeuralRayRenderer(nn.Module):
             self._hot.wf.copy_(torch.from_numpy(_w.pack(can['fine'])))
         self._hot.set_bwd_weights(_w.pack_bwd(can['coarse']), _w.pack_bwd(can['fine']))
         self._hot.can_dev = can_dev
+        self._hot_ver = self._hot_versions()
         return self._hot
 
     def _train_prep(self, ref_imgs_info, rn=0):
@@ -632,6 +648,11 @@ class GraspNeRF(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = {**self.default_cfg_vgn, **cfg}
+        if self.cfg['nr_initial_training_steps'] or self.cfg['freeze_nr_after_init']:
+            # renderer.py:314-321: both branches call `super().forward(data)` = nn.Module.forward, i.e. they raise in the
+            # reference too (GraspNeRF does not derive from the renderer); nrvgn_sdf.yaml leaves them at their defaults
+            raise NotImplementedError('nr_initial_training_steps / freeze_nr_after_init: dead branches of the reference '
+                                      '(renderer.py:314-321 call nn.Module.forward), not built')
         self.nr_net = NeuralRayRenderer(self.cfg)
         self.vgn_net = ConvNet()                                            # gd.networks.get_network("conv"): parameters
         self._head = None                                                   # HIP kernels built from vgn_net's weights
@@ -648,8 +669,11 @@ class GraspNeRF(nn.Module):
         """gd.networks.ConvNet.forward: HIP implicit-GEMM kernels for inference on the GPU (csrc/gnr_head.hip);
         the PyTorch module (same parameters) when autograd is needed."""
         if volume.is_cuda and not torch.is_grad_enabled():
-            if self._head is None:
+            # the packed copy follows the parameters: optimizer.step() updates them in place (version counters move)
+            ver = tuple(p._version for p in self.vgn_net.parameters())
+            if self._head is None or self._head_ver != ver:
                 self._head = GraspHead(self.vgn_net.state_dict(), device=volume.device)
+                self._head_ver = ver
             return self._head(volume)
         return self.vgn_net(volume)
 

@@ -5,9 +5,10 @@ ref: src/nr/train/trainer.py:142-158 (step), train/lr_common_manager.py:19-29 (E
 
 Scenes are independent, so data parallelism is "every rank takes its scenes, gradients are summed": the only
 collective is a sum all-reduce of one flat fp32 buffer (4.66 M parameters = 18.6 MB), divided by the global scene count.
-Parameters that received no gradient contribute zeros (the NeuS variance only becomes trainable after the first step,
-neus.py:17-18), so the buffer layout is static.  The backward of the volumetric path is PyTorch autograd over
-autograd_path.py in this round (the HIP kernels are forward-only)."""
+Parameters that received no gradient on a rank contribute zeros (a rank with an empty shard, or fix_s > 0 keeping the NeuS
+variance frozen for the first steps, neus.py:17-18), so the buffer layout is static.  On the GPU the volumetric path runs in
+HIP in both directions (renderer.py autograd.Functions over csrc/gnr_bwd.inc); PyTorch autograd connects them with the 2D
+backbones, the grasp head and the losses."""
 import torch
 import torch.distributed as dist
 
@@ -83,6 +84,8 @@ class Trainer:
         self.step_id += 1
         # loss terms leave the device in ONE copy after the whole step is queued (a float() per term and scene would
         # stall the host 80 times in front of the all-reduce and the optimiser)
+        if not all_terms:                                  # empty shard (global batch < world): took part in the all-reduce only
+            return {'lr': lr}
         keys = list(all_terms[0])
         means = torch.stack([torch.stack([t[k].detach().float().mean() for k in keys]) for t in all_terms]).mean(0).tolist()
         log = dict(zip(keys, means))

@@ -384,10 +384,13 @@ def render_by_depth(sd, inp, que, depth, dec, agg, cfg, debug=None):
     return out
 
 
-def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None):
+def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None, details=None):
     """Inverse-CDF resampling in normalised inverse depth.  u=None: eval mode (deterministic midpoints,
     render_ops.py:200-203); u [rn,fdn]: the is_train draws of torch.rand (render_ops.py:204-205).
-    -> fine depth [rn,fdn] (unsorted), inds [rn,fdn] int64.   ref: render_ops.py:172-229."""
+    -> fine depth [rn,fdn] (unsorted), inds [rn,fdn] int64.   ref: render_ops.py:172-229.
+    `details` (dict, tests): receives cdf [rn,dn+1], u, margin = min_j|u - cdf_j| [rn,fdn] (an index can only differ
+    between two implementations whose cdf differ by more than this), den_raw (cdf bin width before the 1e-5 guard) and
+    sens [rn,fdn] = |d depth / d cdf| of every sample (how far a cdf perturbation moves the resampled depth)."""
     near, far = -1 / depth_range[0], -1 / depth_range[1]
     d = (-1 / depth - near) / (far - near)
     centre = torch.cat([d[:, :1], (d[:, 1:] + d[:, :-1]) / 2, d[:, -1:]], -1)   # [rn,dn+1]
@@ -408,6 +411,11 @@ def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None):
     t = (u - c0) / den
     fd = b0 + t * (b1 - b0)
     fd = -1 / (fd * (far - near) + near)
+    if details is not None:
+        details.update(cdf=cdf, u=u, den_raw=c1 - c0, centre=centre,
+                       margin=(u[:, :, None].double() - cdf[:, None, :].double()).abs().amin(-1).float(),
+                       # fd_norm = b0 + (u-c0)/den (b1-b0): |d fd_norm / d c| <= (1 + |t|) |b1-b0| / den;  d z / d fd_norm = z^2 (far-near)
+                       sens=(1 + t.abs()) * (b1 - b0).abs() / den * fd * fd * (far - near).abs())
     return fd, inds
 
 
@@ -436,8 +444,9 @@ def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None, fine_u=
     dbg_f = {} if debug is not None else None
     depth = sample_depth(que['depth_range'], rn, cfg['depth_sample_num'])
     out = render_by_depth(sd, inp, que, depth, 'dist_decoder.', 'agg_net.', cfg, dbg_c)
+    f1 = {} if debug is not None else None
     fd, inds = sample_fine_depth(depth, out['hit_prob_nr'][0], que['depth_range'],
-                                 cfg['fine_depth_sample_num'], fine_u)
+                                 cfg['fine_depth_sample_num'], fine_u, details=f1)
     fdepth = torch.sort(fd, -1)[0]                                         # renderer.py:148
     if fine_depth_override is not None:
         fdepth = fine_depth_override
@@ -449,7 +458,7 @@ def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None, fine_u=
         out['pixel_colors_gt'] = gt
         out['pixel_colors_gt_fine'] = gt
     if debug is not None:
-        debug.update(coarse=dbg_c, fine=dbg_f, fine_inds=inds, fine_depth=fdepth, coarse_depth=depth)
+        debug.update(coarse=dbg_c, fine=dbg_f, fine_inds=inds, fine_depth=fdepth, coarse_depth=depth, f1=f1, fine_depth_unsorted=fd)
     return out
 
 

@@ -9,6 +9,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+PARITY_LOG = []      # every value comparison of the -m gpu parity tests: measured error next to its tolerance
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The measured errors of the GPU parity run go to gpurun_out/parity_errors.json (copied to profiles/ per round)."""
+    if not PARITY_LOG:
+        return
+    import json
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        worst = {}
+        for r in PARITY_LOG:
+            key = r['what'].split(' seed ')[0]
+            if key not in worst or r['max_over_tol'] > worst[key]['max_over_tol']:
+                worst[key] = r
+        json.dump({'comparisons': len(PARITY_LOG), 'worst_per_check': sorted(worst.values(), key=lambda r: -r['max_over_tol'])},
+                  open(os.path.join(out, 'parity_errors.json'), 'w'), indent=1)
+    except OSError:
+        pass
 
 
 def pytest_configure(config):
@@ -33,3 +53,16 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, f'golden_{name}.npz')))
     return load
+
+
+def check_resampling_inds(inds, cdf, G_inds, G_cdf, G_margin, what, noise=2e-7):
+    """Row F1 (render_ops.py:210): a searchsorted index can only differ from the reference's where an edge of the cdf moved
+    across the sample, i.e. where the reference's margin min_j|u - cdf_j| (stored per sample in the fixtures) is not
+    larger than this ray's max_j|cdf_j - cdf_ref_j|.  Everything else must be EQUAL.  -> number of (explained) mismatches."""
+    inds, G_inds = np.asarray(inds).reshape(G_inds.shape), np.asarray(G_inds)
+    dc = np.abs(np.asarray(cdf, np.float64).reshape(G_cdf.shape) - G_cdf).max(-1, keepdims=True)
+    bad = inds != G_inds
+    unexplained = bad & (G_margin > dc + noise)
+    assert not unexplained.any(), (f'{what}: {int(unexplained.sum())} resampling indices differ from the reference away from cdf edges '
+                                   f'(margins {G_margin[unexplained][:5]}, cdf moved by {np.broadcast_to(dc, bad.shape)[unexplained][:5]})')
+    return int(bad.sum())

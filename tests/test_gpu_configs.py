@@ -1,0 +1,147 @@
+"""BASELINE.json configurations and numerical regimes under test on the MI355X (pytest -m gpu), all through the C ABI:
+
+* configs[2]: batch 32 full-size scenes (6 views 288x512, 40^3, 512 rays) in ONE launch -- scene 0 against the reference
+  golden, batched == per-scene bitwise;
+* the full-frame render (renderer.py:201-220): 147 456 rays = 36 chunks of ray_batch_num 4096, every output against the
+  oracle on a strided subset of rays, per-chunk sdf_gradient_error against the kernel's own per-ray gradients;
+* weight regimes a trained checkpoint sits in and seeded-random weights do not: decoder / geometry weights x3 and x0.3
+  (saturated tanh cdfs, softplus > 20 linear branch, clip(sdf, +-1) -> zero VJP seed), NeuS variance in
+  {-1.4, 0, 0.3, 1.4} (inv_s = exp(10 s) hits both clips 1e-6 / 1e6, neus.py:15-19)."""
+import numpy as np
+import pytest
+import torch
+
+from graspnerf_amd import weights
+from graspnerf_amd.synth import make_scene, CONFIGS
+from oracle import graspnerf_oracle as O
+from conftest import PARITY_LOG
+from test_gpu_parity import close, ATOL, ATOL_A, ATOLS
+
+pytestmark = pytest.mark.gpu
+
+VALUE_KEYS = ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth']
+
+
+@pytest.fixture(scope='module')
+def hot(weights_np):
+    from graspnerf_amd.hotpath import HotPath
+    return HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+
+
+def test_batch32_full_size(hot, golden):
+    """BASELINE.json configs[2] as bench.py runs it: 32 scenes per launch."""
+    from graspnerf_amd.hotpath import batch_scenes
+    G = golden('cfg2')
+    scenes = [make_scene(i, 'cfg2') for i in range(32)]
+    bref, bque = batch_scenes(scenes)
+    dev = hot.device
+    bref = {k: torch.from_numpy(v).to(dev) for k, v in bref.items()}
+    bque = {k: torch.from_numpy(v).to(dev) for k, v in bque.items()}
+    prep = hot.prepare(bref, 40, 512, 40)
+    vol, vm = hot.sample_volume(bref, 40, want_mask=True, prepared=prep)
+    co, fi = hot.render(bref, bque, prepared=prep)
+    torch.cuda.synchronize()
+    assert vol.shape == (32, 1, 40, 40, 40)
+    close(vol[0].cpu().numpy(), G['volume'][0], 'B=32 scene 0 volume vs reference golden')
+    gm = np.unpackbits(G['volume_mask_bits']).reshape(6, 1600, 40).astype(bool)
+    mine = vm[0].cpu().numpy()
+    for v in range(6):
+        assert np.array_equal(((mine >> v) & 1).astype(bool).reshape(1600, 40)[:, ::-1], gm[v]), f'view {v} mask'
+    for k in VALUE_KEYS + ['sdf_gradient_error']:
+        close(co[k][0].cpu().numpy(), G['render.' + k][0], f'B=32 scene 0 coarse {k}', atol=ATOLS.get(k, ATOL_A))
+    assert np.array_equal(co['ray_mask'][0].cpu().numpy(), G['render.ray_mask'][0])
+    assert np.array_equal(fi['ray_mask'][0].cpu().numpy(), G['render.ray_mask_fine'][0])
+    # scenes are independent: the batched launch is bitwise the per-scene launch, volume and both render levels
+    for i in (0, 13, 31):
+        r1 = {k: v[i:i + 1].contiguous() for k, v in bref.items()}
+        q1 = {k: v[i:i + 1].contiguous() for k, v in bque.items()}
+        v1 = hot.sample_volume(r1, 40)
+        c1, f1 = hot.render(r1, q1)
+        assert torch.equal(v1[0], vol[i]), f'scene {i} volume'
+        for k in VALUE_KEYS + ['depth', 'ray_mask']:
+            assert torch.equal(c1[k][0], co[k][i]), f'scene {i} coarse {k}'
+            assert torch.equal(f1[k][0], fi[k][i]), f'scene {i} fine {k}'
+
+
+def test_full_frame_render_vs_oracle(hot, weights_np):
+    """renderer.py:201-220 at the planner's size: every pixel of the 288x512 query view, ray_batch_num 4096 -> 36 chunks."""
+    from graspnerf_amd.hotpath import batch_scenes
+    W = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    ref, que = make_scene(0, 'cfg2')
+    H, Wd = ref['imgs'].shape[-2:]
+    ys, xs = np.meshgrid(np.arange(H), np.arange(Wd), indexing='ij')
+    que = dict(que, coords=np.stack([xs, ys], -1).reshape(-1, 2).astype(np.float32))
+    rn = H * Wd
+    bref, bque = batch_scenes([(ref, que)])
+    cfg = {'ray_batch_num': 4096}
+    co, fi, inds = hot.render(bref, bque, cfg, debug=True)
+    torch.cuda.synchronize()
+    nch = (rn + 4095) // 4096
+    assert co['sdf_gradient_error'].shape == (1, nch) and fi['sdf_gradient_error'].shape == (1, nch)
+    for o, lvl in ((co, 'coarse'), (fi, 'fine')):
+        g = o['sdf_gradient'][0].cpu().numpy().astype(np.float64)
+        per_ray = ((np.linalg.norm(g, axis=-1) - 1.0) ** 2).mean(-1)
+        chunk_mean = np.array([per_ray[c * 4096:(c + 1) * 4096].mean() for c in range(nch)])
+        np.testing.assert_allclose(o['sdf_gradient_error'][0].cpu().numpy(), chunk_mean, rtol=2e-5, err_msg=f'{lvl} per-chunk eikonal term')
+        assert np.isfinite(o['sdf_values'].cpu().numpy()).all()
+    sel = np.arange(0, rn, 577)                                  # 256 rays spread over all 36 chunks
+    assert len(np.unique(sel // 4096)) == nch
+    sque = dict(que, coords=que['coords'][sel])
+    dbg = {}
+    ref_o = O.render(W, O.to_torch(ref), O.to_torch(sque), {}, debug=dbg, fine_depth_override=fi['depth'][0, sel].cpu())
+    for k in VALUE_KEYS + ['pixel_colors_gt']:
+        close(co[k][0, sel].cpu().numpy(), ref_o[k].numpy()[0], f'full frame coarse {k}', atol=ATOLS.get(k, ATOL_A))
+        close(fi[k][0, sel].cpu().numpy(), ref_o[k + '_fine'].numpy()[0], f'full frame fine {k}', atol=ATOLS.get(k, ATOL_A))
+    close(co['sdf_gradient'][0, sel].cpu().numpy(), dbg['coarse']['grad'].numpy(), 'full frame coarse sdf gradient', atol=2e-4)
+    close(fi['sdf_gradient'][0, sel].cpu().numpy(), dbg['fine']['grad'].numpy(), 'full frame fine sdf gradient', atol=2e-4)
+    assert np.array_equal(co['ray_mask'][0, sel].cpu().numpy(), ref_o['ray_mask'].numpy()[0])
+    assert np.array_equal(fi['ray_mask'][0, sel].cpu().numpy(), ref_o['ray_mask_fine'].numpy()[0])
+    # the resampler on the kernel's own coarse pass, for the subset
+    fd_o, inds_o = O.sample_fine_depth(co['depth'][0, sel].cpu(), co['hit_prob_nr'][0, sel].cpu(), torch.from_numpy(que['depth_range']), 40,
+                                       details=(det := {}))
+    bad = inds[0, sel].cpu().numpy() != inds_o.numpy()
+    assert not (bad & (det['margin'].numpy() > 5e-7)).any()
+
+
+def _scaled(weights_np, scale=None, variance=None):
+    wn = {k: v.copy() for k, v in weights_np.items()}
+    if scale is not None:
+        for k in wn:
+            if k.endswith('.weight') and any(s in k for s in ('mean_decoder', 'var_decoder', 'aw_decoder', 'geometry_fc', 'out_geometry_fc')):
+                wn[k] = wn[k] * np.float32(scale)
+    if variance is not None:
+        for k in wn:
+            if k.endswith('deviation_network.variance'):
+                wn[k] = np.asarray(variance, np.float32).reshape(wn[k].shape)
+    return wn
+
+
+@pytest.mark.parametrize('scale,variance', [(3.0, None), (0.3, None), (None, -1.4), (None, 0.0), (None, 0.3), (None, 1.4), (3.0, 1.4)])
+def test_weight_regimes(scale, variance, weights_np):
+    """Numerical regimes of trained checkpoints (dist_decoder.py:99-142, aggregate_net.py:105-121, neus.py:15-19, ibrnet.py:494)."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    wn = _scaled(weights_np, scale, variance)
+    hp = HotPath(weights.pack_state_dict(wn, 'coarse'), weights.pack_state_dict(wn, 'fine'))
+    Wt = {k: torch.from_numpy(v) for k, v in wn.items()}
+    ref, que = make_scene(0, 'cfg1')
+    bref, bque = batch_scenes([(ref, que)])
+    tag = f'regime x{scale} s={variance}'
+    vol = hp.sample_volume(bref, 16).cpu().numpy()
+    vol_o = O.sample_volume(Wt, O.to_torch(ref), 16).numpy()
+    if scale == 3.0:
+        assert (np.abs(vol_o) == 1.0).mean() > 0.02, 'regime should saturate clip(sdf, -1, 1)'
+    # |sdf| == 1 is a branch (clip): a pre-clip value within noise of +-1 may land on either side; values are compared all the same
+    close(vol[0], vol_o[0], f'{tag} volume', atol=ATOL * (3 if scale == 3.0 else 1))
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16}
+    co, fi = hp.render(bref, bque, cfg, debug=False)
+    dbg = {}
+    ref_o = O.render(Wt, O.to_torch(ref), O.to_torch(que), cfg, debug=dbg, fine_depth_override=fi['depth'][0].cpu())
+    for k in VALUE_KEYS:
+        a = co[k].cpu().numpy()
+        assert np.isfinite(a).all() and np.isfinite(fi[k].cpu().numpy()).all(), (tag, k)
+        m = 3 if scale == 3.0 else 1
+        close(a, ref_o[k].numpy(), f'{tag} coarse {k}', atol=m * ATOLS.get(k, ATOL_A))
+        close(fi[k].cpu().numpy(), ref_o[k + '_fine'].numpy(), f'{tag} fine {k}', atol=m * ATOLS.get(k, ATOL_A))
+    if variance is not None and abs(variance) == 1.4:
+        inv_s = float(torch.exp(torch.tensor(variance * 10.0)).clip(1e-6, 1e6))
+        assert inv_s in (1e-6, 1e6)

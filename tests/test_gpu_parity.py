@@ -1,10 +1,12 @@
 """Parity of the HIP hot path (through the C ABI, libgnr.so) against the CPU oracle and the
 golden vectors produced by the imported reference.  Needs a real MI355X:  pytest -m gpu
 
-Tolerances (BASELINE.json north_star): 1e-3 relative on SDF / alpha (we use
-|a-b| <= ATOL + RTOL*|b| with RTOL = 1e-3, ATOL = 2e-4 for quantities of O(1) magnitude);
-bit-exact on index-valued outputs (in-image view masks, ray masks, voxel index map, resampling
-indices away from cdf edges)."""
+Tolerances (BASELINE.json north_star): 1e-3 relative on SDF / alpha: |a-b| <= ATOL + RTOL*|b| with RTOL = 1e-3 and
+ATOL = 2e-5 on the volume / sdf (measured 3e-6 .. 3e-5), ATOL_A = 6e-5 on alpha-derived quantities (alpha, hit
+probability, composites: measured <= 5e-5 where alpha ~ 0, where a relative bound says nothing); bit-exact on index-valued outputs
+(in-image view masks, ray masks, voxel index map).  Resampling indices (row F1): EQUAL to the reference's except where a
+cdf edge provably moved across the sample (per-sample margins in the fixtures), and the resampler itself is checked in
+isolation against the oracle on the kernel's own coarse hit probabilities (test_f1_*)."""
 import numpy as np
 import pytest
 import torch
@@ -12,10 +14,12 @@ import torch
 from graspnerf_amd import weights
 from graspnerf_amd.synth import make_scene, CONFIGS
 from oracle import graspnerf_oracle as O
+from conftest import check_resampling_inds, PARITY_LOG
 
 pytestmark = pytest.mark.gpu
 
-RTOL, ATOL = 1e-3, 2e-4
+RTOL, ATOL, ATOL_A = 1e-3, 2e-5, 6e-5
+ATOLS = {'sdf_values': ATOL, 'sdf_gradient_error': ATOL}          # everything else: ATOL_A
 DN = {'cfg1': 16, 'cfg2': 40}
 
 
@@ -23,8 +27,12 @@ def close(a, b, what, rtol=RTOL, atol=ATOL):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64).reshape(a.shape)
     assert not np.isnan(a).any(), f'{what}: NaN'
-    err = np.abs(a - b) - (atol + rtol * np.abs(b))
-    assert err.max() <= 0, f'{what}: max abs diff {np.abs(a - b).max():.3e} exceeds tolerance'
+    if a.size == 0:
+        return
+    err = np.abs(a - b)
+    PARITY_LOG.append({'what': what, 'max_abs': float(err.max()), 'max_over_tol': float((err / (atol + rtol * np.abs(b))).max()),
+                       'atol': atol, 'rtol': rtol, 'n': int(a.size)})
+    assert (err - (atol + rtol * np.abs(b))).max() <= 0, f'{what}: max abs diff {err.max():.3e} exceeds tolerance (atol {atol}, rtol {rtol})'
 
 
 @pytest.fixture(scope='module')
@@ -63,31 +71,62 @@ def test_volume_matches_reference_and_oracle(name, hot, W, golden):
         assert np.array_equal(mv, gm[v]), f'view {v} mask differs'
 
 
+def _f1_check(co, fi, inds, que, fdn, u, what):
+    """Row F1 in isolation (render_ops.py:172-229): the kernel's resampler against the oracle's (= the reference's op sequence)
+    on the KERNEL'S OWN coarse depths and hit probabilities.  Indices must be equal wherever the sample is further than float
+    noise (5e-7: the sum of the pdf normalisation has no defined add order in torch) from a cdf edge; the sorted resampled
+    depths must agree to 1e-6 + the sample's own conditioning |d depth / d cdf| x that noise (sorting is 1-Lipschitz in the
+    sup norm, so the bound of a ray is the largest bound of its samples).  -> the oracle's details (cdf ...)."""
+    det = {}
+    depth, hp = co['depth'][0].cpu(), co['hit_prob_nr'][0].cpu()
+    fd_o, inds_o = O.sample_fine_depth(depth, hp, torch.from_numpy(np.asarray(que['depth_range'])).reshape(-1)[:2], fdn,
+                                       None if u is None else torch.from_numpy(np.asarray(u)), details=det)
+    ii = inds.cpu().numpy()[0]
+    margin = det['margin'].numpy()
+    bad = ii != inds_o.numpy()
+    assert not (bad & (margin > 5e-7)).any(), f'{what}: resampling index differs away from a cdf edge'
+    assert bad.mean() < 2e-3, f'{what}: {bad.sum()} samples within 5e-7 of a cdf edge?'
+    fd = fi['depth'][0].cpu().numpy()
+    assert np.all(np.diff(fd, axis=1) >= 0), f'{what}: fine depths not sorted'
+    # the 1e-5 guard on the bin width (render_ops.py:221) is a branch: a sample whose raw width sits within noise of it
+    # may take the other side in fp32 arithmetic of a different add order -- excluded from the value check, and rare
+    guard = (np.abs(det['den_raw'].numpy() - 1e-5) < 3e-7) | bad
+    tol = 1e-6 + det['sens'].numpy() * 5e-7
+    ray_ok = ~guard.any(1)
+    assert ray_ok.mean() > 0.9, f'{what}: {100 * (1 - ray_ok.mean()):.1f} % of the rays touch the bin-width guard'
+    err = np.abs(fd - np.sort(fd_o.numpy(), -1))
+    worst = (err.max(1) - tol.max(1))[ray_ok]
+    assert worst.max() <= 0, f'{what}: resampled depth off by {err[ray_ok].max():.3e} (bound exceeded by {worst.max():.3e})'
+    return det
+
+
 @pytest.mark.parametrize('name', ['cfg1', 'cfg2'])
 def test_render_matches_reference(name, hot, W, golden):
     G = golden(name)
     dn = DN[name]
     cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn}
     scenes, (bref, bque) = _batched(name)
-    # fine pass teacher-forced on the reference's resampled depths (inverse-CDF resampling is
-    # ill-conditioned where the coarse pdf ~ 0; see oracle.render docstring)
+    # fine pass teacher-forced on the reference's resampled depths: tight VALUE parity of the fine level needs identical
+    # sample positions; the resampler itself is checked exactly below and in test_f1_*
     co, fi, inds = hot.render(bref, bque, cfg, fine_depth_in=G['fine_depth_sorted'][None], debug=True)
     torch.cuda.synchronize()
     for k in ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'pixel_colors_gt',
               'render_depth', 'sdf_gradient_error']:
-        close(co[k].cpu().numpy(), G['render.' + k], 'coarse ' + k)
-        close(fi[k].cpu().numpy(), G['render.' + k + '_fine'], 'fine ' + k)
+        close(co[k].cpu().numpy(), G['render.' + k], 'coarse ' + k, atol=ATOLS.get(k, ATOL_A))
+        close(fi[k].cpu().numpy(), G['render.' + k + '_fine'], 'fine ' + k, atol=ATOLS.get(k, ATOL_A))
     assert np.array_equal(co['ray_mask'].cpu().numpy(), G['render.ray_mask'])
     assert np.array_equal(fi['ray_mask'].cpu().numpy(), G['render.ray_mask_fine'])
-    # resampling indices: exact except where u sits within float noise of a cdf edge
-    ii = inds.cpu().numpy()[0]
-    assert (ii != G['fine_inds']).mean() <= 2e-3
+    # resampling indices vs the REFERENCE: equal except where a cdf edge moved across the sample
+    det = _f1_check(co, hot.render(bref, bque, cfg)[1], inds, scenes[0][1], dn, None, f'{name} F1')
+    n_bad = check_resampling_inds(inds.cpu().numpy()[0], det['cdf'].numpy(), G['fine_inds'], G['fine_cdf'], G['fine_inds_margin'],
+                                  f'{name} inds vs reference')
+    assert n_bad <= (G['fine_inds_margin'] < 3e-5).sum()
     # SDF gradient (the in-forward VJP) against the oracle's autograd
     dbo = {}
     O.render(W, O.to_torch(scenes[0][0]), O.to_torch(scenes[0][1]), cfg, debug=dbo,
              fine_depth_override=torch.from_numpy(G['fine_depth_sorted']))
-    close(co['sdf_gradient'].cpu().numpy()[0], dbo['coarse']['grad'].numpy(), 'coarse sdf gradient', atol=2e-3)
-    close(fi['sdf_gradient'].cpu().numpy()[0], dbo['fine']['grad'].numpy(), 'fine sdf gradient', atol=2e-3)
+    close(co['sdf_gradient'].cpu().numpy()[0], dbo['coarse']['grad'].numpy(), 'coarse sdf gradient', atol=2e-4)
+    close(fi['sdf_gradient'].cpu().numpy()[0], dbo['fine']['grad'].numpy(), 'fine sdf gradient', atol=2e-4)
 
 
 def test_train_mode_render_matches_reference(hot, golden):
@@ -99,31 +138,51 @@ def test_train_mode_render_matches_reference(hot, golden):
     bque = dict(bque, fine_u=G['fine_u'][None])
     co, fi, inds = hot.render(bref, bque, cfg, fine_depth_in=G['fine_depth_sorted'][None], debug=True)
     torch.cuda.synchronize()
-    assert (inds.cpu().numpy()[0] != G['fine_inds']).mean() <= 2e-3
     for k in ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth',
               'sdf_gradient_error']:
         assert co[k].shape[1:] == G['render.' + k].shape[1:], k
-        close(co[k].cpu().numpy(), G['render.' + k], 'coarse ' + k)
-        close(fi[k].cpu().numpy(), G['render.' + k + '_fine'], 'fine ' + k)
+        close(co[k].cpu().numpy(), G['render.' + k], 'coarse ' + k, atol=ATOLS.get(k, ATOL_A))
+        close(fi[k].cpu().numpy(), G['render.' + k + '_fine'], 'fine ' + k, atol=ATOLS.get(k, ATOL_A))
     assert co['sdf_gradient_error'].shape == (1, 3)
-    # free-running: the kernel's own resampled + sorted depths
-    co2, fi2 = hot.render(bref, bque, cfg)
-    fd = fi2['depth'].cpu().numpy()[0]
-    assert np.all(np.diff(fd, axis=1) >= 0)
-    assert np.mean(np.abs(fd - G['fine_depth_sorted']) > 1e-3) < 0.02
+    # free-running: the kernel's own resampled + sorted depths on the reference's random draws
+    co2, fi2, inds2 = hot.render(bref, bque, cfg, debug=True)
+    det = _f1_check(co2, fi2, inds2, scenes[0][1], 16, G['fine_u'], 'train-mode F1')
+    check_resampling_inds(inds2.cpu().numpy()[0], det['cdf'].numpy(), G['fine_inds'], G['fine_cdf'], G['fine_inds_margin'],
+                          'train-mode inds vs reference')
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2'])
+def test_f1_resampler_exact_on_margin_scenes(name, hot, golden):
+    """golden_f1.npz: scenes whose every inverse-CDF sample keeps >= 1e-4 (16^3 case) / >= 1e-6 (40^3 case) from every cdf
+    edge of the REFERENCE (tools/make_goldens.py::run_f1, SURVEY H2).  End to end and free-running (no teacher forcing):
+    the kernel's indices are the reference's unless its cdf is further than the margin away, and the resampler is
+    checked in isolation on the kernel's own coarse pass."""
+    G = {k.split('.', 1)[1]: v for k, v in golden('f1').items() if k.startswith(name + '.')}
+    dn = DN[name]
+    cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn}
+    scenes, (bref, bque) = _batched(name, seeds=(int(G['seed']),))
+    co, fi, inds = hot.render(bref, bque, cfg, debug=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(co['depth'][0].cpu().numpy(), G['depth']), 'coarse depths (S1) are bit-exact'
+    close(co['hit_prob_nr'][0].cpu().numpy(), G['hit_prob'], 'coarse hit_prob', atol=ATOL_A)
+    det = _f1_check(co, fi, inds, scenes[0][1], dn, None, f'f1 {name}')
+    dc = np.abs(det['cdf'].numpy() - G['cdf']).max()
+    n_bad = check_resampling_inds(inds.cpu().numpy()[0], det['cdf'].numpy(), G['inds'], G['cdf'], G['margin'], f'f1 {name} vs reference')
+    if dc < G['margin'].min():
+        assert n_bad == 0, f'{name}: cdf within {dc:.2e} of the reference, margin {G["margin"].min():.2e}, yet {n_bad} indices differ'
+    if name == 'cfg1':
+        assert dc < 1e-4 and n_bad == 0, f'16^3 margin scene: every index must be the reference\'s (cdf off by {dc:.2e})'
 
 
 def test_free_running_fine_depths(hot, golden):
-    """End to end (no teacher forcing): resampled depths agree with the reference except on the
-    ill-conditioned samples; sorted ascending; inside the depth range."""
-    G = golden('cfg2')
+    """End to end (no teacher forcing) at full size: resampler exact on the kernel's own coarse pass; depths sorted ascending
+    and inside the depth range."""
     scenes, (bref, bque) = _batched('cfg2')
-    co, fi = hot.render(bref, bque, {})
+    co, fi, inds = hot.render(bref, bque, {}, debug=True)
     torch.cuda.synchronize()
     fd = fi['depth'].cpu().numpy()[0]
-    assert np.all(np.diff(fd, axis=1) >= 0)
-    assert fd.min() >= 0.2 - 1e-4 and fd.max() <= 0.8 + 1e-4
-    assert np.mean(np.abs(fd - G['fine_depth_sorted']) > 1e-3) < 0.02
+    assert fd.min() >= 0.2 - 1e-6 and fd.max() <= 0.8 + 1e-6
+    _f1_check(co, fi, inds, scenes[0][1], 40, None, 'cfg2 free-running')
 
 
 def test_batch_equals_per_scene(hot):
@@ -193,7 +252,7 @@ def test_other_view_counts(V, hot, W):
     ref_o = O.render_by_depth(W, O.to_torch(sc[0]), O.to_torch(sc[1]), depth, 'dist_decoder.', 'agg_net.',
                               O.DEFAULT_RENDER_CFG)
     for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'colors_nr'):
-        close(o[k].cpu().numpy(), ref_o[k].numpy(), f'V={V} {k}')
+        close(o[k].cpu().numpy(), ref_o[k].numpy(), f'V={V} {k}', atol=ATOLS.get(k, ATOL_A))
     assert np.array_equal(o['ray_mask'].cpu().numpy(), ref_o['ray_mask'].numpy())
 
 
@@ -241,7 +300,7 @@ def test_ragged_and_extreme_sizes(res, rn, dn, hot, W):
         ref_o = O.render_by_depth(W, O.to_torch(sc[0]), O.to_torch(sc[1]), depth, 'fine_dist_decoder.', 'fine_agg_net.',
                                   O.DEFAULT_RENDER_CFG)
         for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth'):
-            close(o[k].cpu().numpy()[i], ref_o[k].numpy()[0], f'rn {rn} dn {dn} scene {i} {k}')
+            close(o[k].cpu().numpy()[i], ref_o[k].numpy()[0], f'rn {rn} dn {dn} scene {i} {k}', atol=ATOLS.get(k, ATOL_A))
         assert np.array_equal(o['ray_mask'].cpu().numpy()[i], ref_o['ray_mask'].numpy()[0])
 
 
@@ -282,7 +341,7 @@ def test_random_geometry_sweep(seed, hot, W):
     rays = safe_points({'uv': uv, 'z': z}).reshape(rn, dn).all(1)
     ref_o['pixel_colors_gt'] = O.query_pixel_colors(O.to_torch(que))
     for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'pixel_colors_nr', 'pixel_colors_gt'):
-        close(o[k].cpu().numpy()[0][rays], ref_o[k].numpy()[0][rays], f'seed {seed} {k} {m}', atol=3e-4)
+        close(o[k].cpu().numpy()[0][rays], ref_o[k].numpy()[0][rays], f'seed {seed} {k} {m}', atol=ATOLS.get(k, ATOL_A))
     assert np.array_equal(o['ray_mask'].cpu().numpy()[0][rays], ref_o['ray_mask'].numpy()[0][rays])
 
 

@@ -163,7 +163,8 @@ def test_trainer_with_several_scenes_on_cpu_uses_the_per_scene_loop():
 
 @pytest.mark.gpu
 def test_train_step_on_gpu_matches_reference_gradients():
-    """Same check with the model on the MI355X (autograd path + MIOpen backbones on the device)."""
+    """Same check with the model on the MI355X: the volumetric path in HIP in both directions (renderer.py autograd.Functions over
+    csrc/gnr_bwd.inc), backbones / grasp head / losses under PyTorch autograd."""
     from graspnerf_amd.trainer import train_losses
     from graspnerf_amd import losses
     G = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_step.npz')))
@@ -173,7 +174,7 @@ def test_train_step_on_gpu_matches_reference_gradients():
     terms = train_losses(net(data), data)
     losses.total_loss(terms).backward()
     torch.cuda.synchronize()
-    check_against_golden(net, terms, G, rtol_loss=2e-4, rtol_grad=1e-2)
+    check_against_golden(net, terms, G, rtol_loss=2e-4, rtol_grad=3e-3)
 
 
 @pytest.mark.gpu
@@ -257,3 +258,39 @@ def test_backward_after_another_forward_is_refused():
     with pytest.raises((_lib.GnrError, RuntimeError)):
         l0.backward()
     net.zero_grad(set_to_none=True)
+
+
+
+@pytest.mark.gpu
+def test_eval_after_optimizer_step_uses_the_updated_weights():
+    """The reference trainer validates under eval()+no_grad between optimiser steps (train_valid.py:26): the packed copies of
+    the hot-path weights and of the grasp head must follow optimizer.step() (in-place updates).  An eval forward after a
+    training step equals the eval forward of a fresh model loaded from the trained state dict, bit for bit."""
+    from graspnerf_amd.trainer import Trainer
+    from graspnerf_amd.renderer import GraspNeRF
+    net = build('cuda')
+    data = scene_data('cuda')
+    ev = dict(data, eval=True, full_vol=True)
+    with torch.no_grad():
+        net.eval()
+        torch.manual_seed(5)
+        before = net(ev)                                          # packs the hot path and the grasp head from the initial weights
+    tr = Trainer(net, {'lr_init': 1e-2})
+    torch.manual_seed(6)
+    tr.step([data])
+    with torch.no_grad():
+        net.eval()
+        torch.manual_seed(5)
+        after = net(ev)
+    fresh = GraspNeRF(CFG)
+    fresh.load_state_dict(net.state_dict(), strict=True)
+    fresh = fresh.cuda().eval()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        want = fresh(ev)
+    torch.cuda.synchronize()
+    assert not torch.equal(before['volume'], after['volume']), 'the step should have moved the volume'
+    for k in ('volume', 'sdf_values', 'alpha_values_fine', 'depth_mean', 'depth_mean_fine'):
+        assert torch.equal(after[k], want[k]), k
+    for a, b in zip(after['vgn_pred'], want['vgn_pred']):
+        assert torch.equal(a, b), 'grasp head ran on stale weights'

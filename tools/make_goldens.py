@@ -136,8 +136,16 @@ def run_reference(renderer, net, cfg, ref, que, res):
     out['fine_inds'] = captured['inds'].numpy()[0].astype(np.int64)
     out['fine_depth_sorted'] = captured['fine_depth_sorted'].numpy()[0]
     cdf, u = captured['cdf'].numpy()[0], captured['u'].numpy()[0]
-    out['fine_inds_min_margin'] = np.float32(np.abs(u[:, :, None] - cdf[:, None, :]).min())
+    out['fine_inds_margin'] = inds_margin(cdf, u)          # per sample: min_j |u - cdf_j|
+    out['fine_cdf'] = cdf
+    out['fine_inds_min_margin'] = np.float32(out['fine_inds_margin'].min())
     return out
+
+
+def inds_margin(cdf, u):
+    """cdf [rn,dn+1], u [rn,fdn] -> [rn,fdn] float32: distance of every inverse-CDF sample to the nearest cdf edge.  A
+    searchsorted index can only differ between two implementations where this is below their cdf difference."""
+    return np.abs(u[:, :, None].astype(np.float64) - cdf[:, None, :].astype(np.float64)).min(-1).astype(np.float32)
 
 
 def run_train_mode(renderer, weights):
@@ -158,7 +166,7 @@ def run_train_mode(renderer, weights):
 
     def ss(cdf, u, **kw):
         r = orig_ss(cdf, u, **kw)
-        cap['u'].append(u.clone()); cap['inds'].append(r.clone())
+        cap['u'].append(u.clone()); cap['inds'].append(r.clone()); cap.setdefault('cdf', []).append(cdf.clone())
         return r
 
     def srt(x, *a, **kw):
@@ -176,11 +184,70 @@ def run_train_mode(renderer, weights):
     out['fine_u'] = torch.cat(cap['u'], 1).numpy()[0]
     out['fine_inds'] = torch.cat(cap['inds'], 1).numpy()[0].astype(np.int64)
     out['fine_depth_sorted'] = torch.cat(cap['fds'], 1).numpy()[0]
+    out['fine_cdf'] = torch.cat(cap['cdf'], 1).numpy()[0]
+    out['fine_inds_margin'] = inds_margin(out['fine_cdf'], out['fine_u'])
     out['seed'] = np.int64(7)
     out['ray_batch_num'] = np.int64(24)
     np.savez_compressed(ROOT + '/tests/golden/golden_train_cfg1.npz', **out)
     for k, v in out.items():
         print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
+
+
+class _Stop(Exception):
+    pass
+
+
+def run_f1(renderer, weights, min_margin={'cfg1': 1e-4, 'cfg2': 1e-6}, max_tries=400):
+    """Row F1 in isolation (render_ops.py:172-229): for each shape, the first scene seed >= 1 whose inverse-CDF samples all
+    keep `min_margin` from every cdf edge, so that `inds` must be reproduced EXACTLY by any implementation
+    whose cdf is closer than that to the reference's.  Stores the reference's coarse hit_prob (the resampler's input), its
+    cdf, u, inds, per-sample margins and the resampled depths before and after the sort.  Only the coarse pass runs during
+    the search (the hook on sample_fine_depth stops the forward)."""
+    out = {}
+    for name, res, dn in (('cfg1', 16, 16), ('cfg2', 40, 40)):
+        net, cfg = build_net(renderer, res, dn)
+        load_weights(net, weights)
+        cap = {}
+        orig_sfd, orig_ss = renderer.sample_fine_depth, torch.searchsorted
+
+        def ss(cdf, u, **kw):
+            r = orig_ss(cdf, u, **kw)
+            cap.update(cdf=cdf.clone(), u=u.clone(), inds=r.clone())
+            return r
+
+        def sfd(depth, hit_prob, *a, **k):
+            cap.update(depth=depth.clone(), hit_prob=hit_prob.clone())
+            fd = orig_sfd(depth, hit_prob, *a, **k)
+            cap['fine_depth'] = fd.clone()
+            raise _Stop()
+        renderer.sample_fine_depth, torch.searchsorted = sfd, ss
+        try:
+            for seed in range(1, max_tries):
+                ref, que = make_scene(seed, name)
+                t = lambda a: torch.from_numpy(a.copy())
+                ref_info = {k: t(v) for k, v in ref.items()}
+                que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                            'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+                try:
+                    with torch.no_grad():
+                        net.render(que_info, ref_info, False)
+                except _Stop:
+                    pass
+                marg = inds_margin(cap['cdf'].numpy()[0], cap['u'].numpy()[0])
+                print(f'   f1 {name} seed {seed}: min margin {marg.min():.3e}', flush=True)
+                if marg.min() >= min_margin[name]:
+                    break
+            else:
+                raise RuntimeError('no seed found')
+        finally:
+            renderer.sample_fine_depth, torch.searchsorted = orig_sfd, orig_ss
+        out.update({f'{name}.seed': np.int64(seed), f'{name}.hit_prob': cap['hit_prob'].numpy()[0],
+                    f'{name}.depth': cap['depth'].numpy()[0], f'{name}.cdf': cap['cdf'].numpy()[0],
+                    f'{name}.inds': cap['inds'].numpy()[0].astype(np.int64), f'{name}.margin': marg,
+                    f'{name}.fine_depth': cap['fine_depth'].numpy()[0],
+                    f'{name}.input_sha256': np.frombuffer(sha([ref[k] for k in sorted(ref)] + [que[k] for k in sorted(que)]).encode(), np.uint8)})
+    np.savez_compressed(ROOT + '/tests/golden/golden_f1.npz', **out)
+    print('f1 golden:', {k: (v.shape if hasattr(v, 'shape') and v.shape else v) for k, v in out.items()})
 
 
 def run_full_forward(renderer):
@@ -354,6 +421,8 @@ def main():
         return run_losses()
     if '--full-only' in sys.argv:
         return run_full_forward(renderer)
+    if '--f1-only' in sys.argv:
+        return run_f1(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     if '--train-only' in sys.argv:
         return run_train_mode(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     os.makedirs(ROOT + '/tests/golden', exist_ok=True)
@@ -379,6 +448,7 @@ def main():
         for k, v in out.items():
             print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
     run_train_mode(renderer, weights)
+    run_f1(renderer, weights)
     run_full_forward(renderer)
     run_losses()
     run_post()
