@@ -148,6 +148,9 @@ def lib():
                                         c_float_p, C.c_void_p]
     L.gnr_time_chain_kernel.restype = C.c_int
     L.gnr_chain_timing_begin.restype = C.c_int
+    L.gnr_timing_begin.restype = C.c_int
+    L.gnr_timing_end.argtypes = [C.c_char_p, C.c_size_t]
+    L.gnr_timing_end.restype = C.c_int
     L.gnr_chain_timing_end.argtypes = [c_float_p, C.POINTER(C.c_int)]
     L.gnr_chain_timing_end.restype = C.c_int
     L.gnr_last_error.restype = C.c_char_p
@@ -160,7 +163,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
-            'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_grasp_select_workspace_bytes',
+            'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_timing_begin', 'gnr_timing_end', 'gnr_grasp_select_workspace_bytes',
             'gnr_grasp_select_fwd', 'gnr_post_last_error', 'gnr_packed_bwd_floats', 'gnr_pack_weights_bwd',
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
@@ -172,3 +175,21 @@ def check(rc, what):
     if rc != GNR_OK:
         msg = lib().gnr_last_error().decode(errors='replace')
         raise GnrError(f'{what} failed: {ERRORS.get(rc, rc)} ({msg})')
+
+
+def timing_begin():
+    """Start bracketing every kernel launch of libgnr.so with HIP events on its launch stream (include/gnr.h)."""
+    check(lib().gnr_timing_begin(), 'gnr_timing_begin')
+
+
+def timing_end():
+    """-> {label: (launches, total_ms)} of the launches since timing_begin(); waits for them."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().gnr_timing_end(buf, len(buf))
+    if n < 0:
+        check(n, 'gnr_timing_end')
+    out = {}
+    for line in buf.value.decode().splitlines():
+        label, cnt, ms = line.rsplit(' ', 2)
+        out[label] = (int(cnt), float(ms))
+    return out

@@ -20,6 +20,15 @@
 
 #include "../../include/gnr.h"
 
+// per-launch timing brackets of the library (gnr_capi.inc; active between gnr_timing_begin / gnr_timing_end)
+extern "C" int gnr_internal_timing_open(const char* label, void* stream);
+extern "C" void gnr_internal_timing_close(int idx, void* stream);
+struct HeadScope {
+    void* st; int idx;
+    HeadScope(const char* label, void* s) : st(s), idx(gnr_internal_timing_open(label, s)) {}
+    ~HeadScope() { gnr_internal_timing_close(idx, st); }
+};
+
 namespace gnrh {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -438,6 +447,7 @@ extern "C" int gnr_grasp_head_fwd(int B, int R, const float* volume, const float
     if (B < 1 || R < 8 || R > 64) { snprintf(h_err, sizeof(h_err), "gnr_grasp_head_fwd: bad B/R"); return GNR_ERR_SHAPE; }
     if (ws_bytes < gnr_grasp_head_workspace_bytes(B, R)) { snprintf(h_err, sizeof(h_err), "workspace too small"); return GNR_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
+    HeadScope hs("grasp_head_fwd(all kernels)@gnr_grasp_head_fwd", stream);
     const int d1 = (R - 1) / 2 + 1, d2 = (d1 - 1) / 2 + 1, d3 = (d2 - 1) / 2 + 1;      // conv k, s2, pad k/2
     float* a1 = (float*)ws;                                   // [B][16][d1^3]
     float* a2 = a1 + (size_t)B * 16 * d1 * d1 * d1;           // [B][32][d2^3]
@@ -541,6 +551,7 @@ extern "C" int gnr_conv3d_bwd_weight(const float* x, const float* dy, float* dw,
     const long total = (long)B * D * H * W;
     const int nchunk = (int)((total + gnr_head::BW_CHUNK - 1) / gnr_head::BW_CHUNK);
     const long njobs = (long)nchunk * K * K * K * ((Cin + 15) / 16) * ((Cout + 15) / 16);
+    HeadScope hs("k_conv3d_bwd_weight@gnr_conv3d_bwd_weight", stream);
     hipLaunchKernelGGL(gnr_head::k_conv3d_bwd_weight, dim3((unsigned)((njobs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, dw, B,
                        Cin, Cout, D, H, W, K, nchunk);
     return hipGetLastError() == hipSuccess ? GNR_OK : GNR_ERR_HIP;

@@ -276,8 +276,14 @@ const char* gnr_post_last_error(void);
 /* name of the dominant kernel as it appears in rocprofv3 traces, and the last HIP error text */
 const char* gnr_dominant_kernel_name(void);
 const char* gnr_last_error(void);
-/* In-situ timing of the dominant kernel: between begin and end, every k_chain launch on volume points is
- * bracketed by HIP events recorded on its launch stream (process-wide switch, measurement only). */
+/* In-situ timing (process-wide switch, measurement only): between gnr_timing_begin() and gnr_timing_end() every kernel
+ * launch of the library is bracketed by a pair of HIP events recorded on ITS launch stream (nothing else is added to the
+ * path).  gnr_timing_end() waits for the events and writes one line per label -- "label count total_ms\n", label =
+ * "kernel@entry point" (k_chain / k_ray: "k_chain.volume", "k_chain.render", "...train") -- into `report` (NUL-terminated,
+ * truncated to report_bytes); returns the number of launches recorded or a negative error code.
+ * gnr_chain_timing_begin/end: the same switch, reduced to the average duration of the k_chain launches on volume points. */
+int gnr_timing_begin(void);
+int gnr_timing_end(char* report, size_t report_bytes);
 int gnr_chain_timing_begin(void);
 int gnr_chain_timing_end(float* avg_ms_out, int* count_out);
 /* Time `iters` launches of the dominant kernel alone (volume points of `scene`) with HIP

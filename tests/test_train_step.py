@@ -52,21 +52,27 @@ def scene_data(device='cpu', scene_id=0):
             'grasp_info': tuple(t(x) for x in gt['grasp_info'])}
 
 
-def check_against_golden(net, terms, G, rtol_loss, rtol_grad):
+def check_against_golden(net, terms, G, rtol_loss, rtol_grad, rtol_backbone=None):
     for k in ('loss_rgb_nr', 'loss_rgb_nr_fine', 'loss_depth', 'loss_depth_fine', 'loss_sdf', 'loss_eikonal', 'loss_vgn'):
         np.testing.assert_allclose(float(terms[k].detach().mean()), G['loss.' + k].mean(), rtol=rtol_loss, err_msg=k)
     norms = dict(zip(G['param_names'].tolist(), G['grad_norms'].tolist()))
-    worst = 0.0
+    worst, worst_path = (0.0, ''), (0.0, '')
     for k, p in net.named_parameters():
         assert p.grad is not None, k
         n = float(p.grad.double().norm())
         # biases in front of an InstanceNorm / a softmax over views have an exactly-zero gradient: both sides hold
         # rounding noise of ~1e-8 there, hence the absolute floor
-        worst = max(worst, (abs(n - norms[k]) - 1e-7) / (norms[k] + 1e-12))
+        e = (abs(n - norms[k]) - 1e-7) / (norms[k] + 1e-12)
+        worst = max(worst, (e, k))
+        if any(s in k for s in ('dist_decoder', 'agg_net', 'vgn_net')):
+            worst_path = max(worst_path, (e, k))
         if 'grad.' + k in G:                                   # hot-path parameters: full gradient arrays
             g, r = p.grad.cpu().numpy(), G['grad.' + k]
             assert np.abs(g - r).max() <= rtol_grad * max(np.abs(r).max(), 1e-8) + 1e-9, k
-    assert worst < rtol_grad, f'gradient-norm mismatch {worst}'
+    # the volumetric path's and the grasp head's own parameters (this repo's kernels) sit at ~5e-6 of the reference's gradient
+    # norms; the 2D backbones run through MIOpen (other convolution algorithms than the CPU reference): rtol_backbone
+    assert worst_path[0] < rtol_grad, f'gradient-norm mismatch on the path {worst_path}'
+    assert worst[0] < (rtol_backbone or rtol_grad), f'gradient-norm mismatch {worst}'
 
 
 def test_train_step_gradients_match_reference():
@@ -174,7 +180,7 @@ def test_train_step_on_gpu_matches_reference_gradients():
     terms = train_losses(net(data), data)
     losses.total_loss(terms).backward()
     torch.cuda.synchronize()
-    check_against_golden(net, terms, G, rtol_loss=2e-4, rtol_grad=3e-3)
+    check_against_golden(net, terms, G, rtol_loss=2e-4, rtol_grad=1e-3, rtol_backbone=1e-2)
 
 
 @pytest.mark.gpu
@@ -289,8 +295,14 @@ def test_eval_after_optimizer_step_uses_the_updated_weights():
         torch.manual_seed(5)
         want = fresh(ev)
     torch.cuda.synchronize()
-    assert not torch.equal(before['volume'], after['volume']), 'the step should have moved the volume'
+    # the packed copies are those of the trained parameters, bit for bit ...
+    assert torch.equal(net.nr_net.hot().wc, fresh.nr_net.hot().wc) and torch.equal(net.nr_net.hot().wf, fresh.nr_net.hot().wf)
+    assert torch.equal(net._head.w, fresh._head.w), 'grasp head packed from stale weights'
+    # ... and the outputs follow (MIOpen's 2D backbones are not run-to-run deterministic, ~1e-5 on the feature maps, hence a
+    # tolerance; the training step itself moved the outputs by orders of magnitude more)
+    moved = (before['volume'] - after['volume']).abs().max().item()
+    assert moved > 1e-3, 'the step should have moved the volume'
     for k in ('volume', 'sdf_values', 'alpha_values_fine', 'depth_mean', 'depth_mean_fine'):
-        assert torch.equal(after[k], want[k]), k
-    for a, b in zip(after['vgn_pred'], want['vgn_pred']):
-        assert torch.equal(a, b), 'grasp head ran on stale weights'
+        assert (after[k] - want[k]).abs().max().item() < 5e-5, k
+    for a, b, c in zip(after['vgn_pred'], want['vgn_pred'], before['vgn_pred']):
+        assert (a - b).abs().max().item() < 5e-5 < (a - c).abs().max().item(), 'grasp head ran on stale weights'
