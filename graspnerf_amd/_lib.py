@@ -119,13 +119,15 @@ def lib():
     L.gnr_render_chain_train_workspace_bytes.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_int]
     L.gnr_render_chain_train_workspace_bytes.restype = C.c_size_t
     L.gnr_render_chain_fwd_train.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_size_t, C.c_void_p]
     L.gnr_render_chain_fwd_train.restype = C.c_int
     L.gnr_render_chain_bwd.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_render_chain_bwd.restype = C.c_int
     L.gnr_render_tail_fwd_train.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_int, C.c_void_p,
-                                            C.POINTER(GnrRenderOut), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+                                            C.POINTER(GnrRenderOut), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]
     L.gnr_composite_bwd.argtypes = [C.c_void_p] * 15 + [C.c_int, C.c_int, C.c_void_p]
     L.gnr_host_randperm_prefix.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p]
     L.gnr_host_randperm_prefix.restype = C.c_int
@@ -149,6 +151,8 @@ def lib():
     L.gnr_time_chain_kernel.restype = C.c_int
     L.gnr_chain_timing_begin.restype = C.c_int
     L.gnr_timing_begin.restype = C.c_int
+    L.gnr_timing_begin_only.argtypes = [C.c_char_p]
+    L.gnr_timing_begin_only.restype = C.c_int
     L.gnr_timing_end.argtypes = [C.c_char_p, C.c_size_t]
     L.gnr_timing_end.restype = C.c_int
     L.gnr_chain_timing_end.argtypes = [c_float_p, C.POINTER(C.c_int)]
@@ -163,7 +167,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
-            'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_timing_begin', 'gnr_timing_end', 'gnr_grasp_select_workspace_bytes',
+            'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_timing_begin', 'gnr_timing_begin_only', 'gnr_timing_end', 'gnr_grasp_select_workspace_bytes',
             'gnr_grasp_select_fwd', 'gnr_post_last_error', 'gnr_packed_bwd_floats', 'gnr_pack_weights_bwd',
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
@@ -177,9 +181,10 @@ def check(rc, what):
         raise GnrError(f'{what} failed: {ERRORS.get(rc, rc)} ({msg})')
 
 
-def timing_begin():
-    """Start bracketing every kernel launch of libgnr.so with HIP events on its launch stream (include/gnr.h)."""
-    check(lib().gnr_timing_begin(), 'gnr_timing_begin')
+def timing_begin(only=None):
+    """Start bracketing the kernel launches of libgnr.so (all of them, or those whose label contains `only`) with HIP events
+    on their launch stream (include/gnr.h)."""
+    check(lib().gnr_timing_begin_only(only.encode() if only else None), 'gnr_timing_begin')
 
 
 def timing_end():

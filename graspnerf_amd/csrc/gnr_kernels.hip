@@ -253,6 +253,16 @@ __global__ void k_points_rays(const float* __restrict__ coords, const float* __r
     d[7] = half(k);
 }
 
+// sample points and query directions of a render pass as plain tensors (the inputs of the training pass's backward kernels):
+// pts [B*rn*dn][3] and qdir [B*rn][3] out of the descriptors k_points_rays wrote (same bits the chain consumed)
+__global__ void k_desc_unpack(const float* __restrict__ desc, float* __restrict__ pts, float* __restrict__ qdir, int dn, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* d = desc + (size_t)i * DESC_FLOATS;
+    if (pts) { pts[(size_t)i * 3] = d[0]; pts[(size_t)i * 3 + 1] = d[1]; pts[(size_t)i * 3 + 2] = d[2]; }
+    if (qdir && i % dn == 0) { float* q = qdir + (size_t)(i / dn) * 3; q[0] = d[3]; q[1] = d[4]; q[2] = d[5]; }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_chain
 // ---------------------------------------------------------------------------------------

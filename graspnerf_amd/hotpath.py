@@ -244,27 +244,38 @@ class HotPath:
 
     # ---- render path for training: the per-view chain of one pass in both directions (csrc/gnr_bwd.inc) ---------
     def render_chain_train(self, que, depth, level, cfg, prepared):
-        """que: batched ray dict (coords [B,rn,2], pose, K, depth_range), depth [B,rn,dn] -> (stats [B,rn*dn,66],
-        colours [B,rn*dn,3], ctx for render_chain_bwd).  The training workspace of the pass travels in ctx."""
+        """que: batched ray dict (coords [B,rn,2], pose, K, depth_range[, fine_u]); depth [B,rn,dn], or None for the coarse
+        pass (sample_depth on the device, render_ops.py:146-170) -> (stats [B,rn*dn,66], colours [B,rn*dn,3], the pass's
+        ray geometry {depth [B,rn,dn], pts [B*rn*dn,3], qdir [B*rn,3]}, ctx for render_tail_train / render_chain_bwd).
+        The training workspace of the pass travels in ctx."""
         scene, keep, ws = prepared
-        depth = _f32(depth, self.device)
-        B, rn, dn = depth.shape
-        rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
+        dn0, fdn = cfg.get('depth_sample_num', 40), cfg.get('fine_depth_sample_num', 40)
+        B, rn = que['coords'].shape[:2]
+        if depth is not None:
+            depth = _f32(depth, self.device)
+            assert depth.shape[:2] == (B, rn)
+        dn = dn0 if depth is None else depth.shape[2]
+        rays, rkeep = self._rays(que, dn0, fdn, cfg, scene.H, scene.W)
         need = self.L.gnr_workspace_bytes(C.byref(scene), 1, rn, dn)
         if ws.numel() < need:
             raise _lib.GnrError('render_chain_train: prepare() the workspace for the ray count first')
         tws = torch.empty(self.L.gnr_render_chain_train_workspace_bytes(C.byref(scene), rn, dn), dtype=torch.uint8, device=self.device)
         stats = torch.empty(B, rn * dn, 66, dtype=torch.float32, device=self.device)
         colors = torch.empty(B, rn * dn, 3, dtype=torch.float32, device=self.device)
+        geo = {'depth': torch.empty(B, rn, dn, dtype=torch.float32, device=self.device) if depth is None else depth,
+               'pts': torch.empty(B * rn * dn, 3, dtype=torch.float32, device=self.device),
+               'qdir': torch.empty(B * rn, 3, dtype=torch.float32, device=self.device)}
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_render_chain_fwd_train(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
-                                                     stats.data_ptr(), colors.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                     tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_chain_fwd_train')
-        return stats, colors, (scene, keep, ws, tws, rn, dn, level)
+        _lib.check(self.L.gnr_render_chain_fwd_train(C.byref(scene), C.byref(rays), None if depth is None else depth.data_ptr(), dn,
+                                                     w.data_ptr(), stats.data_ptr(), colors.data_ptr(),
+                                                     geo['depth'].data_ptr() if depth is None else None, geo['pts'].data_ptr(),
+                                                     geo['qdir'].data_ptr(), ws.data_ptr(), ws.numel(), tws.data_ptr(), tws.numel(),
+                                                     self._stream()), 'gnr_render_chain_fwd_train')
+        return stats, colors, geo, (scene, keep, ws, tws, rn, dn, level, rays, rkeep)
 
     def render_chain_bwd(self, ctx, dstats, dcolors):
         """-> (d_canonical [36958] of the pass's level, d_ray_feats, d_img_feats [B,V,32,fh,fw])."""
-        scene, keep, ws, tws, rn, dn, level = ctx
+        scene, keep, ws, tws, rn, dn, level = ctx[:7]
         dstats = _f32(dstats, self.device)
         dcolors = _f32(dcolors, self.device)
         assert dstats.shape[-1] == 65 and dcolors.shape[-1] == 3
@@ -279,25 +290,28 @@ class HotPath:
         return dcan, dray, dimg
 
     # ---- per-ray tail of a training render pass (k_ray<true> forward, k_ray_dual_bwd backward) -----------------
-    def render_tail_train(self, ctx, que, depth, colors, cfg):
+    def render_tail_train(self, ctx, que, depth, colors, want_fine_depth=False):
         """Right after render_chain_train (same `ctx`): the per-ray tail, NeuS alpha and compositing of the pass (k_ray<true>).
         -> dict of device tensors: sdf_values, alpha_values, hit_prob_nr [B,rn,dn], sdf_gradient [B,rn,dn,3],
         pixel_colors_nr [B,rn,3], render_depth [B,rn], ray_mask [B,rn] bool, sdf_gradient_error [B,n_chunks]
-        (+ pixel_colors_gt [B,rn,3] when `que` carries the query images)."""
-        scene, keep, ws, tws, rn, dn, level = ctx
+        (+ pixel_colors_gt [B,rn,3] when `que` carries the query images; + fine_depth [B,rn,fdn], the sorted inverse-CDF
+        resampling of this pass on que['fine_u'] / the eval midpoints, render_ops.py:172-229, when want_fine_depth)."""
+        scene, keep, ws, tws, rn, dn, level, rays, rkeep = ctx
         depth = _f32(depth, self.device)
-        rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
         o_s, o = self._alloc_out(scene.B, rn, dn, 'imgs' in que, True, rays.ray_batch_num or rn)
         o['colors_nr'] = _f32(colors, self.device).reshape(scene.B, rn, dn, 3)
         o_s.colors_nr = o['colors_nr'].data_ptr()
         o_s.depth = None
         o_s.view_mask = None
+        fd = torch.empty(scene.B, rn, rays.fdn, dtype=torch.float32, device=self.device) if want_fine_depth else None
         w = self.wc if level == 'coarse' else self.wf
         _lib.check(self.L.gnr_render_tail_fwd_train(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(), C.byref(o_s),
-                                                    ws.data_ptr(), ws.numel(), tws.data_ptr(), tws.numel(), self._stream()),
-                   'gnr_render_tail_fwd_train')
+                                                    fd.data_ptr() if want_fine_depth else None, ws.data_ptr(), ws.numel(),
+                                                    tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_tail_fwd_train')
         o['ray_mask'] = o['ray_mask'].bool()
         o.pop('depth'), o.pop('view_mask')
+        if want_fine_depth:
+            o['fine_depth'] = fd
         return o
 
     def geo_dual_fwd(self, canon, stats, pts, gamma):

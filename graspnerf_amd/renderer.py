@@ -5,8 +5,11 @@ state-dict keys (ref: src/nr/network/renderer.py:13-335), so `src/gd`'s consumer
 checkpoints plug in unchanged.  The 2D backbones and the grasp head are PyTorch-ROCm modules
 (backbone.py); everything between `ray_feats` and `volume` / the render dict runs in the HIP
 kernels behind libgnr.so (hotpath.py).  With autograd enabled in training mode the same kernels run behind
-autograd.Functions whose backward calls the backward twins (csrc/gnr_bwd.inc); off the GPU, or with the
-cfg['hip_*'] switches off, the same parameters are differentiated through autograd_path.py instead.
+autograd.Functions whose backward calls the backward twins (csrc/gnr_bwd.inc): ray geometry, coarse depths,
+inverse-CDF resampling and the sort are done by the forward kernels, this module only routes tensors between the twin pairs
+and builds the output dicts.  There is no PyTorch statement of the path in the product: without a GPU, training raises
+like inference does (the differentiable reference statement the backward kernels are tested against lives in
+tests/reference_autograd.py).
 """
 import numpy as np
 import torch
@@ -16,7 +19,7 @@ from . import weights as _w
 from .backbone import ResUNetLight, CostVolumeInitNet, DefaultVisEncoder, ConvNet
 from .hotpath import HotPath
 from .grasp_head import GraspHead
-from . import autograd_path as _ag
+from . import _lib
 from . import ray_tail as _rt
 
 
@@ -137,29 +140,42 @@ class _SampleVolumeFn(torch.autograd.Function):
         return (None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys('coarse'))
 
 
+_FW_KEYS = ('sdf_values', 'sdf_gradient', 'alpha_values', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth', 'ray_mask',
+            'sdf_gradient_error')
+_GEO_KEYS = ('depth', 'pts', 'qdir')
+
+
+def _pass_value_names(with_gt, with_fine_depth):
+    """Names of the non-differentiable outputs _RenderChainFn returns after (stats, colours)."""
+    return _GEO_KEYS + _FW_KEYS + (('pixel_colors_gt',) if with_gt else ()) + (('fine_depth',) if with_fine_depth else ())
+
+
 class _RenderChainFn(torch.autograd.Function):
-    """The per-view chain of one render pass of one scene on the HIP path in both directions
+    """The per-view chain of one render pass of B scenes on the HIP path in both directions
     (gnr_render_chain_fwd_train / gnr_render_chain_bwd): everything up to the cross-view statistics and the colour blend.
-    Differentiable inputs: ray_feats, img_feats and every parameter of the pass's level in state-dict order; outputs
-    stats [P,66] (mean, var, wbar, n_valid) and colours [P,3]."""
+    `depth` None = the coarse pass (sample_depth on the device).  Differentiable inputs: ray_feats, img_feats and every
+    parameter of the pass's level in state-dict order; differentiable outputs stats [B,P,66] (mean, var, wbar, n_valid) and
+    colours [B,P,3].  The forward also runs the pass's per-ray tail, NeuS alpha and compositing (k_ray<true>) on the records
+    the chain left in the workspace and returns their VALUES (they become the outputs of _RayTailFn / _CompositeFn, which
+    own the backward), the pass's ray geometry (depth, pts, qdir) and -- for the coarse pass -- the sorted inverse-CDF
+    resampling (render_ops.py:172-229) as non-differentiable outputs, in _pass_value_names() order."""
 
     @staticmethod
-    def forward(ctx, hot, prep, que, depth, level, cfg, ray_feats, img_feats, *params):     # depth [B,rn,dn]
-        stats, colors, hctx = hot.render_chain_train(que, depth, level, cfg, prep)
+    def forward(ctx, hot, prep, que, depth, level, cfg, want_fine_depth, ray_feats, img_feats, *params):
+        stats, colors, geo, hctx = hot.render_chain_train(que, depth, level, cfg, prep)
         ctx.hot, ctx.hctx, ctx.level, ctx.gen = hot, hctx, level, hot.generation
-        # forward of the per-ray tail, NeuS alpha and compositing on the records the chain just left in the workspace:
-        # values only, they become the outputs of _RayTailFn / _CompositeFn, which own the backward
-        fw = hot.render_tail_train(hctx, que, depth, colors, cfg)
-        extra = tuple(fw[k] for k in _FW_KEYS) + ((fw['pixel_colors_gt'],) if 'pixel_colors_gt' in fw else ())
+        fw = hot.render_tail_train(hctx, que, geo['depth'], colors, want_fine_depth)
+        fw.update(geo)
+        extra = tuple(fw[k] for k in _pass_value_names('pixel_colors_gt' in fw, want_fine_depth))
         ctx.mark_non_differentiable(*extra)
-        return (stats, colors) + extra                                      # [B,P,66], [B,P,3], forward values of the pass
+        return (stats, colors) + extra
 
     @staticmethod
     def backward(ctx, dstats, dcolors, *_):
         ctx.hot.check_generation(ctx.gen)
         dcan, dray, dimg = ctx.hot.render_chain_bwd(ctx.hctx, dstats[..., :65].contiguous(), dcolors.contiguous())
         g = _w.split_canonical(dcan, ctx.level)
-        return (None, None, None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
+        return (None,) * 7 + (dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
 
 
 def randperm_prefix(n, k):
@@ -175,23 +191,6 @@ def randperm_prefix(n, k):
         return None
     torch.set_rng_state(st)
     return out
-
-
-_warned_host_training = False
-
-
-def _warn_host_training():
-    global _warned_host_training
-    if not _warned_host_training:
-        _warned_host_training = True
-        import warnings
-        warnings.warn('graspnerf_amd: training forward on host tensors differentiates the PyTorch statement of the path '
-                      '(autograd_path.py, the reference of the backward kernels\' tests); the HIP kernels run for CUDA tensors only',
-                      RuntimeWarning, stacklevel=3)
-
-
-_FW_KEYS = ('sdf_values', 'sdf_gradient', 'alpha_values', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth', 'ray_mask',
-            'sdf_gradient_error')
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -227,32 +226,27 @@ class _RayTailFn(torch.autograd.Function):
     """The per-ray tail of one training render pass (geometry_fc on [stats, embed(p)], attention, LayerNorm,
     out_geometry_fc, clip, and the in-forward gradient of sdf w.r.t. the points; ibrnet.py:485-504).  Forward values are
     k_ray<true>'s (computed next to the chain, _RenderChainFn); the backward takes dL/d sdf AND dL/d grad: a reverse pass
-    on dual numbers (ray_tail.py): k_geo_dual_fwd -> k_ray_dual_bwd -> k_geo_dual_bwd, no double-backward graph.
+    on dual numbers: k_geo_dual_fwd -> k_ray_dual_bwd -> k_geo_dual_bwd (csrc/gnr_bwd.inc), no double-backward graph.
     Differentiable inputs: stats [N,66] and the 14 tail parameters of the level (ray_tail.TAIL_KEYS order)."""
 
     @staticmethod
-    def forward(ctx, hot, level, agg, pts, rn, dn, sdf, grad, hip_core, stats, *params):
+    def forward(ctx, hot, level, agg, pts, rn, dn, sdf, grad, stats, *params):
         ctx.save_for_backward(stats, pts, *params)
-        ctx.meta = (hot, level, agg, rn, dn, hip_core, hot.generation)
+        ctx.meta = (hot, level, agg, rn, dn, hot.generation)
         return sdf.reshape(rn, dn).clone(), grad.reshape(rn, dn, 3).clone()
 
     @staticmethod
     def backward(ctx, a, gamma):
-        hot, level, agg, rn, dn, hip_core, gen = ctx.meta
+        hot, level, agg, rn, dn, gen = ctx.meta
         hot.check_generation(gen)
         stats, pts, *params = ctx.saved_tensors
         P = {agg + 'agg_impl.' + k: p for k, p in zip(_rt.TAIL_KEYS, params)}
         a = torch.zeros(rn, dn, device=stats.device) if a is None else a
         gamma = torch.zeros(rn, dn, 3, device=stats.device) if gamma is None else gamma
-        core = _rt.hip_core(hot, level) if hip_core else _rt.attn_core
-        geo = _rt.hip_geo(hot, level, hot.can_dev[level], lambda d: _w.split_canonical(d, level)) if hip_core else None
         with torch.no_grad():
             # the device kernels read / write the 66-column layout directly (column 65 = n_valid, gradient 0)
-            dstats, G = _rt.tail_backward(P, agg, stats if geo is not None else stats[:, :65], stats[:, 65], pts, rn, dn,
-                                          a.contiguous(), gamma.contiguous(), core, geo)
-            if dstats.shape[1] == 65:
-                dstats = torch.cat([dstats, torch.zeros_like(dstats[:, :1])], 1)
-        return (None,) * 9 + (dstats,) + tuple(G[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS)
+            dstats, G = _rt.tail_backward(hot, level, P, agg, stats, pts, rn, dn, a.contiguous(), gamma.contiguous())
+        return (None,) * 8 + (dstats,) + tuple(G[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS)
 
 
 class NeuralRayRenderer(nn.Module):
@@ -374,77 +368,94 @@ class NeuralRayRenderer(nn.Module):
                 'ray_batch_num': c['ray_batch_num']}
 
     def _use_autograd(self, is_train):
-        """Training (autograd on, parameters trainable): the HIP twin pairs behind autograd.Functions on the GPU, the
-        differentiable PyTorch statement of the path (autograd_path.py) elsewhere."""
+        """Training (autograd on, parameters trainable): the HIP twin pairs behind autograd.Functions."""
         return bool(is_train) and torch.is_grad_enabled()
+
+    @staticmethod
+    def _need_gpu(t):
+        if not t.is_cuda:
+            raise _lib.GnrError('graspnerf_amd: the volumetric path trains on a ROCm GPU only (HIP kernels in both directions); '
+                                'there is no PyTorch / CPU fallback')
 
     def _params(self):
         return dict(self.named_parameters())
 
-    def _hip_pass(self, hot, level, extra, P):
-        """What follows the per-view chain of a training pass, as callables for autograd_path.render_by_depth / render_scenes:
-        tail(agg, stats [N,66], pts, R, dn) -> (sdf, grad) through _RayTailFn and comp(agg, sdf, grad, col, qdir, depth) ->
-        dict of the pass's outputs for all R rays through _CompositeFn.  `extra` = the forward values _RenderChainFn returned
-        after (stats, colours).  cfg['hip_ray_tail']: True (default) = both in HIP; 'torch' = the dual-number backward with
-        its attention core in tensor algebra; False = autograd_path.sdf_tail / composite (autograd double backward)."""
-        mode = self.cfg.get('hip_ray_tail', True)
-        if not mode:
-            return None, None
-        fw = dict(zip(_FW_KEYS, extra))
-        gt = extra[len(_FW_KEYS)] if len(extra) > len(_FW_KEYS) else None
+    def _train_pass(self, hot, prep, que_b, depth, level, want_fine_depth, ray_feats, img_feats, P):
+        """One render pass (renderer.py:90-138) of B scenes in training mode: per-view chain -> per-ray tail -> NeuS alpha /
+        compositing, each a HIP twin pair behind its autograd.Function; tensors are only routed here.
+        -> (dict of [B*rn, ...] results of the pass, dict of its non-differentiable values incl. geometry / fine depths)."""
+        agg = _w.LEVELS[level][1]
+        st, co, *extra = _RenderChainFn.apply(hot, prep, que_b, depth, level, self._render_cfg(), want_fine_depth, ray_feats, img_feats,
+                                              *[P[k] for k, _ in _w.level_keys(level)])
+        ex = dict(zip(_pass_value_names('imgs' in que_b, want_fine_depth), extra))
+        B, rn, dn = ex['depth'].shape
+        R = B * rn
+        sdf, grad = _RayTailFn.apply(hot, level, agg, ex['pts'], R, dn, ex['sdf_values'], ex['sdf_gradient'], st.reshape(-1, 66),
+                                     *[P[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS])
+        col = co.reshape(R, dn, 3)
+        alpha, hit, pix, rdepth, gerr = _CompositeFn.apply(hot, level, ex['depth'].reshape(R, dn), ex['qdir'], ex, sdf, grad, col,
+                                                           P[agg + 'deviation_network.variance'])
+        return {'sdf': sdf, 'col': col, 'alpha': alpha, 'hit': hit, 'pix': pix, 'rdepth': rdepth, 'gerr': gerr,
+                'rmask': ex['ray_mask'].reshape(R), 'gt': ex['pixel_colors_gt'].reshape(R, 3) if 'pixel_colors_gt' in ex else None,
+                's': P[agg + 'deviation_network.variance'].reshape(1, 1)}, ex
 
-        def tail(agg, stats, pts, R, dn):
-            return _RayTailFn.apply(hot, level, agg, pts, R, dn, fw['sdf_values'], fw['sdf_gradient'], mode != 'torch', stats,
-                                    *[P[agg + 'agg_impl.' + k] for k in _rt.TAIL_KEYS])
+    @staticmethod
+    def _scene_dicts(o, B, rn, suffix=''):
+        """Per-scene output dicts (renderer.py:110-138 keys, leading 1) out of a pass's [B*rn, ...] results."""
+        outs = []
+        for b in range(B):
+            sl = slice(b * rn, (b + 1) * rn)
+            d = {'sdf_values': o['sdf'][sl][None], 'alpha_values': o['alpha'][sl][None], 'colors_nr': o['col'][sl][None],
+                 'hit_prob_nr': o['hit'][sl][None], 'pixel_colors_nr': o['pix'][sl][None], 'sdf_gradient_error': o['gerr'][b:b + 1],
+                 's': o['s'], 'render_depth': o['rdepth'][sl][None], 'ray_mask': o['rmask'][sl][None]}
+            if o['gt'] is not None:
+                d['pixel_colors_gt'] = o['gt'][sl][None]
+            outs.append({k + suffix: v for k, v in d.items()})
+        return outs
 
-        def comp(agg, sdf, grad, col, qdir, depth):
-            R = sdf.shape[0]
-            alpha, hit, pix, rdepth, gerr = _CompositeFn.apply(hot, level, depth.contiguous(), qdir.contiguous(), fw, sdf, grad, col,
-                                                               P[agg + 'deviation_network.variance'])
-            return {'alpha': alpha, 'hit': hit, 'pix': pix, 'rdepth': rdepth, 'gerr': gerr, 'rmask': fw['ray_mask'].reshape(R),
-                    'gt': None if gt is None else gt.reshape(R, 3)}
-        return tail, (comp if mode != 'torch' else None)
-
-    def _render_autograd(self, que, ref, _prep=None):
-        """renderer.py:201-220 with autograd: ray chunks of ray_batch_num, per-chunk random samples, outputs
-        concatenated along the ray axis (the [1,1] scalars become [1,n_chunks]).  On the GPU the per-view chain of every
-        pass, its per-ray tail (second order, _RayTailFn) and NeuS alpha / compositing (_CompositeFn) run in HIP in both
-        directions; autograd only connects them."""
-        c, P = self.cfg, self._params()
-        hip = ref['imgs'].is_cuda and c.get('hip_render_backward', True)
-        if hip:
-            hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref)
-        rn, chunk, fdn = que['coords'].shape[1], self.cfg['ray_batch_num'], self.cfg['fine_depth_sample_num']
+    def _render_train(self, hot, prep, que_b, fine_u, ray_feats, img_feats):
+        """renderer.py:140-162 + 201-220 for B scenes in training mode: ray chunks of ray_batch_num (the reference's loop,
+        outputs concatenated along the ray axis, the [1,1] scalars become [1,n_chunks]); per chunk the coarse pass (coarse
+        depths sampled, fine depths resampled from `fine_u` and sorted inside the forward kernels), then the fine pass.
+        que_b: coords [B,rn,2], pose [B,3,4], K [B,3,3], depth_range [B,2] (+ imgs [B,3,H,W]); fine_u [B,rn,fdn] on the device.
+        -> list of B per-scene dicts with '' and '_fine' keys."""
+        P = self._params()
+        B, rn = que_b['coords'].shape[:2]
+        chunk = self.cfg['ray_batch_num']
         parts = []
         for r0 in range(0, rn, chunk):
-            u = torch.rand([1, min(chunk, rn - r0), fdn])                  # render_ops.py:204-205 (CPU generator)
+            q = dict(que_b, coords=que_b['coords'][:, r0:r0 + chunk].contiguous(), fine_u=fine_u[:, r0:r0 + chunk].contiguous())
+            n = q['coords'].shape[1]
+            coarse, ex = self._train_pass(hot, prep, q, None, 'coarse', True, ray_feats, img_feats, P)
+            fine, _ = self._train_pass(hot, prep, q, ex['fine_depth'], 'fine', False, ray_feats, img_feats, P)
+            outs = self._scene_dicts(coarse, B, n)
+            for o, f in zip(outs, self._scene_dicts(fine, B, n, '_fine')):
+                o.update(f)
+            parts.append(outs)
+        outs = [{k: torch.cat([p[b][k] for p in parts], 1) for k in parts[0][b]} for b in range(B)] if len(parts) > 1 else parts[0]
+        if not self.cfg['render_depth']:
+            for o in outs:
+                o.pop('render_depth', None), o.pop('render_depth_fine', None)
+        return outs
+
+    def _render_autograd(self, que, ref, _prep=None):
+        """One scene in training mode (the reference's API): the is_train inverse-CDF samples are drawn exactly as the
+        reference draws them (one torch.rand([1,chunk_rn,fdn]) on the CPU generator per ray chunk, render_ops.py:204-205),
+        the NeuS step counters advance once per chunk (aggregate_net.py:135-137)."""
+        self._need_gpu(ref['imgs'])
+        hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref, que['coords'].shape[1])
+        rn, chunk, fdn = que['coords'].shape[1], self.cfg['ray_batch_num'], self.cfg['fine_depth_sample_num']
+        us = []
+        for r0 in range(0, rn, chunk):
+            us.append(torch.rand([1, min(chunk, rn - r0), fdn]))
             for net in (self.agg_net, self.fine_agg_net):
                 net.train_step_bookkeeping()
-            q = {'coords': que['coords'][0, r0:r0 + chunk], 'pose': que['poses'][0], 'K': que['Ks'][0],
-                 'depth_range': que['depth_range'][0]}
-            if 'imgs' in que:
-                q['imgs'] = que['imgs']
-            chains = None
-            if hip:
-                bq = {'coords': q['coords'][None], 'pose': q['pose'][None], 'K': q['K'][None], 'depth_range': q['depth_range'][None]}
-                if 'imgs' in q:
-                    bq['imgs'] = q['imgs']
-                rc = self._render_cfg()
-
-                def chain_of(level, bq=bq, rc=rc):
-                    keys = [P[k] for k, _ in _w.level_keys(level)]
-
-                    def run(depth):
-                        st, co, *extra = _RenderChainFn.apply(hot, prep, bq, depth.detach()[None], level, rc,
-                                                              ref['ray_feats'][None], ref['img_feats'][None], *keys)
-                        return (st[0], co[0]) + self._hip_pass(hot, level, extra, P)
-                    return run
-                chains = (chain_of('coarse'), chain_of('fine'))
-            parts.append(_ag.render(P, ref, q, self._render_cfg(), u[0], chains))
-        out = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
-        if not c['render_depth']:
-            out.pop('render_depth', None), out.pop('render_depth_fine', None)
-        return out
+        dev = ref['imgs'].device
+        fine_u = torch.cat(us, 1).pin_memory().to(dev, non_blocking=True)
+        bq = {'coords': que['coords'], 'pose': que['poses'], 'K': que['Ks'], 'depth_range': que['depth_range']}
+        if 'imgs' in que:
+            bq['imgs'] = que['imgs']
+        return self._render_train(hot, prep, bq, fine_u, ref['ray_feats'][None], ref['img_feats'][None])[0]
 
     @staticmethod
     def draw_fine_u(rn, fdn, chunk):
@@ -455,12 +466,11 @@ class NeuralRayRenderer(nn.Module):
     # ---- the reference's methods ------------------------------------------------------------------
     def sample_volume(self, ref_imgs_info, _prep=None, is_train=False):     # renderer.py:164-199
         if self._use_autograd(is_train):
-            if ref_imgs_info['imgs'].is_cuda and self.cfg.get('hip_volume_backward', True):
-                hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
-                P = self._params()
-                return _SampleVolumeFn.apply(hot, bref, prep, self.cfg['volume_resolution'], ref_imgs_info['ray_feats'][None],
-                                             ref_imgs_info['img_feats'][None], *[P[k] for k, _ in _w.level_keys('coarse')])
-            return _ag.sample_volume(self._params(), ref_imgs_info, self.cfg['volume_resolution'])
+            self._need_gpu(ref_imgs_info['imgs'])
+            hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
+            P = self._params()
+            return _SampleVolumeFn.apply(hot, bref, prep, self.cfg['volume_resolution'], ref_imgs_info['ray_feats'][None],
+                                         ref_imgs_info['img_feats'][None], *[P[k] for k, _ in _w.level_keys('coarse')])
         bref, prep = _prep or self._prepare(ref_imgs_info)
         return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
 
@@ -521,16 +531,13 @@ class NeuralRayRenderer(nn.Module):
         coords = self.gen_depth_loss_coords(h, w, ref_imgs_info['imgs'].device)
         if self._use_autograd(is_train):
             P = self._params()
-            if ref_imgs_info['imgs'].is_cuda:
-                # HIP forward + HIP backward behind an autograd.Function (csrc/gnr_bwd.inc)
-                hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
-                xy = coords.to(torch.float32)[None]
-                mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'][None],
-                                             *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])[0]
-                          for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
-            else:
-                mc = _ag.depth_mean(P, ref_imgs_info, coords, 'dist_decoder.')
-                mf = _ag.depth_mean(P, ref_imgs_info, coords, 'fine_dist_decoder.')
+            self._need_gpu(ref_imgs_info['imgs'])
+            # HIP forward + HIP backward behind an autograd.Function (csrc/gnr_bwd.inc)
+            hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
+            xy = coords.to(torch.float32)[None]
+            mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'][None],
+                                         *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])[0]
+                      for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
             return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
                     'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]}
         # the reference feeds (row, col) where (x, y) is expected; kept
@@ -551,11 +558,8 @@ class NeuralRayRenderer(nn.Module):
         ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
         out = {}
         if self._use_autograd(is_train):
-            if not ref['imgs'].is_cuda:
-                # not a fallback of the HIP path (inference has none and raises without a GPU): training on host tensors
-                # runs the PyTorch statement the backward kernels are tested against -- say so, once
-                _warn_host_training()
-            prep = self._train_prep(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0) if ref['imgs'].is_cuda else None
+            self._need_gpu(ref['imgs'])
+            prep = self._train_prep(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
         else:
             prep = self._prepare(ref, que['coords'].shape[1] if self.cfg['render_rgb'] else 0)
         if self.cfg['render_rgb']:
@@ -579,8 +583,7 @@ class NeuralRayRenderer(nn.Module):
         ques = [d['que_imgs_info'] for d in datas]
         same = all(r['imgs'].shape == refs[0]['imgs'].shape and q['coords'].shape == ques[0]['coords'].shape for r, q in zip(refs, ques))
         if not (len(datas) > 1 and same and all('eval' not in d for d in datas) and self._use_autograd(True) and refs[0]['imgs'].is_cuda
-                and c['render_rgb'] and c.get('sample_volume', False) and c.get('hip_render_backward', True)
-                and c.get('hip_volume_backward', True) and ques[0]['coords'].shape[1] <= c['ray_batch_num']):
+                and c['render_rgb'] and c.get('sample_volume', False) and ques[0]['coords'].shape[1] <= c['ray_batch_num']):
             return None
         B, V = len(datas), refs[0]['imgs'].shape[0]
         h, w = refs[0]['imgs'].shape[-2:]
@@ -612,29 +615,17 @@ class NeuralRayRenderer(nn.Module):
                 'bbox3d': stack('bbox3d', refs)}
         prep = hot.prepare(bref, R, rn, max(c['depth_sample_num'], fdn))
         P = self._params()
-        bq = {'coords': torch.cat([q['coords'] for q in ques]), 'pose': torch.cat([q['poses'] for q in ques]),
-              'K': torch.cat([q['Ks'] for q in ques]), 'depth_range': torch.cat([q['depth_range'] for q in ques])}
-        rc = self._render_cfg()
-        que_b = dict(bq)
+        que_b = {'coords': torch.cat([q['coords'] for q in ques]), 'pose': torch.cat([q['poses'] for q in ques]),
+                 'K': torch.cat([q['Ks'] for q in ques]), 'depth_range': torch.cat([q['depth_range'] for q in ques])}
         if 'imgs' in ques[0]:
             que_b['imgs'] = torch.cat([q['imgs'] for q in ques])
-
-        def chain_of(level):
-            keys = [P[k] for k, _ in _w.level_keys(level)]
-
-            def run(depth):
-                st, co, *extra = _RenderChainFn.apply(hot, prep, que_b, depth.detach(), level, rc, ray_feats, img_feats, *keys)
-                return (st, co) + self._hip_pass(hot, level, extra, P)
-            return run
-        outs = _ag.render_scenes(P, que_b, (h, w), rc, fine_u, (chain_of('coarse'), chain_of('fine')))
+        outs = self._render_train(hot, prep, que_b, fine_u, ray_feats, img_feats)
         vol = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
         if want_depth:
             xy = coords.to(torch.float32)
             mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
                       for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
         for b, o in enumerate(outs):
-            if not c['render_depth']:
-                o.pop('render_depth', None), o.pop('render_depth_fine', None)
             o['volume'] = vol[b:b + 1]
             if want_depth:
                 o.update({'depth_mean': mc[b, ..., 0], 'depth_coords': coords[b][None].repeat(V, 1, 1), 'depth_mean_2': mc[b, ..., 1],

@@ -190,14 +190,18 @@ int gnr_sample_volume_bwd(const GnrScene* scene, int volume_res, const float* le
                           float* d_img_feats, void* workspace, size_t workspace_bytes, void* train_workspace,
                           size_t train_workspace_bytes, int stages, void* stream);
 
-/* Render path for training (hybrid): the per-view chain of one render pass in HIP in both directions; the per-ray tail
- * (renderer.py:90-108, ibrnet.py:485-504) has its own twin pair below; NeuS alpha / compositing / losses (element-wise on
- * [rn,dn]) stay in PyTorch autograd, which supplies d stats / d colours.
+/* Render path for training: the per-view chain of one render pass in both directions; the per-ray tail (renderer.py:90-108,
+ * ibrnet.py:485-504) and NeuS alpha / compositing have their own twin pairs below; the ray geometry (S1-S3), the inverse-CDF
+ * resampling and the sort (F1/F2) run in the forward kernels.  PyTorch autograd only connects the pairs with the losses.
  *   stats_out [B, rn*dn, 66] = mean(32) var(32) wbar n_valid_views (true scale); colors_out [B, rn*dn, 3]           */
 size_t gnr_render_chain_train_workspace_bytes(const GnrScene* scene, int rn, int dn);
+/*   depth == NULL: the coarse pass, sample_depth (render_ops.py:146-170) on the device (dn must be rays->dn).
+ *   depth_out [B,rn,dn], pts_out [B,rn*dn,3], qdir_out [B,rn,3] (each nullable): the depths the pass used and its ray
+ *   geometry (render_ops.py:4-39: sample points, normalised query directions) for the tail / compositing backward.  */
 int gnr_render_chain_fwd_train(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn, const float* level_weights,
-                               float* stats_out, float* colors_out, void* workspace, size_t workspace_bytes,
-                               void* train_workspace, size_t train_workspace_bytes, void* stream);
+                               float* stats_out, float* colors_out, float* depth_out, float* pts_out, float* qdir_out,
+                               void* workspace, size_t workspace_bytes, void* train_workspace, size_t train_workspace_bytes,
+                               void* stream);
 int gnr_render_chain_bwd(const GnrScene* scene, int rn, int dn, const float* level_weights, const float* level_weights_bwd,
                          const float* dstats, const float* dcolors, float* d_canonical, float* d_ray_feats, float* d_img_feats,
                          void* workspace, size_t workspace_bytes, void* train_workspace, size_t train_workspace_bytes,
@@ -214,8 +218,10 @@ int gnr_render_chain_bwd(const GnrScene* scene, int rn, int dn, const float* lev
  * a, nvalid [nrays*dn] -> gbar, gdbar [nrays*dn,16] and dtail [gnr_ray_tail_grad_floats()] = dWq, dWk, dWv, dWfc [16][16],
  * dLNw, dLNb [16], d w_eff [16], d b_eff (out_geometry_fc folded into one row; unfolded by the caller).  The two ELU
  * layers of geometry_fc around it: gnr_geo_dual_fwd / gnr_geo_dual_bwd below.                                        */
+/* fine_depth_out [B,rn,rays->fdn] (nullable): this (coarse) pass's inverse-CDF resampling, sorted (render_ops.py:172-229,
+ * renderer.py:146-148); rays->fine_u = the is_train draws, NULL = eval midpoints. */
 int gnr_render_tail_fwd_train(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn, const float* level_weights,
-                              GnrRenderOut* out, void* workspace, size_t workspace_bytes,
+                              GnrRenderOut* out, float* fine_depth_out, void* workspace, size_t workspace_bytes,
                               void* train_workspace, size_t train_workspace_bytes, void* stream);
 int gnr_ray_tail_grad_floats(void);
 /* geometry_fc (86 -> 64 -> 16, two ELUs; ibrnet.py:488-489) on dual numbers, around gnr_ray_tail_dual_bwd.  canonical_dev =
@@ -281,8 +287,12 @@ const char* gnr_last_error(void);
  * path).  gnr_timing_end() waits for the events and writes one line per label -- "label count total_ms\n", label =
  * "kernel@entry point" (k_chain / k_ray: "k_chain.volume", "k_chain.render", "...train") -- into `report` (NUL-terminated,
  * truncated to report_bytes); returns the number of launches recorded or a negative error code.
- * gnr_chain_timing_begin/end: the same switch, reduced to the average duration of the k_chain launches on volume points. */
+ * Event pairs around EVERY launch cost a few microseconds of pipeline bubble each (11 launches per forward step: ~2 % of the
+ * step), so a headline measurement brackets its dominant kernel only (gnr_timing_begin_only) and takes the full table in a
+ * separate pass.  gnr_chain_timing_begin/end: the same switch for the k_chain launches on volume points, reduced to their
+ * average duration. */
 int gnr_timing_begin(void);
+int gnr_timing_begin_only(const char* label_substring);   /* bracket only the launches whose label contains the substring */
 int gnr_timing_end(char* report, size_t report_bytes);
 int gnr_chain_timing_begin(void);
 int gnr_chain_timing_end(float* avg_ms_out, int* count_out);

@@ -1,14 +1,15 @@
-"""Differentiable PyTorch statement of the volumetric path, for TRAINING ONLY.
+"""TEST INFRASTRUCTURE: the differentiable PyTorch statement of the volumetric path, the reference the
+HIP backward kernels (csrc/gnr_bwd.inc) are tested against.  Not part of the product: graspnerf_amd/ trains through its HIP
+twin pairs only and raises without a GPU.
 
-On the GPU every piece of the path has a HIP twin pair behind an autograd.Function (renderer.py: _SampleVolumeFn,
-_DepthMeanFn, _RenderChainFn, _RayTailFn, _CompositeFn; csrc/gnr_bwd.inc); this module then only supplies the glue between
-them (ray geometry, fine-depth resampling, the per-scene output dicts).  Its full statement of the math -- same algebra and
-the same parameter tensors as the kernels (live `nn.Parameter`s of the mirror modules, reference state-dict names), nothing
-detached, the in-forward VJP taken with `create_graph=True` (`ibrnet.py:497-504`) -- is the reference the backward kernels
-are tested against (`taps`), the training path off the GPU, and what the cfg['hip_*'] switches fall back to.  Inference and
-evaluation never come here (`NeuralRayRenderer.forward` routes to the HIP path whenever autograd is off).
-
-Layout: one scene per call, view-major flat arrays [V, N, C] with N = rn*dn points.
+* the path itself, one scene per call, view-major flat arrays [V, N, C] with N = rn*dn points, live `nn.Parameter`s under
+  the reference's state-dict names, nothing detached, the in-forward VJP taken with `create_graph=True` (ibrnet.py:497-504);
+  `taps` keeps intermediates (and their gradients) for the stage-by-stage checks of tests/test_bwd_twins.py
+* `attn_core` / `tail_backward`: the dual-number reverse pass of the per-ray tail in plain tensor algebra, checked against
+  autograd's double backward (tests/test_ray_tail.py) and what k_ray_dual_bwd / k_geo_dual_* are compared with
+* `ReferenceRenderer`: NeuralRayRenderer whose TRAINING forward runs this statement (any device), so that the model
+  mirror, the losses and the trainer can be pinned against the reference's own backward (golden_train_step.npz) on the CPU,
+  and the HIP training path against it on the GPU.
 ref: src/nr/network/renderer.py:62-220, render_ops.py, dist_decoder.py, aggregate_net.py, ibrnet.py:447-513.
 """
 import numpy as np
@@ -264,7 +265,7 @@ def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
     return out
 
 
-def _scene_outputs(P, agg, sdf, col, o, B, rn):
+def _scene_outputs_UNUSED(P, agg, sdf, col, o, B, rn):
     """Per-scene output dicts (renderer.py:110-138 keys) from the batched results of a HIP composite callable."""
     outs = []
     var = P[agg + 'deviation_network.variance'].reshape(1, 1)
@@ -407,3 +408,209 @@ def render_scenes(P, que, hw, cfg, fine_u, chains):
     for o, f in zip(coarse, fine):
         o.update({k + '_fine': v for k, v in f.items()})
     return coarse
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the per-ray tail's backward incl. the second-order path, in tensor algebra (moved here from the product's ray_tail.py)
+# ----------------------------------------------------------------------------------------------------------------------
+from graspnerf_amd.ray_tail import TAIL_KEYS, unfold_out_geometry      # noqa: E402
+
+
+def _elu_d1(x):        # ELU'(x)
+    return torch.where(x > 0, torch.ones_like(x), torch.exp(x))
+
+
+def _elu_d2(x):        # ELU''(x)
+    return torch.where(x > 0, torch.zeros_like(x), torch.exp(x))
+
+
+def embed_tangent(p, gamma):
+    """d/d eps of embed(p + eps*gamma) for the 21-channel embedder (neus.py:21-66): [p, sin p, cos p, sin 2p, ...]."""
+    out = [gamma]
+    for f in (1.0, 2.0, 4.0):
+        out += [f * torch.cos(f * p) * gamma, -f * torch.sin(f * p) * gamma]
+    return torch.cat(out, -1)
+
+
+def attn_core(W, g, gd, a, nvalid):
+    """Dual reverse pass over [+PE, attention, fc + residual, LayerNorm, folded out_geometry_fc, clip / mask].
+    W: dict with wq, wk, wv, wfc [16,16], lnw, lnb [16], weff [16], beff [].   g, gd [R,dn,16] value / tangent of the
+    geometry_fc output; a [R,dn]; nvalid [R,dn].
+    -> gbar, gdbar [R,dn,16] and a dict of gradients for the entries of W."""
+    R, dn, _ = g.shape
+    t = g + sinusoid_on(dn, g)[None]
+    td = gd
+    heads = lambda x, w: (x @ w.t()).reshape(R, dn, 4, 4).transpose(1, 2)           # [R,4,dn,4]
+    merge = lambda x: x.transpose(1, 2).reshape(R, dn, 16)
+    q, k, v = heads(t, W['wq']), heads(t, W['wk']), heads(t, W['wv'])
+    qd, kd, vd = heads(td, W['wq']), heads(td, W['wk']), heads(td, W['wv'])
+    rowok = (nvalid > 1).reshape(R, 1, dn, 1)
+    S = (0.5 * q) @ k.transpose(2, 3)
+    Sd = ((0.5 * qd) @ k.transpose(2, 3) + (0.5 * q) @ kd.transpose(2, 3)) * rowok
+    Pm = torch.softmax(S.masked_fill(~rowok, -1e9), -1)
+    r = torch.sum(Pm * Sd, -1, keepdim=True)
+    Pd = Pm * (Sd - r)
+    o, od = merge(Pm @ v), merge(Pd @ v + Pm @ vd)
+    y, yd = o @ W['wfc'].t() + t, od @ W['wfc'].t() + td
+    # LayerNorm (eps 1e-6) on dual numbers
+    c = y - y.mean(-1, keepdim=True)
+    rs = torch.rsqrt((c * c).mean(-1, keepdim=True) + 1e-6)
+    xh = c * rs
+    cd = yd - yd.mean(-1, keepdim=True)
+    m1 = (xh * cd).mean(-1, keepdim=True)
+    xhd = rs * (cd - xh * m1)
+    n, nd = W['lnw'] * xh + W['lnb'], W['lnw'] * xhd
+    u = n @ W['weff'] + W['beff']
+    m = ((u >= -1) & (u <= 1) & (nvalid >= 1)).to(g.dtype)
+    sbar, sdbar = a * m, m                                                # seeds: d Phi / d u, d Phi / d u_dot
+    G = {'weff': torch.sum(sbar[..., None] * n + sdbar[..., None] * nd, (0, 1)), 'beff': sbar.sum()}
+    nbar, ndbar = sbar[..., None] * W['weff'], sdbar[..., None] * W['weff']
+    G['lnw'], G['lnb'] = torch.sum(nbar * xh + ndbar * xhd, (0, 1)), nbar.sum((0, 1))
+    xhbar, e = W['lnw'] * nbar, W['lnw'] * ndbar
+    E1 = torch.sum(e * xh, -1, keepdim=True)
+    rsbar = torch.sum(e * xhd, -1, keepdim=True) / rs
+    cdbar = rs * (e - xh * E1 / 16)
+    xhbar = xhbar - rs * (m1 * e + (E1 / 16) * cd)
+    ydbar = cdbar - cdbar.mean(-1, keepdim=True)
+    cbar = rs * xhbar
+    rsbar = rsbar + torch.sum(xhbar * c, -1, keepdim=True)
+    cbar = cbar + (2.0 / 16) * c * (-0.5 * rs ** 3 * rsbar)
+    ybar = cbar - cbar.mean(-1, keepdim=True)
+    # fc + residual
+    tbar, tdbar = ybar.clone(), ydbar.clone()
+    G['wfc'] = torch.einsum('rio,rik->ok', ybar, o) + torch.einsum('rio,rik->ok', ydbar, od)
+    split = lambda x: x.reshape(R, dn, 4, 4).transpose(1, 2)
+    obar, odbar = split(ybar @ W['wfc']), split(ydbar @ W['wfc'])
+    # attention
+    vbar = Pm.transpose(2, 3) @ obar + Pd.transpose(2, 3) @ odbar
+    vdbar = Pm.transpose(2, 3) @ odbar
+    Pbar = obar @ v.transpose(2, 3) + odbar @ vd.transpose(2, 3)
+    Pdbar = odbar @ v.transpose(2, 3)
+    cst = torch.sum(Pdbar * Pm, -1, keepdim=True)
+    Sdbar = Pm * (Pdbar - cst) * rowok
+    Pbar2 = Pbar + Pdbar * (Sd - r) - cst * Sd
+    Sbar = Pm * (Pbar2 - torch.sum(Pm * Pbar2, -1, keepdim=True)) * rowok
+    qbar = 0.5 * (Sbar @ k + Sdbar @ kd)
+    qdbar = 0.5 * (Sdbar @ k)
+    kbar = 0.5 * (Sbar.transpose(2, 3) @ q + Sdbar.transpose(2, 3) @ qd)
+    kdbar = 0.5 * (Sdbar.transpose(2, 3) @ q)
+    for name, xb, xdb in (('wq', qbar, qdbar), ('wk', kbar, kdbar), ('wv', vbar, vdbar)):
+        xb, xdb = merge(xb), merge(xdb)
+        G[name] = torch.einsum('rio,rik->ok', xb, t) + torch.einsum('rio,rik->ok', xdb, td)
+        tbar = tbar + xb @ W[name]
+        tdbar = tdbar + xdb @ W[name]
+    return tbar, tdbar, G
+
+
+
+def tail_weights(P, agg):
+    """The tail's parameters under the names attn_core uses (out_geometry_fc folded: two linears, no activation)."""
+    a = agg + 'agg_impl.'
+    wa, ba = P[a + 'out_geometry_fc.0.weight'], P[a + 'out_geometry_fc.0.bias']
+    wb, bb = P[a + 'out_geometry_fc.1.weight'], P[a + 'out_geometry_fc.1.bias']
+    return {'wq': P[a + 'ray_attention.w_qs.weight'], 'wk': P[a + 'ray_attention.w_ks.weight'],
+            'wv': P[a + 'ray_attention.w_vs.weight'], 'wfc': P[a + 'ray_attention.fc.weight'],
+            'lnw': P[a + 'ray_attention.layer_norm.weight'], 'lnb': P[a + 'ray_attention.layer_norm.bias'],
+            'weff': (wb @ wa)[0], 'beff': (wb @ ba + bb)[0]}
+
+
+def tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, core=attn_core, geo=None):
+    """stats [N,65] = (mean 32, var 32, wbar), nvalid [N], pts [N,3] (N = rn*dn), a [rn,dn], gamma [rn,dn,3].
+    -> d stats [N,65] and {state-dict name: gradient} for geometry_fc, ray_attention, out_geometry_fc of `agg`.
+    `core` = attn_core or the HIP kernel's wrapper (same signature); `geo` = None (the two geometry_fc layers in tensor
+    algebra, below) or hip_geo(...): k_geo_dual_fwd / k_geo_dual_bwd."""
+    assert geo is None
+    pre = agg + 'agg_impl.'
+    W1, b1 = P[pre + 'geometry_fc.0.weight'], P[pre + 'geometry_fc.0.bias']
+    W2, b2 = P[pre + 'geometry_fc.2.weight'], P[pre + 'geometry_fc.2.bias']
+    p = pts.detach()
+    emb = torch.cat([p] + [fn(p * f) for f in (1.0, 2.0, 4.0) for fn in (torch.sin, torch.cos)], -1)
+    embd = embed_tangent(p, gamma.reshape(-1, 3))
+    x = torch.cat([stats, emb], -1)
+    h1p = x @ W1.t() + b1
+    e1 = _elu_d1(h1p)
+    h1, h1pd = F.elu(h1p), embd @ W1[:, 65:].t()
+    h1d = e1 * h1pd
+    gp = h1 @ W2.t() + b2
+    e2 = _elu_d1(gp)
+    gpd = h1d @ W2.t()
+    W = tail_weights(P, agg)
+    gbar, gdbar, G = core(W, F.elu(gp).reshape(rn, dn, 16), (e2 * gpd).reshape(rn, dn, 16), a, nvalid.reshape(rn, dn))
+    gbar, gdbar = gbar.reshape(-1, 16), gdbar.reshape(-1, 16)
+    gpbar = e2 * gbar + _elu_d2(gp) * gpd * gdbar
+    gpdbar = e2 * gdbar
+    h1bar, h1dbar = gpbar @ W2, gpdbar @ W2
+    h1pbar = e1 * h1bar + _elu_d2(h1p) * h1pd * h1dbar
+    h1pdbar = e1 * h1dbar
+    dW1 = h1pbar.t() @ x
+    dW1[:, 65:] += h1pdbar.t() @ embd
+    grads = {pre + 'geometry_fc.0.weight': dW1, pre + 'geometry_fc.0.bias': h1pbar.sum(0),
+             pre + 'geometry_fc.2.weight': gpbar.t() @ h1 + gpdbar.t() @ h1d, pre + 'geometry_fc.2.bias': gpbar.sum(0)}
+    for k, name in (('wq', 'w_qs'), ('wk', 'w_ks'), ('wv', 'w_vs'), ('wfc', 'fc')):
+        grads[pre + 'ray_attention.' + name + '.weight'] = G[k]
+    grads[pre + 'ray_attention.layer_norm.weight'], grads[pre + 'ray_attention.layer_norm.bias'] = G['lnw'], G['lnb']
+    grads.update(unfold_out_geometry(P, agg, G['weff'], G['beff']))
+    return h1pbar @ W1[:, :65], grads
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# NeuralRayRenderer whose training forward is this statement
+# ----------------------------------------------------------------------------------------------------------------------
+from graspnerf_amd.renderer import NeuralRayRenderer      # noqa: E402
+
+
+class ReferenceRenderer(NeuralRayRenderer):
+    """Same module (parameters, backbones, cfg, RNG draw order, output dict) as the product's NeuralRayRenderer; in
+    training mode the volumetric path is differentiated through the PyTorch statement above instead of the HIP twin
+    pairs.  `use_reference_statement(net)` swaps the class of an existing GraspNeRF's nr_net in place."""
+
+    def _render_autograd(self, que, ref, _prep=None):
+        P = self._params()
+        rn, chunk, fdn = que['coords'].shape[1], self.cfg['ray_batch_num'], self.cfg['fine_depth_sample_num']
+        parts = []
+        for r0 in range(0, rn, chunk):
+            u = torch.rand([1, min(chunk, rn - r0), fdn])                  # render_ops.py:204-205 (CPU generator)
+            for net in (self.agg_net, self.fine_agg_net):
+                net.train_step_bookkeeping()
+            q = {'coords': que['coords'][0, r0:r0 + chunk], 'pose': que['poses'][0], 'K': que['Ks'][0],
+                 'depth_range': que['depth_range'][0]}
+            if 'imgs' in que:
+                q['imgs'] = que['imgs']
+            parts.append(render(P, ref, q, self._render_cfg(), u[0]))
+        out = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
+        if not self.cfg['render_depth']:
+            out.pop('render_depth', None), out.pop('render_depth_fine', None)
+        return out
+
+    def sample_volume(self, ref_imgs_info, _prep=None, is_train=False):
+        if self._use_autograd(is_train):
+            return sample_volume(self._params(), ref_imgs_info, self.cfg['volume_resolution'])
+        return super().sample_volume(ref_imgs_info, _prep, is_train)
+
+    def predict_mean_for_depth_loss(self, ref_imgs_info, _prep=None, is_train=False):
+        if not self._use_autograd(is_train):
+            return super().predict_mean_for_depth_loss(ref_imgs_info, _prep, is_train)
+        h, w = ref_imgs_info['imgs'].shape[-2:]
+        rfn = ref_imgs_info['imgs'].shape[0]
+        coords = self.gen_depth_loss_coords(h, w, ref_imgs_info['imgs'].device)
+        P = self._params()
+        mc = depth_mean(P, ref_imgs_info, coords, 'dist_decoder.')
+        mf = depth_mean(P, ref_imgs_info, coords, 'fine_dist_decoder.')
+        return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
+                'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]}
+
+    def _train_prep(self, ref_imgs_info, rn=0):
+        return None                                                        # no HIP workspaces on this route
+
+    def _need_gpu(self, t):
+        pass
+
+    def forward_scenes(self, datas):
+        return None                                                        # scene by scene, like the reference
+
+
+def use_reference_statement(net, on=True):
+    """GraspNeRF `net`: route its nr_net's training forward through this module (on=True) or back through the product's HIP
+    twin pairs (on=False).  Parameters, buffers and cfg are untouched (class swap)."""
+    net.nr_net.__class__ = ReferenceRenderer if on else NeuralRayRenderer
+    return net

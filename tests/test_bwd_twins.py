@@ -1,4 +1,4 @@
-"""Backward twins of the HIP path against PyTorch autograd over graspnerf_amd/autograd_path.py (which is itself pinned
+"""Backward twins of the HIP path against PyTorch autograd over tests/reference_autograd.py (which is itself pinned
 to the reference's backward by tests/test_train_step.py).  Round 1: gnr_depth_mean_bwd."""
 import numpy as np
 import pytest
@@ -34,7 +34,7 @@ def test_bwd_blob_layout(weights_np):
 @pytest.mark.parametrize('level,pn', [('coarse', 333), ('fine', 64)])
 def test_depth_mean_bwd_matches_autograd(level, pn, weights_np):
     from graspnerf_amd.hotpath import HotPath, batch_scenes
-    from graspnerf_amd import autograd_path as ag
+    import reference_autograd as ag
     hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
     hp.set_bwd_weights(weights.pack_bwd(weights.canonical_blob(weights_np, 'coarse')),
                        weights.pack_bwd(weights.canonical_blob(weights_np, 'fine')))
@@ -93,7 +93,7 @@ def _nat(x8):
 @pytest.fixture(scope='module')
 def vol_bwd_case(weights_np):
     from graspnerf_amd.hotpath import HotPath, batch_scenes
-    from graspnerf_amd import autograd_path as ag
+    import reference_autograd as ag
     res = 16
     hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
     can = weights.canonical_blob(weights_np, 'coarse')
@@ -225,7 +225,7 @@ def test_volume_bwd_complete(vol_bwd_case):
 def test_volume_bwd_other_shapes(V, res, B, weights_np):
     """View counts 2..8, grids whose point count is not a multiple of the 16-point tile, several scenes per call."""
     from graspnerf_amd.hotpath import HotPath, batch_scenes
-    from graspnerf_amd import autograd_path as ag
+    import reference_autograd as ag
     from graspnerf_amd.synth import CONFIGS
     hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
     can = weights.canonical_blob(weights_np, 'coarse')
@@ -260,7 +260,7 @@ def test_render_chain_twin_matches_autograd(V, rn, dn, weights_np):
     """One render pass: statistics / colours of the HIP chain against the autograd chain, and the gradients a random
     upstream (d stats, d colours) produces for the level's parameters and both feature maps (fine level)."""
     from graspnerf_amd.hotpath import HotPath, batch_scenes
-    from graspnerf_amd import autograd_path as ag
+    import reference_autograd as ag
     from graspnerf_amd.synth import CONFIGS
     hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
     hp.set_bwd_weights(weights.pack_bwd(weights.canonical_blob(weights_np, 'coarse')), weights.pack_bwd(weights.canonical_blob(weights_np, 'fine')))
@@ -271,7 +271,7 @@ def test_render_chain_twin_matches_autograd(V, rn, dn, weights_np):
     depth = torch.sort(torch.from_numpy(rng.uniform(0.25, 0.75, (rn, dn)).astype(np.float32)), -1)[0].cuda()
     cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
     bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
-    stats, colors, ctx = hp.render_chain_train(bq, depth[None], 'fine', cfg, prep)
+    stats, colors, geo, ctx = hp.render_chain_train(bq, depth[None], 'fine', cfg, prep)
     # autograd chain on the same points
     P = {k: torch.from_numpy(v).cuda().requires_grad_(True) for k, v in weights_np.items()}
     tref = {k: torch.from_numpy(v).cuda() for k, v in ref.items()}

@@ -1,10 +1,13 @@
-"""Per-ray tail of the render path in training: the dual-number backward (graspnerf_amd/ray_tail.py, k_ray_dual_bwd) against
-autograd's double backward of autograd_path.sdf_tail (second order through the in-forward SDF gradient, ibrnet.py:497-504)."""
+"""Per-ray tail of the render path in training: the dual-number backward (tensor algebra: tests/reference_autograd.py; device:
+graspnerf_amd/ray_tail.py over k_geo_dual_fwd / k_ray_dual_bwd / k_geo_dual_bwd) against autograd's double backward of
+reference_autograd.sdf_tail (second order through the in-forward SDF gradient, ibrnet.py:497-504)."""
 import numpy as np
 import pytest
 import torch
 
-from graspnerf_amd import autograd_path as ag, ray_tail as rt, weights
+from graspnerf_amd import ray_tail as prt, weights
+import reference_autograd as ag
+rt = ag            # attn_core / tail_backward / tail_weights in tensor algebra live next to the statement
 from graspnerf_amd.synth import make_scene
 
 AGG = 'agg_net.'
@@ -12,7 +15,7 @@ AGG = 'agg_net.'
 
 def _tail_params(weights_np, dtype, device='cpu', agg=AGG):
     return {agg + 'agg_impl.' + k: torch.from_numpy(weights_np[agg + 'agg_impl.' + k]).to(device=device, dtype=dtype).requires_grad_(True)
-            for k in rt.TAIL_KEYS}
+            for k in prt.TAIL_KEYS}
 
 
 def _case(seed, rn, dn, dtype, device='cpu'):
@@ -52,30 +55,14 @@ def test_dual_backward_equals_double_backward_fp64(rn, dn, weights_np):
         assert _rel(G[k], g) < 1e-12, k
 
 
-class _FakeHot:
-    generation = 0
-
-    def check_generation(self, g):
-        assert g == self.generation
-
-
-def test_tail_function_wiring_cpu(weights_np):
-    """_RayTailFn (tensor-algebra core) inside autograd: same gradients as sdf_tail with create_graph, float32."""
-    from graspnerf_amd.renderer import _RayTailFn
-    rn, dn = 4, 16
-    P = _tail_params(weights_np, torch.float32)
-    stats, nvalid, pts, a, gamma = _case(3, rn, dn, torch.float32)
-    sdf_ref, grad_ref, dstats_ref, G_ref = _autograd_reference(P, stats, nvalid, pts, rn, dn, a, gamma)
-    st66 = torch.cat([stats, nvalid[:, None]], 1).requires_grad_(True)
-    sdf, grad = _RayTailFn.apply(_FakeHot(), 'coarse', AGG, pts, rn, dn, sdf_ref, grad_ref, False, st66,
-                                 *[P[AGG + 'agg_impl.' + k] for k in rt.TAIL_KEYS])
-    assert torch.equal(sdf, sdf_ref) and torch.equal(grad, grad_ref)
-    for p in P.values():
-        p.grad = None
-    ((a * sdf).sum() + (gamma * grad).sum()).backward()
-    assert _rel(st66.grad[:, :65], dstats_ref) < 2e-4 and float(st66.grad[:, 65].abs().max()) == 0
-    for k, g in G_ref.items():
-        assert _rel(P[k].grad, g) < 2e-4, k
+def _hip_core(hp, level):
+    """k_ray_dual_bwd through the C ABI with attn_core's signature."""
+    def core(W, g, gd, a, nvalid):
+        gbar, gdbar, dt = hp.ray_tail_dual_bwd(level, g, gd, a, nvalid)
+        m = lambda k: dt[256 * k:256 * (k + 1)].reshape(16, 16)
+        return gbar, gdbar, {'wq': m(0), 'wk': m(1), 'wv': m(2), 'wfc': m(3), 'lnw': dt[1024:1040], 'lnb': dt[1040:1056],
+                             'weff': dt[1056:1072], 'beff': dt[1072]}
+    return core
 
 
 @pytest.mark.gpu
@@ -94,7 +81,7 @@ def test_dual_core_kernel_matches_tensor_algebra(R, dn, level, weights_np):
     a = torch.randn(R, dn, generator=g).cuda()
     nvalid = torch.randint(0, 4, (R, dn), generator=g).float().cuda()
     tb, tdb, G = rt.attn_core(W, gg, gd, a, nvalid)
-    hb, hdb, H = rt.hip_core(hp, level)(W, gg, gd, a, nvalid)
+    hb, hdb, H = _hip_core(hp, level)(W, gg, gd, a, nvalid)
     torch.cuda.synchronize()
     assert _rel(hb, tb) < 5e-4 and _rel(hdb, tdb) < 5e-4
     for k in G:
@@ -116,13 +103,15 @@ def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
     depth = torch.sort(torch.from_numpy(rng.uniform(0.25, 0.75, (rn, dn)).astype(np.float32)), -1)[0].cuda()
     cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
     bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
-    stats, colors, ctx = hp.render_chain_train(bq, depth[None], 'fine', cfg, prep)
-    fw = hp.render_tail_train(ctx, bq, depth[None], colors, cfg)
+    stats, colors, geo, ctx = hp.render_chain_train(bq, depth[None], 'fine', cfg, prep)
+    fw = hp.render_tail_train(ctx, bq, depth[None], colors)
     sdf, grad = fw['sdf_values'], fw['sdf_gradient']
     agg = 'fine_agg_net.'
     P = _tail_params(weights_np, torch.float32, 'cuda', agg)
     q1 = {'coords': bq['coords'][0], 'pose': bq['pose'][0], 'K': bq['K'][0]}
-    pts, _ = ag.ray_points(q1, depth)
+    pts, qdir = ag.ray_points(q1, depth)
+    # the ray geometry the kernels export (S2, render_ops.py:4-39) against the statement's
+    assert _rel(geo['pts'], pts) < 1e-6 and _rel(geo['qdir'], qdir) < 1e-6 and torch.equal(geo['depth'][0], depth)
     a = torch.from_numpy(rng.standard_normal((rn, dn)).astype(np.float32)).cuda()
     gamma = torch.from_numpy(rng.standard_normal((rn, dn, 3)).astype(np.float32)).cuda()
     st = stats[0]
@@ -130,10 +119,11 @@ def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
     torch.cuda.synchronize()
     assert float((sdf[0] - sdf_ref).abs().max()) < 1e-3 * max(1.0, float(sdf_ref.abs().max()))
     assert _rel(grad[0], grad_ref) < 1e-3
-    with torch.no_grad():
-        dstats, G = rt.tail_backward(P, agg, st[:, :65], st[:, 65], pts, rn, dn, a, gamma, rt.hip_core(hp, 'fine'))
+    hp.can_dev = {'fine': torch.from_numpy(weights.canonical_blob(weights_np, 'fine')).cuda()}
+    with torch.no_grad():                                                  # the product's device orchestration
+        dstats, G = prt.tail_backward(hp, 'fine', P, agg, st, geo['pts'], rn, dn, a, gamma)
     torch.cuda.synchronize()
-    assert _rel(dstats, dstats_ref) < 1e-3
+    assert _rel(dstats[:, :65], dstats_ref) < 1e-3 and float(dstats[:, 65].abs().max()) == 0
     for k, g in G_ref.items():
         assert _rel(G[k], g) < 2e-3, k
 
@@ -141,7 +131,7 @@ def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
 @pytest.mark.gpu
 @pytest.mark.parametrize('R,dn,level', [(70, 40, 'coarse'), (5, 7, 'fine'), (130, 64, 'coarse')])
 def test_composite_backward_kernel(R, dn, level, weights_np):
-    """k_composite_bwd against autograd over autograd_path.composite (NeuS alpha, cumprod compositing, eikonal term) for a
+    """k_composite_bwd against autograd over reference_autograd.composite (NeuS alpha, cumprod compositing, eikonal term) for a
     random upstream on every output, including the gradient of deviation_network.variance."""
     from graspnerf_amd.hotpath import HotPath
     hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
@@ -187,18 +177,18 @@ def test_geometry_dual_kernels(P_, level, weights_np):
     if dn < 3:
         rn, dn = 1, P_
     stats, nvalid, pts, a, gamma = _case(P_, rn, dn, torch.float32, 'cuda')
+    hp.can_dev = {level: canon}
     with torch.no_grad():
-        want_ds, want = rt.tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, rt.hip_core(hp, level))
-        geo = rt.hip_geo(hp, level, canon, lambda d: weights.split_canonical(d, level))
-        got_ds, got = rt.tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, rt.hip_core(hp, level), geo)
+        want_ds, want = rt.tail_backward(P, agg, stats, nvalid, pts, rn, dn, a, gamma, _hip_core(hp, level))
+        got_ds, got = prt.tail_backward(hp, level, P, agg, torch.cat([stats, nvalid[:, None]], 1), pts, rn, dn, a, gamma)
     torch.cuda.synchronize()
-    assert _rel(got_ds, want_ds) < 1e-3
+    assert _rel(got_ds[:, :65], want_ds) < 1e-3
     for k in want:
         assert _rel(got[k], want[k]) < 1e-3, k
 
 
 def test_positive_cumprod_backward_equals_autograd():
-    """autograd_path._CumprodPositive: torch.cumprod's values, and its gradient for strictly positive factors, without the
+    """reference_autograd._CumprodPositive: torch.cumprod's values, and its gradient for strictly positive factors, without the
     `(x == 0).any()` host read of the stock backward."""
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(7, 41, generator=g, dtype=torch.float64) + 1e-10).requires_grad_(True)

@@ -32,11 +32,17 @@ render_depth: true
 """)
 
 
-def build(device='cpu'):
+def build(device='cpu', reference_statement=None):
+    """The model mirror with synthetic parameters.  On the CPU (or with reference_statement=True) its training forward
+    runs the differentiable PyTorch statement of the path (tests/reference_autograd.py: test infrastructure -- the product
+    trains through its HIP twin pairs only and raises without a GPU)."""
     from graspnerf_amd.renderer import GraspNeRF
+    from reference_autograd import use_reference_statement
     net = GraspNeRF(CFG)
     syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()}, strict=True)
+    if reference_statement if reference_statement is not None else (str(device) == 'cpu'):
+        use_reference_statement(net)
     return net.to(device)
 
 
@@ -140,6 +146,55 @@ def test_flat_gradient_allreduce_gloo():
         np.testing.assert_allclose(got, (p.grad / 3.0).numpy(), rtol=1e-6)
 
 
+def _step_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from graspnerf_amd.trainer import Trainer
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    net = build()
+    tr = Trainer(net, {'lr_init': 1e-3})
+    shards = {2: [[0], [1, 2]], 3: [[0], [1, 2], []]}[world][rank]        # ragged / empty shards
+    torch.manual_seed(100 + rank)
+    log = tr.step([scene_data(scene_id=i) for i in shards])
+    sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items() if 'dist_decoder' in k or 'vgn_net.conv_qual' in k or 'agg_net.prob_embed' in k}
+    q.put((rank, sd, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_trainer_step_end_to_end_gloo(world):
+    """Trainer.step over gloo with ragged shards (1 + 2 scenes; world 3 adds a rank with an EMPTY shard, as scene_shard
+    produces when the global batch is smaller than the world): every rank takes part in the flat-gradient all-reduce and
+    ends the step with identical parameters, which moved; the empty rank returns a log without loss terms instead of failing."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ps = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in ps:
+        r, sd, log = q.get(timeout=600)
+        res[r] = (sd, log)
+    for p in ps:
+        p.join(120)
+    ref0 = build().state_dict()
+    moved = 0
+    for k, v in res[0][0].items():
+        for r in range(1, world):
+            assert np.array_equal(v, res[r][0][k]), f'{k}: ranks 0 and {r} diverged'
+        moved += int(not np.array_equal(v, ref0[k].numpy()))
+    assert moved > len(res[0][0]) // 2, 'the optimiser step should have moved the parameters'
+    assert all(np.isfinite(v) for k, v in res[0][1].items() if k.startswith('loss'))
+    if world == 3:
+        assert [k for k in res[2][1] if k.startswith('loss')] == [] and res[2][1]['lr'] == 1e-3
+
+
 def test_optimizer_step_changes_parameters_and_reduces_loss():
     from graspnerf_amd.trainer import Trainer, exp_decay_lr
     assert exp_decay_lr(0) == 1e-4 and exp_decay_lr(100000) == 5e-5 and exp_decay_lr(10 ** 7) == 1e-5
@@ -167,6 +222,14 @@ def test_trainer_with_several_scenes_on_cpu_uses_the_per_scene_loop():
     assert all(p.grad is not None for p in net.parameters())
 
 
+def test_product_refuses_to_train_without_a_gpu():
+    """No PyTorch / CPU fallback in the product: a training forward on host tensors raises (inference raises in HotPath)."""
+    from graspnerf_amd import _lib
+    net = build(reference_statement=False).train()
+    with pytest.raises(_lib.GnrError):
+        net(scene_data())
+
+
 @pytest.mark.gpu
 def test_train_step_on_gpu_matches_reference_gradients():
     """Same check with the model on the MI355X: the volumetric path in HIP in both directions (renderer.py autograd.Functions over
@@ -185,15 +248,18 @@ def test_train_step_on_gpu_matches_reference_gradients():
 
 @pytest.mark.gpu
 def test_hip_and_autograd_training_paths_agree():
-    """The same train-mode forward + backward with the HIP twins switched off (pure autograd over autograd_path.py) and
-    on: outputs and every parameter gradient."""
+    """The same train-mode forward + backward through the differentiable PyTorch statement (tests/reference_autograd.py, pure
+    autograd incl. the double backward) and through the product's HIP twin pairs: outputs and every parameter gradient."""
     from graspnerf_amd.trainer import train_losses
     from graspnerf_amd import losses
+    from reference_autograd import use_reference_statement
     net = build('cuda').train()
     data = scene_data('cuda')
     res = {}
     for hip in (False, True):
-        net.nr_net.cfg['hip_render_backward'] = net.nr_net.cfg['hip_volume_backward'] = hip
+        use_reference_statement(net, on=not hip)
+        for a in (net.nr_net.agg_net, net.nr_net.fine_agg_net):
+            a.step = 0
         net.zero_grad(set_to_none=True)
         torch.manual_seed(11)
         out = net(data)
@@ -201,7 +267,9 @@ def test_hip_and_autograd_training_paths_agree():
         torch.cuda.synchronize()
         res[hip] = ({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v) and v.dtype.is_floating_point},
                     {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    assert set(res[False][0]) == set(res[True][0])
     for k, v in res[False][0].items():
+        assert res[True][0][k].shape == v.shape, k
         assert (res[True][0][k] - v).abs().max() <= 2e-4 + 1e-3 * v.abs().max(), k
     for k, g in res[False][1].items():
         d = (res[True][1][k] - g).abs().max().item()

@@ -1,7 +1,6 @@
 """End-to-end train step (BASELINE.json configs[4]): backbones + volumetric path + grasp head + losses, backward, one flat
 gradient all-reduce over RCCL, Adam.  `--scenes` scenes per GPU per step (default 8), full-size scenes (6 views 288x512,
-40^3 volume, 512 rays x (40+40) samples).  The volumetric path runs in HIP in both directions (--tail selects how the
-per-ray tail's second-order backward runs); --coords-rng cpu (default) draws the depth-loss pixels with the reference's CPU
+40^3 volume, 512 rays x (40+40) samples).  The volumetric path runs in HIP in both directions; --coords-rng cpu (default) draws the depth-loss pixels with the reference's CPU
 randperm stream (through gnr_host_randperm_prefix), device on the GPU generator.
     python tools/train_step_bench.py [--scenes 8] [--steps 3] [--warmup 1]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py ..."""
@@ -37,7 +36,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--scenes', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--warmup', type=int, default=1)
-ap.add_argument('--tail', default='hip', choices=['hip', 'torch', 'autograd'], help='per-ray tail backward: HIP dual-number core, the same in tensor algebra, or autograd double backward')
 ap.add_argument('--coords-rng', default='cpu', choices=['cpu', 'device'], help="depth-loss pixel draw: the reference's CPU randperm stream, or the GPU generator")
 ap.add_argument('--sync-debug', action='store_true')
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark: let MIOpen search its convolution solvers')
@@ -51,7 +49,6 @@ dist = None
 if 'TORCHELASTIC_RUN_ID' in os.environ or world > 1:
     import torch.distributed as dist
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-CFG['hip_ray_tail'] = {'hip': True, 'torch': 'torch', 'autograd': False}[a.tail]
 CFG['depth_coords_rng'] = a.coords_rng
 net = GraspNeRF(CFG)
 syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
@@ -86,7 +83,7 @@ if rank == 0:
     dt = float(tm)
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-                      'scenes_per_gpu': a.scenes, 'ray_tail': a.tail, 'depth_coords_rng': a.coords_rng, 'miopen_find': bool(a.miopen_find), 'backward': {'hip': 'HIP kernels for sample_volume, the per-view chains and the per-ray tails (second order, dual numbers) of both render passes, the depth-mean head, the grasp head weight gradient; torch autograd for NeuS alpha / compositing / losses, the 2D backbones, the grasp head data gradient', 'torch': 'as hip, the dual-number tail core in tensor algebra', 'autograd': 'as hip, the per-ray tail by autograd double backward'}[a.tail],
+                      'scenes_per_gpu': a.scenes, 'depth_coords_rng': a.coords_rng, 'miopen_find': bool(a.miopen_find),
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')}}))
 if a.sync_debug and rank == 0:                      # list every host<->device synchronisation of one step (stderr)
