@@ -48,6 +48,17 @@ def chain_flops(points, views, render):
     return 2.0 * points * (views * (MAC_VIEW_RAY if render else MAC_VIEW_VOL) + MAC_POINT_CHAIN)
 
 
+def recorded_bwd_traffic(scenes):
+    """HBM-side bytes per launch of k_view1_bwd (volume points, 8 scenes) from the same recorded PMC passes, or None."""
+    try:
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
+        k = json.load(open(newest))['kernels']['k_view1_bwd']
+        return (int(k['hbm_bytes_corrected']), os.path.relpath(newest, ROOT)) if scenes == 8 else (None, None)
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
 def recorded_pmc(batch):
     """Counters of the dominant kernel from the committed rocprofv3 PMC passes (newest profiles/r*_pmc_counters.json, made by
     tools/collect_profiles.sh: separate --pmc runs, gfx950 2x read correction applied to FETCH_SIZE).  PMC counters cannot be
@@ -255,7 +266,8 @@ def train_leg(args, world, rank, dev, dist, sync):
             'hip_kernels_ms_per_step': per_step,
             'roofline': {'bound': 'mfma', 'kernel': 'k_view1_bwd on the volume points (gnr_sample_volume_bwd)', 'achieved': round(ach, 3),
                          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'ms_per_launch': round(ms, 4),
-                         'launches_timed': cnt, 'flops_per_launch': fl, 'traffic': None,
+                         'launches_timed': cnt, 'flops_per_launch': fl, 'traffic': recorded_bwd_traffic(n)[0],
+                         'traffic_source': recorded_bwd_traffic(n)[1],
                          'note': 'algorithmic fp32 FLOPs 2*2*(6304+2112+624+264) per (view, point): dX + dW of decoder, prob_embed, '
                                  'ray_dir_fc, neuray gate; the recomputed forward is not counted.  Next to it the kernel scatters '
                                  '4 taps x 64 channels x 4 B = 1 KB of feature-map gradient per (view, point) through L2 atomics'},

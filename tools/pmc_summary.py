@@ -22,9 +22,10 @@ for k, cs in res.items():
     if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
         cs['hbm_bytes_corrected'] = (2 * cs['FETCH_SIZE'] + cs['WRITE_SIZE']) * 1024
 json.dump({
-    'command': 'rocprofv3 --pmc <set> --output-format csv -- python tools/run_hot.py --iters 1   (B=32 scenes, 6 views, 40^3 + 512 rays; '
+    'command': 'rocprofv3 --pmc <set> --output-format csv -- python tools/run_hot.py --iters 1   (forward kernels: B=32 scenes, 6 views, '
+               '40^3 + 512 rays) and -- python tools/time_volume_bwd.py --scenes 8 (k_*_bwd kernels of sample_volume: 8 scenes); '
                'one run per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU SQ_INSTS_MFMA | '
-               'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES | SQ_WAVE_CYCLES GRBM_GUI_ACTIVE)',
+               'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES | SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; tools/collect_profiles.sh',
     'units': 'FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; per-launch averages',
     'note': 'gfx950: FETCH_SIZE under-counts wide (16 B/lane) reads by 2x (MI355X_MICROARCH.md, HBM section); hbm_bytes_corrected = '
             '(2*FETCH_SIZE + WRITE_SIZE)*1024 is the corrected upper bound used for roofline.traffic.',
