@@ -16,7 +16,12 @@ for f in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive
         name = meta[(ff, did)]
         m = re.search(r'gnr::(k_\w+(<[^>]*>)?)', name)
         if m:
-            acc[m.group(1)][cname].append(v)
+            k = m.group(1)
+            # the backward passes (pmc/bwd_*: tools/time_volume_bwd.py, 8 scenes) also launch inference kernels at another batch
+            # size: keep only the training kernels from them
+            if os.sep + 'bwd_' in ff and not ('_bwd' in k or k.endswith(', true>') and k.startswith('k_chain')):
+                continue
+            acc[k][cname].append(v)
 res = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
 for k, cs in res.items():
     if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
