@@ -2,7 +2,10 @@
 numpy images / extrinsics / intrinsics in, (volume, qual, rot, width, seconds) out, and of its `__call__`
 (main.py:185-209) from arrays: `plan()` adds the grasp post-processing (`process`, `select`, main.py:23-84) on the
 device (graspnerf_amd/grasp_post.py).  Loads reference checkpoints (`network_state_dict`, main.py:153-155) unchanged.
-The simulator / Blender loop and image I/O are outside the volumetric path and not rebuilt."""
+`GraspNeRFPlanner` below is the file-I/O half of the reference class (main.py:87-209: rendered PNGs, camera poses, intrinsics,
+fixed depth range -> core -> process/select), with PIL / numpy only.  The simulator / Blender loop that produces those files
+is outside the volumetric path and not rebuilt."""
+import os
 import time
 
 import numpy as np
@@ -73,3 +76,117 @@ def plan(net, images, extrinsics, intrinsics, depth_range=(0.2, 0.8), bbox3d=((-
     if return_volumes:
         grasps['volumes'] = tuple(x.cpu().numpy() for x in (out['volume'], q, r, wd, sel['qual']))
     return grasps, dt
+
+
+# ---- the planner's file I/O (ref: src/nr/main.py:87-209) -----------------------------------------------
+BLENDER2OPENCV = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]], np.float64)      # main.py:104
+SRC_WH = {'vgn_syn': (640, 360)}                                                                          # main.py:100-102
+
+
+def resize_bilinear_u8(img, wh):
+    """cv2.resize(img, wh) for uint8 HxWxC images with its default INTER_LINEAR (main.py:171): half-pixel centres, border
+    replication, OpenCV's fixed-point arithmetic (11-bit coefficients, (.. + 2) >> 2 rounding in the vertical pass), no
+    anti-aliasing -- PIL's BILINEAR filters when downscaling and gives different pixels.  (cv2 is not in this image: written
+    from OpenCV's resize.cpp, checked against float bilinear to 1 LSB in tests/test_planner_io.py.)"""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3
+    sh, sw = img.shape[:2]
+    dw, dh = int(wh[0]), int(wh[1])
+    if (dw, dh) == (sw, sh):
+        return img.copy()
+
+    def axis(dn, sn):
+        f = (np.arange(dn, dtype=np.float64) + 0.5) * (sn / dn) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        w = (f - i0).astype(np.float32)
+        lo = i0 < 0
+        i0[lo], w[lo] = 0, 0.0
+        hi = i0 >= sn - 1
+        i0[hi], w[hi] = sn - 1, 0.0
+        i1 = np.minimum(i0 + 1, sn - 1)
+        c1 = np.clip(np.rint(w.astype(np.float64) * 2048), -32768, 32767).astype(np.int64)      # saturate_cast<short>(w * 2^11)
+        c0 = np.clip(np.rint((1.0 - w.astype(np.float64)) * 2048), -32768, 32767).astype(np.int64)
+        return i0, i1, c0, c1
+    x0, x1, a0, a1 = axis(dw, sw)
+    y0, y1, b0, b1 = axis(dh, sh)
+    src = img.astype(np.int64)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]                       # horizontal pass: int, scale 2^11
+    s0, s1 = rows[y0], rows[y1]
+    out = (((b0[:, None, None] * (s0 >> 4)) >> 16) + ((b1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def read_rgb_png(path):
+    """skimage.io.imread(path)[:, :, :3] (main.py:169-170) through PIL."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert('RGBA' if im.mode in ('RGBA', 'LA', 'P') else 'RGB'))[:, :, :3].copy()
+
+
+class Grasp:
+    """(rotation quaternion x,y,z,w; translation; width) -- the fields of gd.grasp.Grasp(Transform(Rotation, t), width) the
+    callers of the planner read (main.py:79-84, 205)."""
+
+    def __init__(self, quat, translation, width):
+        self.quat, self.translation, self.width = np.asarray(quat, np.float64), np.asarray(translation, np.float64), float(width)
+
+    def __repr__(self):
+        return f'Grasp(t={self.translation.round(4).tolist()}, q={self.quat.round(4).tolist()}, w={self.width:.4f})'
+
+
+class GraspNeRFPlanner:
+    """Mirror of the reference planner (main.py:87-209) on files: `rgb/%04d.png` renderings and `camera_pose.npy`.
+
+    cfg: the reference's yaml as a dict;  checkpoint: `model_best.pth` path or state dict ({'network_state_dict': ...});
+    renderer_root_dir: holds camera_pose.npy (main.py:174);  rgb_dir: the directory of the rendered `%04d.png` images
+    (main.py:168);  database_name: as in the reference's args, e.g. 'vgn_syn/test/packed/packed_170-220/032cd891d9be4a16be5ea4be9f7eca2b/w_0.8'
+    (the trailing `<background>_<size>` sets the down-sampling, main.py:96-103)."""
+
+    def __init__(self, cfg, checkpoint, renderer_root_dir, rgb_dir, database_name='vgn_syn/test/x/x/x/w_0.8', seed=0, device='cuda:0'):
+        tp, _split, _stype, _ssplit, _sid, background_size = database_name.split('/')                 # main.py:96
+        self.tp, self.down_sample = tp, float(background_size.split('_')[1])
+        self.img_wh = (np.array(SRC_WH[tp]) * self.down_sample).astype(int)                            # main.py:103
+        K = np.array([[892.62, 0.0, 639.5], [0.0, 892.62, 359.5], [0.0, 0.0, 1.0]])                    # main.py:105-111
+        K[:2] = K[:2] * self.down_sample
+        if tp == 'vgn_syn':
+            K[:2] /= 2
+        self.K = K
+        self.voxel_size, self.bbox3d = 0.3 / 40, [[-0.15, -0.15, -0.0503], [0.15, 0.15, 0.2497]]       # main.py:90-91
+        self.tsdf_thres_high, self.tsdf_thres_low = 0.0, -0.85                                         # main.py:92-93
+        self.renderer_root_dir, self.rgb_dir, self.seed = renderer_root_dir, rgb_dir, seed
+        self.net = load_model(cfg, checkpoint, device)                                                 # main.py:150-157
+        self.step = 0
+        if isinstance(checkpoint, (str, bytes)):
+            self.step = torch.load(checkpoint, map_location='cpu').get('step', 0)
+        self.selector = GraspSelector(next(self.net.parameters()).device)
+        self._poses = None
+
+    def get_image(self, img_id, round_idx=0):                                                          # main.py:167-172
+        img = read_rgb_png(os.path.join(self.rgb_dir, '%04d.png' % img_id))
+        return resize_bilinear_u8(img, self.img_wh).astype(np.float32)
+
+    def get_pose(self, img_id):                                                                        # main.py:174-177
+        if self._poses is None:
+            ori = np.load(os.path.join(self.renderer_root_dir, 'camera_pose.npy'))
+            self._poses = [np.linalg.inv(p @ BLENDER2OPENCV)[:3, :] for p in ori]
+        return self._poses[img_id].astype(np.float32).copy()
+
+    def get_K(self, img_id):
+        return self.K.astype(np.float32).copy()
+
+    def get_depth_range(self, img_id, round_idx=0, fixed=True):                                        # main.py:182-187
+        if not fixed:
+            raise NotImplementedError('depth-map based ranges need the simulator\'s depth renderings (main.py:185-187)')
+        return np.array([0.2, 0.8])
+
+    def __call__(self, test_view_id, round_idx=0, n_grasp=0, gt_tsdf=None):                            # main.py:189-209
+        images = np.stack([self.get_image(i, round_idx) for i in test_view_id], 0)
+        images = (images.astype(np.float32) / 255).transpose([0, 3, 1, 2])                             # color_map_forward
+        extrinsics = np.stack([self.get_pose(i) for i in test_view_id], 0)
+        intrinsics = np.stack([self.get_K(i) for i in test_view_id], 0)
+        depth_range = np.asarray([self.get_depth_range(i, round_idx, fixed=True) for i in test_view_id], dtype=np.float32)
+        g, toc = plan(self.net, images, extrinsics, intrinsics, depth_range, self.bbox3d, seed=self.seed + round_idx + n_grasp,
+                      selector=self.selector, tsdf_thres_high=self.tsdf_thres_high, tsdf_thres_low=self.tsdf_thres_low,
+                      voxel_size=self.voxel_size)
+        grasps = [Grasp(q, t, w) for q, t, w in zip(g['quat'], g['pos'], g['width'])]
+        return grasps, g['score'], toc

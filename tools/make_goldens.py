@@ -250,6 +250,20 @@ def run_f1(renderer, weights, min_margin={'cfg1': 1e-4, 'cfg2': 1e-6}, max_tries
     print('f1 golden:', {k: (v.shape if hasattr(v, 'shape') and v.shape else v) for k, v in out.items()})
 
 
+def run_ckpt_keys(renderer):
+    """The layout of a reference checkpoint (`torch.save({'network_state_dict': net.state_dict(), ...})`, trainer side;
+    loaded at main.py:153-155): every key of the reference's own GraspNeRF(cfg).state_dict() with its shape, in order.
+    A 4.66 M-parameter checkpoint cannot be a fixture; its key / shape list can (tests build a `model_best.pth` from it)."""
+    cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
+    net = renderer.GraspNeRF(cfg)
+    sd = net.state_dict()
+    names = np.array(list(sd.keys()))
+    shapes = np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()])
+    np.savez_compressed(ROOT + '/tests/golden/golden_ckpt_keys.npz', names=names, shapes=shapes,
+                        dtypes=np.array([str(v.dtype) for v in sd.values()]))
+    print('checkpoint layout golden:', len(names), 'tensors,', sum(v.numel() for v in sd.values()), 'values')
+
+
 def run_full_forward(renderer):
     """GraspNeRF.forward (backbones + render + sample_volume + depth-mean head + grasp head), eval mode,
     cfg1 shape, parameters from synth_state_dict.  ref: renderer.py:268-331."""
@@ -421,6 +435,8 @@ def main():
         return run_losses()
     if '--full-only' in sys.argv:
         return run_full_forward(renderer)
+    if '--ckpt-keys-only' in sys.argv:
+        return run_ckpt_keys(renderer)
     if '--f1-only' in sys.argv:
         return run_f1(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     if '--train-only' in sys.argv:
@@ -449,6 +465,7 @@ def main():
             print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
     run_train_mode(renderer, weights)
     run_f1(renderer, weights)
+    run_ckpt_keys(renderer)
     run_full_forward(renderer)
     run_losses()
     run_post()
