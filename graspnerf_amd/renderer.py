@@ -271,6 +271,9 @@ class NeuralRayRenderer(nn.Module):
             ('fine_depth_use_all', not c['fine_depth_use_all']), ('disable_view_dir', not c['disable_view_dir']),
             ('volume_type', list(c.get('volume_type', ['sdf'])) == ['sdf'])) if not ok]
         if unsupported:
+            # Not configured by the reference's only yaml.  disable_view_dir cannot run in the reference either with
+            # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None); fine_depth_use_all renders dn + fdn = 80
+            # samples per ray (the kernels hold <= 64 per ray) and needs another sample_num; use_vis adds a fourth decoder branch.
             raise NotImplementedError(f'config options outside configs/nrvgn_sdf.yaml are not built: {unsupported}')
         self.vis_encoder = DefaultVisEncoder(c['vis_encoder_cfg'])
         self.dist_decoder = _DistDecoderParams()
@@ -433,9 +436,11 @@ class NeuralRayRenderer(nn.Module):
                 o.update(f)
             parts.append(outs)
         outs = [{k: torch.cat([p[b][k] for p in parts], 1) for k in parts[0][b]} for b in range(B)] if len(parts) > 1 else parts[0]
-        if not self.cfg['render_depth']:
-            for o in outs:
+        for o in outs:
+            if not self.cfg['render_depth']:
                 o.pop('render_depth', None), o.pop('render_depth_fine', None)
+            if not self.cfg['use_ray_mask']:                                # renderer.py:129-132
+                o.pop('ray_mask', None), o.pop('ray_mask_fine', None)
         return outs
 
     def _render_autograd(self, que, ref, _prep=None):
@@ -475,7 +480,9 @@ class NeuralRayRenderer(nn.Module):
         return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
 
     def _out_dict(self, o, suffix, level_net):
-        keys = ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr', 'ray_mask']
+        keys = ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr']
+        if self.cfg['use_ray_mask']:                                        # renderer.py:129-132
+            keys.append('ray_mask')
         if 'pixel_colors_gt' in o:
             keys.append('pixel_colors_gt')
         if self.cfg['render_depth']:

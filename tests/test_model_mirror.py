@@ -78,6 +78,31 @@ def test_unsupported_config_is_refused():
         NeuralRayRenderer({**CFG, 'agg_net_type': 'default'})
 
 
+def _data(device):
+    ref, que = make_scene(0, 'cfg1')
+    t = lambda a: torch.from_numpy(a).to(device)
+    ref_info = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    return {'step': 0, 'eval': True, 'full_vol': True, 'ref_imgs_info': ref_info, 'que_imgs_info': que_info, 'src_imgs_info': dict(ref_info)}
+
+
+@pytest.mark.gpu
+def test_use_ray_mask_false_drops_the_key(G):
+    """cfg use_ray_mask: false (renderer.py:129-132): the render dict simply has no ray_mask / ray_mask_fine."""
+    import copy
+    from graspnerf_amd.renderer import GraspNeRF
+    cfg = copy.deepcopy(CFG)
+    cfg['use_ray_mask'] = False
+    net = GraspNeRF(cfg)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth_state_dict(shapes).items()})
+    net = net.cuda().eval()
+    with torch.no_grad():
+        out = net(_data('cuda'))
+    assert 'ray_mask' not in out and 'ray_mask_fine' not in out and 'sdf_values_fine' in out
+
+
 def test_select_gathers_grasp_voxels(model):
     q, r, w = torch.rand(1, 1, 4, 4, 4), torch.rand(1, 4, 4, 4, 4), torch.rand(1, 1, 4, 4, 4)
     idx = torch.tensor([[1, 2, 3]])
