@@ -556,3 +556,281 @@ extern "C" int gnr_conv3d_bwd_weight(const float* x, const float* dy, float* dw,
                        Cin, Cout, D, H, W, K, nchunk);
     return hipGetLastError() == hipSuccess ? GNR_OK : GNR_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Stride-1, same-padding 3D convolution for the grasp head UNDER AUTOGRAD (decoder.conv3 and the fused heads: the two
+// k5 layers at 20^3 / 40^3 that hold 92 % of the head's MACs).  One kernel serves the forward and the backward-data pass:
+//   mode 0:  y [b,co,p] = bias[co] + sum_{ci,tap} w[co,ci,tap]  x[b,ci,p + tap - K/2]
+//   mode 1:  dx[b,ci,p] =            sum_{co,tap} w[co,ci,tap] dy[b,co,p - (tap - K/2)]   (= mode 0 with the weights
+//            transposed and the taps flipped)
+// The weights change every optimiser step, so the MFMA A fragments are packed ON THE DEVICE from the canonical
+// [Cout][Cin][K^3] tensor (k_pack_conv3d_frag) right before the convolution.
+// Implicit GEMM like k_conv3d_staged: a workgroup (4 wavefronts) owns an 8x8x4 output brick and one block of 16 output
+// channels; the input channels are swept in chunks of 16 whose halo (+ zero border) is staged in LDS, the A fragments of one
+// x-row of taps at a time.  73.7 KB (halo of a k5 chunk) + 5 KB of fragments: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------
+namespace gnr_head {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// frag [chunk][tap][c = 0..3][nb][64 lanes]: A operand of lane l = W_eff[out = 16 nb + l % 16][in = 16 chunk + 4 c + l / 16][tap]
+__global__ void k_pack_conv3d_frag(const float* __restrict__ w, float* __restrict__ frag, int Cin, int Cout, int K, int mode,
+                                   int nchunks, int nbt) {
+    const int K3 = K * K * K;
+    const long n = (long)nchunks * K3 * 4 * nbt * 64;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int lane = (int)(i & 63);
+    long q = i >> 6;
+    const int nb = (int)(q % nbt); q /= nbt;
+    const int c = (int)(q & 3); q >>= 2;
+    const int tap = (int)(q % K3), chunk = (int)(q / K3);
+    const int o = 16 * nb + (lane & 15), in = 16 * chunk + 4 * c + (lane >> 4);
+    float v = 0.f;
+    if (mode == 0) { if (o < Cout && in < Cin) v = w[((long)o * Cin + in) * K3 + tap]; }
+    else           { if (o < Cin && in < Cout) v = w[((long)in * Cin + o) * K3 + (K3 - 1 - tap)]; }
+    frag[i] = v;
+}
+
+struct Conv1Args {
+    const float* in;       // [B][cin][D][H][W]
+    const float* frag;     // [chunks][taps][4][nbt][64]
+    const float* bias;     // [cout] or null
+    float* out;            // [B][cout][D][H][W]
+    int B, cin, cout, D, H, W, nchunks, nbt;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void k_conv3d_s1(Conv1Args a) {
+    constexpr int PAD = KS / 2, TAPS = KS * KS * KS;
+    constexpr int HX = 8 + KS - 1, HY = 8 + KS - 1, HZ = 4 + KS - 1, HALO = HX * HY * HZ;
+    constexpr int AFL = 4 * 64;                           // A floats per tap (16 input channels x 16 outputs)
+    constexpr int TS = KS;                                // taps staged per step: one x-row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                                   // [16][HALO]
+    float* asl = smem + 16 * HALO;                        // [TS][64 lanes][4 c]
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int nbx = (a.W + 7) >> 3, nby = (a.H + 7) >> 3, nbz = (a.D + 3) >> 2;
+    const int blk = blockIdx.x;
+    const int b = blk / (nbx * nby * nbz), br = blk - b * nbx * nby * nbz;
+    const int bz4 = (br / (nbx * nby)) * 4, by8 = ((br / nbx) % nby) * 8, bx8 = (br % nbx) * 8;
+    const int ox = bx8 + (wave & 1) * 4 + (r & 3), oy = by8 + (wave >> 1) * 4 + (r >> 2);
+    const int nb = blockIdx.y;
+    const size_t V3 = (size_t)a.D * a.H * a.W;
+    f4 acc[4];
+    {
+        f4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const int o = 16 * nb + 4 * g;
+            b4.x = o < a.cout ? a.bias[o] : 0.f; b4.y = o + 1 < a.cout ? a.bias[o + 1] : 0.f;
+            b4.z = o + 2 < a.cout ? a.bias[o + 2] : 0.f; b4.w = o + 3 < a.cout ? a.bias[o + 3] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = b4;
+    }
+    // per-lane halo offsets: output (ox, oy, bz4 + t) reads halo cell (ox - bx8 + tx, oy - by8 + ty, t + tz)
+    const int lx = ox - bx8, ly = (oy - by8) * HX;
+    const float* hg = halo + g * HALO;                    // lane group g = input channel 4c + g of the chunk
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        __syncthreads();                                  // everybody is done with the previous chunk's halo
+        const float* in = a.in + ((size_t)b * a.cin + 16 * ch) * V3;
+        for (int i = threadIdx.x; i < 16 * HALO; i += 256) {
+            const int c = i / HALO, rem = i - c * HALO;
+            const int z = bz4 - PAD + rem / (HX * HY), y = by8 - PAD + (rem / HX) % HY, x = bx8 - PAD + rem % HX;
+            const bool ok = 16 * ch + c < a.cin && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            halo[i] = ok ? in[(size_t)c * V3 + ((size_t)z * a.H + y) * a.W + x] : 0.f;
+        }
+        const float* fr = a.frag + ((size_t)ch * TAPS * 4 * a.nbt + nb) * 64;      // + ((tap * 4 + c) * nbt) * 64 + lane
+        for (int row = 0; row < KS * KS; ++row) {         // (tz, ty) row of KS x-taps
+            __syncthreads();                              // previous slice consumed / halo written
+            for (int i = threadIdx.x; i < TS * AFL; i += 256) {
+                const int ln = i & 63, c = (i >> 6) & 3, tp = i >> 8;
+                asl[(tp * 64 + ln) * 4 + c] = fr[((size_t)((row * KS + tp) * 4 + c) * a.nbt) * 64 + ln];
+            }
+            __syncthreads();
+            const int tz = row / KS, ty = row - tz * KS;
+            const int base = (tz * HY + ty) * HX + ly + lx;
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) {
+                const f4 av = *reinterpret_cast<const f4*>(asl + (tx * 64 + lane) * 4);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float bv = hg[4 * cc * HALO + base + t * HX * HY + tx];
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc], bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (ox < a.W && oy < a.H && b < a.B) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oz = bz4 + t;
+            if (oz >= a.D) continue;
+            const size_t v = ((size_t)oz * a.H + oy) * a.W + ox;
+            const float e[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = 16 * nb + 4 * g + q;
+                if (o < a.cout) a.out[((size_t)b * a.cout + o) * V3 + v] = e[q];
+            }
+        }
+    }
+}
+
+}  // namespace gnr_head
+
+extern "C" size_t gnr_conv3d_same_workspace_bytes(int Cin, int Cout, int K) {
+    if (Cin < 1 || Cout < 1 || K < 1) return 0;
+    const int m = Cin > Cout ? Cin : Cout;
+    const size_t nch = (m + 15) / 16, nbt = (m + 15) / 16;
+    return nch * K * K * K * 4 * nbt * 64 * sizeof(float);
+}
+
+// mode 0: x [B][Cin][D][H][W] -> y [B][Cout][D][H][W] (+ bias [Cout] or NULL);  mode 1: x = dy [B][Cout][..] -> y = dx [B][Cin][..]
+// (bias ignored).  w = the layer's canonical weights [Cout][Cin][K][K][K] on the device.  K = 3 or 5.
+extern "C" int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H,
+                               int W, int K, int mode, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || !ws) { snprintf(h_err, sizeof(h_err), "gnr_conv3d_same: null pointer"); return GNR_ERR_ARG; }
+    if (B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5) || (mode != 0 && mode != 1)) {
+        snprintf(h_err, sizeof(h_err), "gnr_conv3d_same: bad shape / mode (K must be 3 or 5)"); return GNR_ERR_SHAPE; }
+    if (ws_bytes < gnr_conv3d_same_workspace_bytes(Cin, Cout, K)) { snprintf(h_err, sizeof(h_err), "gnr_conv3d_same: workspace too small"); return GNR_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int cin = mode ? Cout : Cin, cout = mode ? Cin : Cout;
+    const int nchunks = (cin + 15) / 16, nbt = (cout + 15) / 16, K3 = K * K * K;
+    float* frag = (float*)ws;
+    {
+        const long n = (long)nchunks * K3 * 4 * nbt * 64;
+        HeadScope hs("k_pack_conv3d_frag@gnr_conv3d_same", stream);
+        hipLaunchKernelGGL(gnr_head::k_pack_conv3d_frag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, frag, Cin, Cout, K, mode, nchunks, nbt);
+        HCHK(hipGetLastError());
+    }
+    gnr_head::Conv1Args a{x, frag, mode ? nullptr : bias, y, B, cin, cout, D, H, W, nchunks, nbt};
+    const long blocks = (long)B * ((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4);
+    HeadScope hs(mode ? "k_conv3d_s1.bwd_data@gnr_conv3d_same" : "k_conv3d_s1.fwd@gnr_conv3d_same", stream);
+    if (K == 5) {
+        const size_t lds = (16 * (12 * 12 * 8) + 5 * 256) * sizeof(float);
+        static bool attr = false;
+        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL(gnr_head::k_conv3d_s1<5>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
+    } else {
+        const size_t lds = (16 * (10 * 10 * 6) + 3 * 256) * sizeof(float);
+        static bool attr = false;
+        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL(gnr_head::k_conv3d_s1<3>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
+    }
+    HCHK(hipGetLastError());
+    return GNR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the same stride-1 convolutions, LDS-staged (replaces the one-wavefront-per-(tap, block, voxel chunk)
+// kernel above for K = 3 / 5: that one re-derives voxel coordinates per element and fetches both operands from global
+// memory per k-step, 9 TFLOP/s):
+//   dW[o][i][tap] = sum_{b, voxel} dy[b][o][voxel] * x[b][i][voxel + tap - K/2]
+// A workgroup owns one (16 input channels, 16 output channels) pair and sweeps 8x8x4 voxel bricks: the brick's x halo
+// (channel-minor, + zero border) and its dy tile go to LDS once, then the four wavefronts split the K^3 taps and run
+// 64 k-steps (4 voxels each) per tap with the voxel axis as the MFMA K: A = dy [o][voxel], B = x [voxel + tap][i], both
+// read conflict-free (64 consecutive floats per wavefront instruction).  The 16x16 accumulators of a wavefront's <= 32 taps
+// stay in registers across all bricks of the workgroup and are flushed once with atomics.
+// ---------------------------------------------------------------------------------------------------------
+namespace gnr_head {
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_s1(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                            int B, int Cin, int Cout, int D, int H, int W, int nbi) {
+    constexpr int PAD = KS / 2, TAPS = KS * KS * KS, TPW = (TAPS + 3) / 4;      // taps per wavefront
+    constexpr int HX = 8 + KS - 1, HY = 8 + KS - 1, HZ = 4 + KS - 1, HALO = HX * HY * HZ;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                                   // [HALO cells][16 input channels]
+    float* dyt = smem + HALO * 16;                        // [256 voxels][16 output channels]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.y, bi = pair % nbi, bo = pair / nbi;
+    const int nbx = (W + 7) >> 3, nby = (H + 7) >> 3, nbz = (D + 3) >> 2;
+    const int nbricks = B * nbx * nby * nbz;
+    const size_t V3 = (size_t)D * H * W;
+    f4 acc[TPW];
+    int off[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+        const int tap = wave + 4 * j, t = tap < TAPS ? tap : 0;
+        off[j] = ((t / (KS * KS)) * HY + (t / KS) % KS) * HX + t % KS;
+    }
+    for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+        const int b = brick / (nbx * nby * nbz), br = brick - b * nbx * nby * nbz;
+        const int bz4 = (br / (nbx * nby)) * 4, by8 = ((br / nbx) % nby) * 8, bx8 = (br % nbx) * 8;
+        __syncthreads();                                  // the previous brick's MFMAs are done with the tiles
+        {
+            const float* xin = x + ((size_t)b * Cin + 16 * bi) * V3;
+            for (int i = threadIdx.x; i < 16 * HALO; i += 256) {
+                const int c = i / HALO, cell = i - c * HALO;
+                const int z = bz4 - PAD + cell / (HX * HY), y = by8 - PAD + (cell / HX) % HY, xx = bx8 - PAD + cell % HX;
+                const bool ok = 16 * bi + c < Cin && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+                halo[cell * 16 + c] = ok ? xin[(size_t)c * V3 + ((size_t)z * H + y) * W + xx] : 0.f;
+            }
+            const float* din = dy + ((size_t)b * Cout + 16 * bo) * V3;
+            for (int i = threadIdx.x; i < 16 * 256; i += 256) {
+                const int o = i >> 8, v = i & 255;
+                const int z = bz4 + (v >> 6), y = by8 + ((v >> 3) & 7), xx = bx8 + (v & 7);
+                const bool ok = 16 * bo + o < Cout && z < D && y < H && xx < W;
+                dyt[v * 16 + o] = ok ? din[(size_t)o * V3 + ((size_t)z * H + y) * W + xx] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {                    // k-step s = voxels 4s .. 4s+3 (consecutive x)
+            const float av = dyt[64 * s + lane];          // A: row o = lane % 16, k = lane / 16  <->  dyt[(4s + k) * 16 + o]
+            const int cellbase = ((s >> 4) * HY + ((s >> 1) & 7)) * HX + 4 * (s & 1);
+            const float* hb = halo + cellbase * 16 + lane;        // B: col i = lane % 16, k = lane / 16  <->  halo[(cell + k) * 16 + i]
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hb[off[j] * 16], acc[j], 0, 0, 0);
+        }
+    }
+    const int i = 16 * bi + (lane & 15), kg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tap = wave + 4 * j;
+        if (tap >= TAPS || i >= Cin) continue;
+        const float e[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = 16 * bo + 4 * kg + q;
+            if (o < Cout) unsafeAtomicAdd(dw + ((size_t)o * Cin + i) * TAPS + tap, e[q]);
+        }
+    }
+}
+
+}  // namespace gnr_head
+
+// dw [Cout][Cin][K][K][K] is ACCUMULATED (zero it first); K = 3 or 5.  Same contract as gnr_conv3d_bwd_weight.
+extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
+                                          void* stream) {
+    if (!x || !dy || !dw || B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5)) return GNR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbi = (Cin + 15) / 16, nbo = (Cout + 15) / 16;
+    const long nbricks = (long)B * ((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4);
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    long gx = (cus + nbi * nbo - 1) / (nbi * nbo);
+    if (gx > nbricks) gx = nbricks;
+    if (gx < 1) gx = 1;
+    HeadScope hs("k_conv3d_wgrad_s1@gnr_conv3d_same_bwd_weight", stream);
+    if (K == 5) {
+        const size_t lds = (16 * (12 * 12 * 8) + 16 * 256) * sizeof(float);
+        static bool attr = false;
+        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, dw, B, Cin, Cout, D, H, W, nbi);
+    } else {
+        const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
+        static bool attr = false;
+        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<3>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, dw, B, Cin, Cout, D, H, W, nbi);
+    }
+    HCHK(hipGetLastError());
+    return GNR_OK;
+}

@@ -155,6 +155,20 @@ const char* gnr_head_last_error(void);
 int gnr_conv3d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
                           void* stream);
 
+/* Stride-1, same-padding (K/2) 3D convolution on fp32 MFMA for the grasp head under autograd (gd/networks.py:30-37,91-96: the
+ * two k5 layers at 20^3 / 40^3), K = 3 or 5.  w = the layer's canonical weights [Cout][Cin][K][K][K] on the device; the MFMA
+ * fragments are packed on the device into `workspace` (gnr_conv3d_same_workspace_bytes) at every call, the weights move
+ * every optimiser step.
+ *   mode 0 (forward):        x [B][Cin][D][H][W]       -> y  [B][Cout][D][H][W]  (+ bias [Cout], or NULL)
+ *   mode 1 (backward data):  x = dy [B][Cout][D][H][W] -> y = dx [B][Cin][D][H][W]  (transposed, flipped weights; bias ignored) */
+/*   gnr_conv3d_same_bwd_weight: dw [Cout][Cin][K][K][K] is ACCUMULATED from x [B][Cin][D][H][W] and dy [B][Cout][D][H][W]
+ *   (LDS-staged successor of gnr_conv3d_bwd_weight for K = 3 / 5). */
+size_t gnr_conv3d_same_workspace_bytes(int Cin, int Cout, int K);
+int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
+                               void* stream);
+int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int K,
+                    int mode, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- backward twins ------------------------------------------------------------------------
  * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
  * consumed by DepthLoss, loss.py:87-144).  sample_volume and the per-view chain of the render passes follow below;

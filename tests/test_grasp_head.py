@@ -50,17 +50,65 @@ def test_head_matches_pytorch(R, B):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,Cin,Cout,D,H,W,K', [(2, 16, 6, 9, 7, 10, 5), (1, 32, 16, 6, 6, 6, 5), (3, 20, 33, 5, 4, 7, 3), (1, 16, 6, 40, 40, 40, 5)])
-def test_conv3d_weight_gradient_kernel(B, Cin, Cout, D, H, W, K):
-    """gnr_conv3d_bwd_weight against PyTorch's own conv3d backward (ragged channel counts, non-cubic volumes)."""
+def test_conv3d_same_all_three_directions(B, Cin, Cout, D, H, W, K):
+    """conv3d_same under autograd = gnr_conv3d_same (forward, backward data) + gnr_conv3d_same_bwd_weight against PyTorch's own
+    conv3d forward / backward (ragged channel counts incl. several 16-channel chunks, non-cubic volumes that are not
+    multiples of the 8x8x4 brick)."""
     from graspnerf_amd.backbone import conv3d_same
     g = torch.Generator().manual_seed(B * 100 + Cin)
     x = torch.randn(B, Cin, D, H, W, generator=g).cuda().requires_grad_(True)
     w = (0.1 * torch.randn(Cout, Cin, K, K, K, generator=g)).cuda().requires_grad_(True)
     b = torch.randn(Cout, generator=g).cuda().requires_grad_(True)
     dy = torch.randn(B, Cout, D, H, W, generator=g).cuda()
-    (conv3d_same(x, w, b) * dy).sum().backward()
-    got = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    y = conv3d_same(x, w, b)
+    (y * dy).sum().backward()
+    got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
     x.grad = w.grad = b.grad = None
-    (torch.nn.functional.conv3d(x, w, b, padding=K // 2) * dy).sum().backward()
-    for a, r, name in zip(got, (x.grad, w.grad, b.grad), ('dx', 'dw', 'db')):
-        assert (a - r).abs().max() <= 2e-4 * r.abs().max() + 1e-5, name
+    y0 = torch.nn.functional.conv3d(x, w, b, padding=K // 2)
+    (y0 * dy).sum().backward()
+    for a, r, name in zip(got, (y0.detach(), x.grad, w.grad, b.grad), ('y', 'dx', 'dw', 'db')):
+        assert a.shape == r.shape and (a - r).abs().max() <= 2e-4 * r.abs().max() + 1e-5, name
+
+
+@pytest.mark.gpu
+def test_convnet_under_autograd_matches_pytorch():
+    """gd.networks.ConvNet mirror in training mode (HIP convolutions for decoder.conv3 and the fused heads) against the same
+    module with every convolution in PyTorch: outputs and all 18 parameter gradients."""
+    from graspnerf_amd import backbone
+    torch.manual_seed(0)
+    net = backbone.ConvNet().cuda()
+    vol = torch.randn(2, 1, 40, 40, 40, device='cuda').clamp(-1, 1)
+    ups = [torch.randn(2, c, 40, 40, 40, device='cuda') for c in (1, 4, 1)]
+    res = {}
+    for hip in (True, False):
+        net.zero_grad(set_to_none=True)
+        orig = backbone.conv3d_same
+        if not hip:
+            backbone.conv3d_same = lambda x, w, b: torch.nn.functional.conv3d(x, w, b, padding=w.shape[-1] // 2)
+        try:
+            out = net(vol)
+            sum((o * u).sum() for o, u in zip(out, ups)).backward()
+        finally:
+            backbone.conv3d_same = orig
+        torch.cuda.synchronize()
+        res[hip] = ([o.detach().clone() for o in out], {k: p.grad.clone() for k, p in net.named_parameters()})
+    for a, r in zip(res[True][0], res[False][0]):
+        assert (a - r).abs().max() <= 1e-4 * r.abs().max() + 1e-6
+    for k, r in res[False][1].items():
+        assert (res[True][1][k] - r).abs().max() <= 5e-4 * r.abs().max() + 1e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Cin,Cout,D,H,W,K', [(2, 16, 6, 9, 7, 10, 5), (1, 40, 20, 6, 5, 9, 3)])
+def test_first_generation_weight_gradient_kernel(B, Cin, Cout, D, H, W, K):
+    """gnr_conv3d_bwd_weight (any odd K; kept in the ABI) against PyTorch."""
+    import ctypes as C
+    from graspnerf_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, D, H, W, generator=g).cuda()
+    dy = torch.randn(B, Cout, D, H, W, generator=g).cuda()
+    dw = torch.zeros(Cout, Cin, K, K, K, device='cuda')
+    assert _lib.lib().gnr_conv3d_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, Cout, D, H, W, K, None) == 0
+    want = torch.nn.grad.conv3d_weight(x, dw.shape, dy, padding=K // 2)
+    torch.cuda.synchronize()
+    assert (dw - want).abs().max() <= 2e-4 * want.abs().max() + 1e-5
