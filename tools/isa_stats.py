@@ -3,11 +3,11 @@ Usage: python tools/isa_stats.py        (compiles into /tmp/isa)"""
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs('/tmp/isa', exist_ok=True)
-subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', '-save-temps', '-Wno-unused-value',
+subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', '-save-temps', '-Wno-unused-value', '-fno-slp-vectorize',
                 os.path.join(ROOT, 'graspnerf_amd/csrc/gnr_kernels.hip'), '-o', '/dev/null'], cwd='/tmp/isa',
                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
 txt = open('/tmp/isa/gnr_kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read()
-for kern in ('k_chainILi6ELb0', 'k_chainILi6ELb1'):
+for kern in ('k_chainILi6ELb0ELb0', 'k_chainILi6ELb1ELb0'):
     m = re.search(r'\n(_ZN3gnr7%sEEEvNS_9ChainArgsE):.*?\n\s*s_endpgm' % kern, txt, re.S)
     body = m.group(0).split('\n')
     # inner loops = regions between a label and the backward branch to it
