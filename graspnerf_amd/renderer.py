@@ -297,8 +297,11 @@ class NeuralRayRenderer(nn.Module):
     def _hot_versions(self):
         """Autograd version counters of the hot-path parameters: every in-place update (optimizer.step, copy_, load_state_dict)
         bumps them, so a change means the packed copies in the HotPath are stale."""
-        P = self._params()
-        return tuple(P[k]._version for lvl in ('coarse', 'fine') for k, _ in _w.level_keys(lvl))
+        ps = getattr(self, '_hot_params', None)
+        if ps is None or self._hot is None:                  # (re)collected whenever the HotPath is rebuilt (_apply / load_state_dict)
+            P = self._params()
+            ps = self._hot_params = [P[k] for lvl in ('coarse', 'fine') for k, _ in _w.level_keys(lvl)]
+        return tuple(p._version for p in ps)
 
     def hot(self):
         """The HIP path with weights packed from the CURRENT parameter values: re-packed whenever a parameter was updated in

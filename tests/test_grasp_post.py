@@ -87,3 +87,22 @@ def test_hip_post_processing_ragged_and_truncated():
         assert np.array_equal(out['index'][b].cpu().numpy(), idx[:8])
         assert np.array_equal(out['score'][b].cpu().numpy(), score[:8])
         assert np.array_equal(out['quat'][b].cpu().numpy(), quat[:8])
+
+
+@pytest.mark.gpu
+def test_truncated_selection_is_reported():
+    """The reference's select() returns every NMS survivor (main.py:70-84): a selection that does not fit the buffers raises
+    instead of silently returning the first max_grasps candidates in index order."""
+    import torch
+    from graspnerf_amd import _lib
+    from graspnerf_amd.grasp_post import GraspSelector, grasps_from_selection
+    from graspnerf_amd.synth import synth_head_outputs
+    tsdf, qual, rot, width = synth_head_outputs(0)
+    sel = GraspSelector(max_grasps=2048)(tsdf, qual, rot, width, tsdf_thres_high=0.0, tsdf_thres_low=-0.85)
+    n = int(sel['count'][0])
+    assert n > 3
+    assert len(grasps_from_selection(sel, 0)['index']) == n
+    small = GraspSelector(max_grasps=3)(tsdf, qual, rot, width, tsdf_thres_high=0.0, tsdf_thres_low=-0.85)
+    assert int(small['count'][0]) == n
+    with pytest.raises(_lib.GnrError):
+        grasps_from_selection(small, 0)
