@@ -374,3 +374,87 @@ def test_eval_after_optimizer_step_uses_the_updated_weights():
         assert (after[k] - want[k]).abs().max().item() < 5e-5, k
     for a, b, c in zip(after['vgn_pred'], want['vgn_pred'], before['vgn_pred']):
         assert (a - b).abs().max().item() < 5e-5 < (a - c).abs().max().item(), 'grasp head ran on stale weights'
+
+
+def _full_size_cfg():
+    import copy
+    cfg = copy.deepcopy(CFG)
+    cfg.update(volume_resolution=40, depth_sample_num=40, fine_depth_sample_num=40, ray_batch_num=4096)
+    cfg['agg_net_cfg']['sample_num'] = cfg['fine_agg_net_cfg']['sample_num'] = 40
+    return cfg
+
+
+def _full_size_scene(i, device='cuda'):
+    ref, que = make_scene(i, 'cfg2')
+    _, gt = synth_loss_case(seed=100 + i, rfn=6, h=288, w=512, rn=512, R=40)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    ri = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
+    ri.update(true_depth=t(gt['true_depth']), sdf_gt=t(gt['sdf_gt']))
+    qi = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+          'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    return {'step': 0, 'ref_imgs_info': ri, 'que_imgs_info': qi, 'src_imgs_info': dict(ri), 'grasp_info': tuple(t(x) for x in gt['grasp_info'])}
+
+
+@pytest.mark.gpu
+def test_full_size_train_step_matches_the_reference_statement():
+    """BASELINE.json configs[4] at its real size (6 views 288x512, 40^3 volume, 512 rays x (40+40) samples): one scene through
+    the product's HIP twin pairs against the differentiable PyTorch statement (pure autograd incl. the double backward) -- every
+    loss term and the gradient of every parameter of the volumetric path and the grasp head; then two scenes batched
+    (forward_scenes, what the trainer and bench.py's train_step run) against the per-scene loop."""
+    from graspnerf_amd.renderer import GraspNeRF
+    from graspnerf_amd.trainer import train_losses
+    from graspnerf_amd import losses
+    from reference_autograd import use_reference_statement
+    cfg = _full_size_cfg()
+    net = GraspNeRF(cfg)
+    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()}, strict=True)
+    net = net.cuda().train()
+    data = _full_size_scene(0)
+    res = {}
+    for hip in (False, True):
+        use_reference_statement(net, on=not hip)
+        for a in (net.nr_net.agg_net, net.nr_net.fine_agg_net):
+            a.step = 0
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        terms = train_losses(net(data), data)
+        losses.total_loss(terms).backward()
+        torch.cuda.synchronize()
+        res[hip] = ({k: float(v.detach().mean()) for k, v in terms.items() if k.startswith('loss')},
+                    {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        del terms
+        torch.cuda.empty_cache()
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= 2e-3 * abs(v) + 1e-7, (k, res[True][0][k], v)
+    worst = (0.0, '')
+    for k, g in res[False][1].items():
+        if any(s in k for s in ('dist_decoder', 'agg_net', 'vgn_net')):
+            if k.endswith('rgb_fc.4.bias'):               # bias in front of the softmax over views: the gradient is exactly zero,
+                assert float(g.abs().max()) < 1e-4 and float(res[True][1][k].abs().max()) < 1e-4     # both sides hold rounding noise
+                continue
+            e = (res[True][1][k] - g).norm().item() / (g.norm().item() + 1e-9)
+            worst = max(worst, (e, k))
+    assert worst[0] < 5e-3, f'gradient mismatch at full size {worst}'
+    # two scenes in one batched forward / backward against the per-scene loop
+    datas = [data, _full_size_scene(1)]
+    got = {}
+    for batched in (False, True):
+        for a in (net.nr_net.agg_net, net.nr_net.fine_agg_net):
+            a.step = 0
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(9)
+        if batched:
+            outs = net.forward_scenes(datas)
+            assert outs is not None
+            sum(losses.total_loss(train_losses(o, d)) for o, d in zip(outs, datas)).backward()
+        else:
+            for d in datas:
+                losses.total_loss(train_losses(net(d), d)).backward()
+        torch.cuda.synchronize()
+        got[batched] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if any(s in k for s in ('dist_decoder', 'agg_net', 'vgn_net'))}
+    for k, g in got[False].items():
+        if k.endswith('rgb_fc.4.bias'):
+            continue
+        e = (got[True][k] - g).norm().item() / (g.norm().item() + 1e-9)
+        assert e < 3e-3, (k, e)
