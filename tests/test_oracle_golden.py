@@ -119,3 +119,43 @@ def test_grid_index_map():
     np.testing.assert_allclose(g[x * 1600 + y * 40 + z], (np.array([x, y, z]) + 0.5) * 0.0075, rtol=1e-6)
     q = O.volume_query_points(40, [0, 0, 0])
     assert np.array_equal(q[17, 0].numpy(), g[17 * 40 + 39])        # sample 0 = top voxel
+
+
+def test_resampling_checker_catches_a_wrong_index(golden):
+    """The F1 check is not vacuous: one wrong index at a sample far from every cdf edge is reported, a flip explained by a
+    moved cdf edge is not."""
+    G = golden('cfg2')
+    inds, cdf, margin = G['fine_inds'].copy(), G['fine_cdf'], G['fine_inds_margin']
+    assert check_resampling_inds(inds, cdf, G['fine_inds'], cdf, margin, 'identity') == 0
+    r, c = np.unravel_index(np.argmax(margin), margin.shape)
+    bad = inds.copy()
+    bad[r, c] += 1
+    with pytest.raises(AssertionError):
+        check_resampling_inds(bad, cdf, G['fine_inds'], cdf, margin, 'wrong index')
+    # a cdf edge that really moved across the sample explains a flip there (and only there)
+    r2, c2 = np.unravel_index(np.argmin(margin), margin.shape)
+    moved = cdf.astype(np.float64).copy()
+    moved[r2] += 2 * float(margin[r2, c2]) + 1e-6
+    ok = inds.copy()
+    ok[r2, c2] -= 1
+    assert check_resampling_inds(ok, moved, G['fine_inds'], cdf, margin, 'explained flip') == 1
+
+
+def test_f1_properties_random_inputs():
+    """Oracle resampler on random pdfs (incl. empty bins and saturated rays): indices in range and consistent with the cdf,
+    depths inside the ray's range and non-decreasing in u."""
+    g = torch.Generator().manual_seed(0)
+    for dn, fdn in ((40, 40), (16, 24), (3, 7), (64, 64)):
+        depth = O.sample_depth(torch.tensor([0.2, 0.8]), 33, dn)
+        hit = torch.rand(33, dn, generator=g) ** 8
+        hit[::3, dn // 2:] = 0.0                                        # empty bins -> the 1e-5 guard
+        hit[1] = 0.0
+        det = {}
+        fd, inds = O.sample_fine_depth(depth, hit, torch.tensor([0.2, 0.8]), fdn, details=det)
+        cdf, u = det['cdf'], det['u']
+        assert inds.min() >= 1 and inds.max() <= dn
+        lo = torch.gather(cdf, 1, (inds - 1).clamp(min=0))
+        hi = torch.gather(cdf, 1, inds.clamp(max=dn))
+        assert bool(((lo <= u) & ((u < hi) | (inds == dn))).all())
+        assert float(fd.min()) >= 0.2 - 1e-5 and float(fd.max()) <= 0.8 + 1e-5
+        assert bool((fd[:, 1:] >= fd[:, :-1] - 1e-6).all())            # eval-mode u is increasing -> depths are
