@@ -265,39 +265,11 @@ def composite(P, agg, sdf, grad, col, nvalid, qdir, depth, que, ref_hw, cfg):
     return out
 
 
-def _scene_outputs_UNUSED(P, agg, sdf, col, o, B, rn):
-    """Per-scene output dicts (renderer.py:110-138 keys) from the batched results of a HIP composite callable."""
-    outs = []
-    var = P[agg + 'deviation_network.variance'].reshape(1, 1)
-    for b in range(B):
-        sl = slice(b * rn, (b + 1) * rn)
-        out = {'sdf_values': sdf[sl][None], 'alpha_values': o['alpha'][sl][None], 'colors_nr': col[sl][None],
-               'hit_prob_nr': o['hit'][sl][None], 'pixel_colors_nr': o['pix'][sl][None], 'sdf_gradient_error': o['gerr'][b:b + 1],
-               's': var, 'render_depth': o['rdepth'][sl][None], 'ray_mask': o['rmask'][sl][None]}
-        if o.get('gt') is not None:
-            out['pixel_colors_gt'] = o['gt'][sl][None]
-        outs.append(out)
-    return outs
-
-
-def render_by_depth(P, ref, que, depth, dec, agg, cfg, chain=None):
-    """renderer.py:90-138 for one scene; depth [rn,dn].  que: coords [rn,2], pose [3,4], K [3,3], depth_range [2].
-    `chain(depth) -> (stats [rn*dn,66], colours [rn*dn,3][, tail])` replaces the per-view part (everything up to the cross-view
-    statistics and the colour blend) with the HIP twin pair; the per-ray tail stays here."""
+def render_by_depth(P, ref, que, depth, dec, agg, cfg):
+    """renderer.py:90-138 for one scene; depth [rn,dn].  que: coords [rn,2], pose [3,4], K [3,3], depth_range [2]."""
     rn, dn = depth.shape
     h, w = ref['imgs'].shape[-2:]
     pts, qdir = ray_points(que, depth)
-    if chain is not None:
-        stats, col, *ex = chain(depth)
-        tail, comp = (ex + [None, None])[:2]
-        if tail is not None:                                               # HIP tail in both directions (renderer._RayTailFn)
-            sdf, grad = tail(agg, stats, pts, rn, dn)
-        else:
-            sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], stats[:, 65].detach(), pts, rn, dn, True)
-        if comp is not None:                                               # ... and NeuS alpha / compositing (renderer._CompositeFn)
-            col = col.reshape(rn, dn, 3)
-            return _scene_outputs(P, agg, sdf, col, comp(agg, sdf, grad, col, qdir, depth), 1, rn)[0]
-        return composite(P, agg, sdf, grad, col.reshape(rn, dn, 3), stats[:, 65].detach().reshape(rn, dn), qdir, depth, que, (h, w), cfg)
     uv, z, mask, dirv = project(pts, ref['poses'], ref['Ks'], h, w)
     f_ray, rgb, f_img = _gather(ref, uv, mask)
     near, far = -1 / que['depth_range'][0], -1 / que['depth_range'][1]
@@ -331,9 +303,8 @@ def sample_fine_depth(depth, hit_prob, depth_range, fdn, u):
     return -1 / (fd * (far - near) + near)
 
 
-def render(P, ref, que, cfg, fine_u=None, chains=None):
-    """renderer.py:140-162 for one chunk of rays of one scene -> dict with '' and '_fine' keys.
-    chains = (coarse, fine) callables for the HIP per-view chain (see render_by_depth)."""
+def render(P, ref, que, cfg, fine_u=None):
+    """renderer.py:140-162 for one chunk of rays of one scene -> dict with '' and '_fine' keys."""
     dev = ref['imgs'].device
     rn, dn, fdn = que['coords'].shape[0], cfg['depth_sample_num'], cfg['fine_depth_sample_num']
     near, far = que['depth_range'][0], que['depth_range'][1]
@@ -341,12 +312,11 @@ def render(P, ref, que, cfg, fine_u=None, chains=None):
     ticks = torch.cat([torch.zeros(1, device=dev), diff / (dn - 1) * torch.arange(1, dn - 1, dtype=torch.float32, device=dev),
                        diff.reshape(1)])
     depth = (1 / (1 / near + ticks))[None].expand(rn, dn).contiguous()    # render_ops.py:146-170
-    out = render_by_depth(P, ref, que, depth, 'dist_decoder.', 'agg_net.', cfg, chains[0] if chains else None)
+    out = render_by_depth(P, ref, que, depth, 'dist_decoder.', 'agg_net.', cfg)
     if fine_u is None:
         fine_u = ((0.5 + torch.arange(fdn, dtype=torch.float32, device=dev)) / fdn)[None].expand(rn, fdn)
     fd = sample_fine_depth(depth, out['hit_prob_nr'][0].detach(), que['depth_range'], fdn, fine_u.to(dev))
-    fine = render_by_depth(P, ref, que, torch.sort(fd, -1)[0], 'fine_dist_decoder.', 'fine_agg_net.', cfg,
-                           chains[1] if chains else None)
+    fine = render_by_depth(P, ref, que, torch.sort(fd, -1)[0], 'fine_dist_decoder.', 'fine_agg_net.', cfg)
     out.update({k + '_fine': v for k, v in fine.items()})
     return out
 
@@ -360,54 +330,6 @@ def depth_mean(P, ref, coords_rc, dec):
     f = bilinear_border(ref['ray_feats'], uv, h, w)
     return _mlp3(f, P, dec + 'mean_decoder', F.softplus)
 
-
-def render_scenes(P, que, hw, cfg, fine_u, chains):
-    """render() for B scenes at once around the batched HIP chains (training, GPU): the per-ray tail treats the rays of
-    all scenes as one long list.  que: coords [B,rn,2], pose [B,3,4], K [B,3,3], depth_range [B,2], optional imgs
-    [B,3,H,W]; fine_u [B,rn,fdn]; chains = (coarse, fine) with chain(depth [B,rn,dn]) -> (stats [B,P,66], colours [B,P,3]).
-    -> list of B per-scene output dicts (same keys and shapes as render())."""
-    dev = que['coords'].device
-    B, rn = que['coords'].shape[:2]
-    dn, fdn = cfg['depth_sample_num'], cfg['fine_depth_sample_num']
-    near, far = que['depth_range'][:, 0:1], que['depth_range'][:, 1:2]                  # [B,1]
-    diff = 1 / far - 1 / near
-    ar = torch.arange(1, dn - 1, dtype=torch.float32, device=dev)[None]
-    ticks = torch.cat([torch.zeros(B, 1, device=dev), diff / (dn - 1) * ar, diff], 1)   # [B,dn]
-    depth = (1 / (1 / near + ticks))[:, None].expand(B, rn, dn).contiguous()
-
-    def one_pass(depth, agg, chain):
-        d = depth.shape[-1]
-        geo = [ray_points({'coords': que['coords'][b], 'pose': que['pose'][b], 'K': que['K'][b]}, depth[b]) for b in range(B)]
-        pts = torch.cat([g[0] for g in geo])
-        qdir = torch.cat([g[1] for g in geo])
-        stats, col, *ex = chain(depth)
-        tail, comp = (ex + [None, None])[:2]
-        stats, col = stats.reshape(-1, 66), col.reshape(-1, 3)
-        nval = stats[:, 65].detach()
-        if tail is not None:
-            sdf, grad = tail(agg, stats, pts, B * rn, d)
-        else:
-            sdf, grad = sdf_tail(P, agg, stats[:, :32], stats[:, 32:64], stats[:, 64:65], nval, pts, B * rn, d, True)
-        if comp is not None:
-            col = col.reshape(B * rn, d, 3)
-            return _scene_outputs(P, agg, sdf, col, comp(agg, sdf, grad, col, qdir, depth.reshape(B * rn, d)), B, rn)
-        outs = []
-        for b in range(B):                                                 # per-scene means / query images
-            sl = slice(b * rn, (b + 1) * rn)
-            q = {'coords': que['coords'][b]}
-            if 'imgs' in que:
-                q['imgs'] = que['imgs'][b:b + 1]
-            outs.append(composite(P, agg, sdf[sl], grad[sl], col.reshape(B * rn, d, 3)[sl], nval.reshape(B * rn, d)[sl], qdir[sl],
-                                  depth[b], q, hw, cfg))
-        return outs
-    coarse = one_pass(depth, 'agg_net.', chains[0])
-    hit = torch.cat([o['hit_prob_nr'][0].detach() for o in coarse])
-    dr = que['depth_range'][:, None].expand(B, rn, 2).reshape(-1, 2)
-    fd = sample_fine_depth(depth.reshape(-1, dn), hit, (dr[:, 0:1], dr[:, 1:2]), fdn, fine_u.reshape(-1, fdn).to(dev))
-    fine = one_pass(torch.sort(fd, -1)[0].reshape(B, rn, fdn), 'fine_agg_net.', chains[1])
-    for o, f in zip(coarse, fine):
-        o.update({k + '_fine': v for k, v in f.items()})
-    return coarse
 
 
 # ----------------------------------------------------------------------------------------------------------------------
