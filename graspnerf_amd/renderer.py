@@ -319,21 +319,42 @@ class NeuralRayRenderer(nn.Module):
             self._hot_ver = ver
         return self._hot
 
+    def repack_begin(self):
+        """First half of the per-step weight re-pack, to be called BEFORE the 2D backbones are queued: the canonical blobs of
+        both levels are gathered on the device and start their way to pinned host memory (stream-ordered, nothing waits).
+        hot_for_training() then finishes the job -- host-side packing + pinned, non-blocking uploads -- while the GPU works
+        on the backbones, instead of holding the GPU idle for it at the start of every step."""
+        sd = self._params()
+        can_dev = {lvl: _w.canonical_blob_device(sd, lvl, as_tensor=True) for lvl in ('coarse', 'fine')}
+        host = {lvl: torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for lvl, t in can_dev.items()}
+        ev = torch.cuda.Event()
+        ev.record()
+        self._repack_pending = (can_dev, host, ev, self._hot_versions())
+
     def hot_for_training(self):
         """The HIP path with weights re-packed from the CURRENT parameter values (they move every optimiser step), plus
         the transposed fragments of the backward twins."""
-        sd = self._params()
+        if getattr(self, '_repack_pending', None) is None or self._repack_pending[3] != self._hot_versions():
+            self.repack_begin()
+        can_dev, host, ev, ver = self._repack_pending
+        self._repack_pending = None
         dev = next(self.parameters()).device
-        can_dev = {lvl: _w.canonical_blob_device(sd, lvl, as_tensor=True) for lvl in ('coarse', 'fine')}
-        can = {lvl: t.cpu().numpy() for lvl, t in can_dev.items()}
+        ev.synchronize()                                                    # the two 148 KB copies; queued ahead of the backbones
+        can = {lvl: t.numpy() for lvl, t in host.items()}
+        up = lambda a: torch.from_numpy(a).pin_memory()
         if self._hot is None:
             self._hot = HotPath(_w.pack(can['coarse']), _w.pack(can['fine']), device=dev)
         else:
-            self._hot.wc.copy_(torch.from_numpy(_w.pack(can['coarse'])))
-            self._hot.wf.copy_(torch.from_numpy(_w.pack(can['fine'])))
-        self._hot.set_bwd_weights(_w.pack_bwd(can['coarse']), _w.pack_bwd(can['fine']))
+            self._hot.wc.copy_(up(_w.pack(can['coarse'])), non_blocking=True)
+            self._hot.wf.copy_(up(_w.pack(can['fine'])), non_blocking=True)
+        wb = getattr(self._hot, 'wb', None)
+        if wb is None or wb.get('fine') is None:
+            self._hot.set_bwd_weights(_w.pack_bwd(can['coarse']), _w.pack_bwd(can['fine']))
+        else:
+            wb['coarse'].copy_(up(_w.pack_bwd(can['coarse'])), non_blocking=True)
+            wb['fine'].copy_(up(_w.pack_bwd(can['fine'])), non_blocking=True)
         self._hot.can_dev = can_dev
-        self._hot_ver = self._hot_versions()
+        self._hot_ver = ver
         return self._hot
 
     def _train_prep(self, ref_imgs_info, rn=0):
@@ -563,6 +584,8 @@ class NeuralRayRenderer(nn.Module):
         ref = dict(data['ref_imgs_info'])
         que = dict(data['que_imgs_info'])
         is_train = 'eval' not in data
+        if self._use_autograd(is_train) and ref['imgs'].is_cuda:
+            self.repack_begin()                                             # finished in _train_prep, behind the backbones
         ref['img_feats'] = self.image_encoder(ref['imgs'])
         ref['ray_feats'] = self.init_net(ref, data.get('src_imgs_info'), is_train)
         ref['ray_feats'] = self.vis_encoder(ref['ray_feats'], ref['img_feats'])
@@ -599,14 +622,15 @@ class NeuralRayRenderer(nn.Module):
         h, w = refs[0]['imgs'].shape[-2:]
         rn, fdn, R = ques[0]['coords'].shape[1], c['fine_depth_sample_num'], c['volume_resolution']
         dev = refs[0]['imgs'].device
-        # Host-side order matters (the step is host-bound): the weight re-pack first, while the GPU is idle (its
-        # device<->host copies wait for the queue); then the backbones are queued; the reference's CPU random draws run
-        # while the GPU works on them and reach the device in one pinned, non-blocking copy each.
-        hot = self.hot_for_training()
+        # Host-side order matters: the canonical weight blobs start their way to the host first (stream-ordered, ahead of
+        # everything); then the backbones are queued; while the GPU works on them the host packs the weights and uploads them
+        # (pinned, non-blocking) and runs the reference's CPU random draws, which reach the device in one pinned copy each.
+        self.repack_begin()
         imgs = torch.cat([r['imgs'] for r in refs])
         img_feats = self.image_encoder(imgs)
         ray_feats = self.vis_encoder(self.init_net({'imgs': imgs}, None, True), img_feats)
         img_feats, ray_feats = img_feats.reshape(B, V, *img_feats.shape[1:]), ray_feats.reshape(B, V, *ray_feats.shape[1:])
+        hot = self.hot_for_training()
         want_depth = c.get('use_depth_loss', False) and 'true_depth' in refs[0]
         us, coords = [], []
         for _ in range(B):                                                  # the per-scene draw order of forward()
