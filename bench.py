@@ -334,8 +334,8 @@ def main():
     ap.add_argument('--no-train', action='store_true', help='skip the configs[4] train-step sub-record')
     ap.add_argument('--no-backbones', action='store_true', help='skip the images -> grasps figure')
     ap.add_argument('--train-scenes', type=int, default=8)
-    ap.add_argument('--train-steps', type=int, default=6)
-    ap.add_argument('--train-warmup', type=int, default=3)
+    ap.add_argument('--train-steps', type=int, default=8)
+    ap.add_argument('--train-warmup', type=int, default=10, help='the caching allocators and MIOpen settle over ~10 steps')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
