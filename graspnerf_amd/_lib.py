@@ -97,7 +97,9 @@ def lib():
     L.gnr_grasp_head_fwd.restype = C.c_int
     L.gnr_head_last_error.restype = C.c_char_p
     L.gnr_conv3d_bwd_weight.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]
-    L.gnr_conv3d_same_bwd_weight.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]
+    L.gnr_conv3d_same_bwd_weight.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_conv3d_same_bwd_weight_workspace_bytes.argtypes = [C.c_int] * 7
+    L.gnr_conv3d_same_bwd_weight_workspace_bytes.restype = C.c_size_t
     L.gnr_conv3d_same_bwd_weight.restype = C.c_int
     L.gnr_conv3d_same_workspace_bytes.argtypes = [C.c_int] * 3
     L.gnr_conv3d_same_workspace_bytes.restype = C.c_size_t
@@ -177,7 +179,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_grasp_select_fwd', 'gnr_post_last_error', 'gnr_packed_bwd_floats', 'gnr_pack_weights_bwd',
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
-            'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_same_bwd_weight',
+            'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
             'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_composite_bwd', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_host_randperm_prefix']
 
 

@@ -257,9 +257,14 @@ class _Conv3dSame(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
             xc = x.contiguous()
-            rc = _lib.lib().gnr_conv3d_same_bwd_weight(xc.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.shape[0], x.shape[1], w.shape[0],
-                                                       x.shape[2], x.shape[3], x.shape[4], k,
-                                                       C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            L = _lib.lib()
+            dims = (x.shape[0], x.shape[1], w.shape[0], x.shape[2], x.shape[3], x.shape[4], k)
+            need = L.gnr_conv3d_same_bwd_weight_workspace_bytes(*dims)
+            key = (x.device, 'wgrad', need)
+            if key not in _CONV_WS:
+                _CONV_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+            rc = L.gnr_conv3d_same_bwd_weight(xc.data_ptr(), dy.data_ptr(), dw.data_ptr(), *dims, _CONV_WS[key].data_ptr(), need,
+                                              C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             if rc:
                 raise _lib.GnrError(f'gnr_conv3d_same_bwd_weight failed: {rc}')
         db = dy.sum((0, 2, 3, 4)) if ctx.needs_input_grad[2] else None

@@ -734,12 +734,13 @@ extern "C" int gnr_conv3d_same(const float* x, const float* w, const float* bias
 // (channel-minor, + zero border) and its dy tile go to LDS once, then the four wavefronts split the K^3 taps and run
 // 64 k-steps (4 voxels each) per tap with the voxel axis as the MFMA K: A = dy [o][voxel], B = x [voxel + tap][i], both
 // read conflict-free (64 consecutive floats per wavefront instruction).  The 16x16 accumulators of a wavefront's <= 32 taps
-// stay in registers across all bricks of the workgroup and are flushed once with atomics.
+// stay in registers across all bricks of the workgroup; every workgroup stores its partial blocks, k_conv3d_wgrad_reduce
+// sums them into dw.
 // ---------------------------------------------------------------------------------------------------------
 namespace gnr_head {
 
 template <int KS>
-__global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_s1(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+__global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_s1(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                                             int B, int Cin, int Cout, int D, int H, int W, int nbi) {
     constexpr int PAD = KS / 2, TAPS = KS * KS * KS, TPW = (TAPS + 3) / 4;      // taps per wavefront
     constexpr int HX = 8 + KS - 1, HY = 8 + KS - 1, HZ = 4 + KS - 1, HALO = HX * HY * HZ;
@@ -790,27 +791,39 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_s1(const float* __restr
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hb[off[j] * 16], acc[j], 0, 0, 0);
         }
     }
-    const int i = 16 * bi + (lane & 15), kg = lane >> 4;
+    // partial sums of this workgroup: part[pair][workgroup][tap][o = 4 kg + q][i = lane % 16] (plain stores; hundreds of
+    // workgroups adding atomically into the same few thousand weights serialise at the memory side: 1.2 ms of a 1.5 ms kernel)
+    float* pp = part + (((size_t)pair * gridDim.x + blockIdx.x) * TAPS) * 256;
+    const int kg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int tap = wave + 4 * j;
-        if (tap >= TAPS || i >= Cin) continue;
+        if (tap >= TAPS) continue;
         const float e[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = 16 * bo + 4 * kg + q;
-            if (o < Cout) unsafeAtomicAdd(dw + ((size_t)o * Cin + i) * TAPS + tap, e[q]);
-        }
+        for (int q = 0; q < 4; ++q) pp[(size_t)tap * 256 + (4 * kg + q) * 16 + (lane & 15)] = e[q];
     }
+}
+
+// dw[o][i][tap] += sum over the workgroups' partial blocks
+__global__ void k_conv3d_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int Cin, int Cout, int taps, int nbi,
+                                      int npairs, int nwg) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;              // (pair, tap, o16, i16)
+    if (idx >= npairs * taps * 256) return;
+    const int pair = idx / (taps * 256), rem = idx - pair * taps * 256;
+    const int tap = rem >> 8, o16 = (rem >> 4) & 15, i16 = rem & 15;
+    const int bi = pair % nbi, bo = pair / nbi;
+    const int o = 16 * bo + o16, i = 16 * bi + i16;
+    if (o >= Cout || i >= Cin) return;
+    const float* p = part + ((size_t)pair * nwg * taps) * 256 + rem;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += p[(size_t)w * taps * 256];
+    dw[((size_t)o * Cin + i) * taps + tap] += s;
 }
 
 }  // namespace gnr_head
 
-// dw [Cout][Cin][K][K][K] is ACCUMULATED (zero it first); K = 3 or 5.  Same contract as gnr_conv3d_bwd_weight.
-extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
-                                          void* stream) {
-    if (!x || !dy || !dw || B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5)) return GNR_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
+static long wgrad_grid(int B, int Cin, int Cout, int D, int H, int W) {
     const int nbi = (Cin + 15) / 16, nbo = (Cout + 15) / 16;
     const long nbricks = (long)B * ((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4);
     int dev = 0, cus = 256;
@@ -818,19 +831,44 @@ extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     long gx = (cus + nbi * nbo - 1) / (nbi * nbo);
     if (gx > nbricks) gx = nbricks;
-    if (gx < 1) gx = 1;
-    HeadScope hs("k_conv3d_wgrad_s1@gnr_conv3d_same_bwd_weight", stream);
-    if (K == 5) {
-        const size_t lds = (16 * (12 * 12 * 8) + 16 * 256) * sizeof(float);
-        static bool attr = false;
-        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-        hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, dw, B, Cin, Cout, D, H, W, nbi);
-    } else {
-        const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
-        static bool attr = false;
-        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-        hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<3>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, dw, B, Cin, Cout, D, H, W, nbi);
+    return gx < 1 ? 1 : gx;
+}
+
+extern "C" size_t gnr_conv3d_same_bwd_weight_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int K) {
+    if (B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || K < 1) return 0;
+    const size_t npairs = (size_t)((Cin + 15) / 16) * ((Cout + 15) / 16);
+    return npairs * (size_t)wgrad_grid(B, Cin, Cout, D, H, W) * K * K * K * 256 * sizeof(float);
+}
+
+// dw [Cout][Cin][K][K][K] is ACCUMULATED (zero it first); K = 3 or 5; workspace = gnr_conv3d_same_bwd_weight_workspace_bytes(...).
+extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw || !ws || B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5)) return GNR_ERR_ARG;
+    if (ws_bytes < gnr_conv3d_same_bwd_weight_workspace_bytes(B, Cin, Cout, D, H, W, K)) return GNR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbi = (Cin + 15) / 16, nbo = (Cout + 15) / 16;
+    const long gx = wgrad_grid(B, Cin, Cout, D, H, W);
+    float* part = (float*)ws;
+    {
+        HeadScope hs("k_conv3d_wgrad_s1@gnr_conv3d_same_bwd_weight", stream);
+        if (K == 5) {
+            const size_t lds = (16 * (12 * 12 * 8) + 16 * 256) * sizeof(float);
+            static bool attr = false;
+            if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+            hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi);
+        } else {
+            const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
+            static bool attr = false;
+            if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+            hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<3>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi);
+        }
+        HCHK(hipGetLastError());
     }
-    HCHK(hipGetLastError());
+    {
+        HeadScope hs("k_conv3d_wgrad_reduce@gnr_conv3d_same_bwd_weight", stream);
+        const int K3 = K * K * K, n = nbi * nbo * K3 * 256;
+        hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)part, dw, Cin, Cout, K3, nbi, nbi * nbo, (int)gx);
+        HCHK(hipGetLastError());
+    }
     return GNR_OK;
 }

@@ -319,14 +319,25 @@ class NeuralRayRenderer(nn.Module):
             self._hot_ver = ver
         return self._hot
 
+    def _pinned(self, name, n):
+        """Persistent pinned staging buffers of the per-step weight re-pack (allocating pinned memory every step is a slow
+        path of the host allocator that can stall the queue)."""
+        bufs = self.__dict__.setdefault('_pin_bufs', {})
+        if name not in bufs or bufs[name].numel() != n:
+            bufs[name] = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        return bufs[name]
+
     def repack_begin(self):
         """First half of the per-step weight re-pack, to be called BEFORE the 2D backbones are queued: the canonical blobs of
         both levels are gathered on the device and start their way to pinned host memory (stream-ordered, nothing waits).
         hot_for_training() then finishes the job -- host-side packing + pinned, non-blocking uploads -- while the GPU works
         on the backbones, instead of holding the GPU idle for it at the start of every step."""
         sd = self._params()
+        up = getattr(self, '_repack_uploaded', None)
+        if up is not None:
+            up.synchronize()                                                # the staging buffers of the previous re-pack are free
         can_dev = {lvl: _w.canonical_blob_device(sd, lvl, as_tensor=True) for lvl in ('coarse', 'fine')}
-        host = {lvl: torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for lvl, t in can_dev.items()}
+        host = {lvl: self._pinned('can_' + lvl, t.numel()).copy_(t, non_blocking=True) for lvl, t in can_dev.items()}
         ev = torch.cuda.Event()
         ev.record()
         self._repack_pending = (can_dev, host, ev, self._hot_versions())
@@ -341,18 +352,24 @@ class NeuralRayRenderer(nn.Module):
         dev = next(self.parameters()).device
         ev.synchronize()                                                    # the two 148 KB copies; queued ahead of the backbones
         can = {lvl: t.numpy() for lvl, t in host.items()}
-        up = lambda a: torch.from_numpy(a).pin_memory()
+
+        def up(name, a):                                                    # packed host array -> persistent pinned buffer
+            buf = self._pinned(name, a.size)
+            buf.numpy()[:] = a
+            return buf
         if self._hot is None:
             self._hot = HotPath(_w.pack(can['coarse']), _w.pack(can['fine']), device=dev)
         else:
-            self._hot.wc.copy_(up(_w.pack(can['coarse'])), non_blocking=True)
-            self._hot.wf.copy_(up(_w.pack(can['fine'])), non_blocking=True)
+            self._hot.wc.copy_(up('wc', _w.pack(can['coarse'])), non_blocking=True)
+            self._hot.wf.copy_(up('wf', _w.pack(can['fine'])), non_blocking=True)
         wb = getattr(self._hot, 'wb', None)
         if wb is None or wb.get('fine') is None:
             self._hot.set_bwd_weights(_w.pack_bwd(can['coarse']), _w.pack_bwd(can['fine']))
         else:
-            wb['coarse'].copy_(up(_w.pack_bwd(can['coarse'])), non_blocking=True)
-            wb['fine'].copy_(up(_w.pack_bwd(can['fine'])), non_blocking=True)
+            wb['coarse'].copy_(up('wbc', _w.pack_bwd(can['coarse'])), non_blocking=True)
+            wb['fine'].copy_(up('wbf', _w.pack_bwd(can['fine'])), non_blocking=True)
+        self._repack_uploaded = torch.cuda.Event()
+        self._repack_uploaded.record()
         self._hot.can_dev = can_dev
         self._hot_ver = ver
         return self._hot

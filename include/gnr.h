@@ -162,10 +162,12 @@ int gnr_conv3d_bwd_weight(const float* x, const float* dy, float* dw, int B, int
  *   mode 0 (forward):        x [B][Cin][D][H][W]       -> y  [B][Cout][D][H][W]  (+ bias [Cout], or NULL)
  *   mode 1 (backward data):  x = dy [B][Cout][D][H][W] -> y = dx [B][Cin][D][H][W]  (transposed, flipped weights; bias ignored) */
 /*   gnr_conv3d_same_bwd_weight: dw [Cout][Cin][K][K][K] is ACCUMULATED from x [B][Cin][D][H][W] and dy [B][Cout][D][H][W]
- *   (LDS-staged successor of gnr_conv3d_bwd_weight for K = 3 / 5). */
+ *   (LDS-staged successor of gnr_conv3d_bwd_weight for K = 3 / 5; the workgroups' partial blocks go through `workspace` and
+ *   are summed by a second kernel instead of hundreds of workgroups adding atomically into the same few thousand weights). */
 size_t gnr_conv3d_same_workspace_bytes(int Cin, int Cout, int K);
+size_t gnr_conv3d_same_bwd_weight_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int K);
 int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
-                               void* stream);
+                               void* workspace, size_t workspace_bytes, void* stream);
 int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int K,
                     int mode, void* workspace, size_t workspace_bytes, void* stream);
 
