@@ -226,11 +226,18 @@ def train_leg(args, world, rank, dev, dist, sync):
     dom = 'k_view1_bwd@gnr_sample_volume_bwd'          # dominant backward kernel of the path: first view loop, volume points
     if rank == 0:
         _lib.timing_begin(only=dom)                    # the timed steps bracket this kernel only
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.train_steps + 1)]
+    host = []
     t0 = time.perf_counter()
-    for _ in range(args.train_steps):
+    marks[0].record()
+    for i in range(args.train_steps):
+        h0 = time.perf_counter()
         log = tr.step(scenes)
+        host.append((time.perf_counter() - h0) * 1e3)
+        marks[i + 1].record()                              # per-step spans on the stream (no synchronisation added)
     sync()
     dt = max_over_ranks(time.perf_counter() - t0, dev)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.train_steps)]
     table = _lib.timing_end() if rank == 0 else {}
     K = args.train_steps
     # per-kernel table of the library: two further steps with every launch bracketed (outside the timed region: ~60 event
@@ -256,6 +263,8 @@ def train_leg(args, world, rank, dev, dist, sync):
             'warmup': args.train_warmup, 'scenes_per_gpu': n, 'global_batch': world * n, 'n_gpus': world, 'dtype': 'f32', 'data': 'synthetic',
             'config': 'BASELINE.json configs[4]: backbones + nr TSDF + render + depth-mean head + grasp head + losses (render, depth, sdf, vgn), '
                       'batch 8/GPU, one flat fp32 gradient all-reduce (4.66 M parameters), Adam',
+            'ms_each_step': [round(x, 2) for x in step_ms], 'ms_per_step_median': round(float(np.median(step_ms)), 3),
+            'host_ms_each_step': [round(x, 2) for x in host],
             'max_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 3),
             'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')},
             'split_ms_per_step': {'hip_path_kernels': round(path_ms, 3), 'hip_grasp_head_kernels': round(head_ms, 3),
