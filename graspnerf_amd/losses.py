@@ -1,7 +1,13 @@
 """Loss / metric terms of the reference evaluated on the forward outputs (first half): plain
 PyTorch reductions over the output dict, same keys and weights as `src/nr/network/loss.py` for the configured path
 (`loss: [render, depth, sdf, vgn]`, configs/nrvgn_sdf.yaml:36).  They run on whatever device the outputs live on.
-The training step is graspnerf_amd/trainer.py."""
+The training step is graspnerf_amd/trainer.py.
+
+Every term takes `scenes=None` (one scene: the reference's shapes and reductions) or `scenes=B`: the inputs carry B scenes
+stacked along the leading axis and every reduction the reference does over one scene becomes a reduction per scene, so each
+term comes out as a [B] vector whose entry b equals the one-scene term of scene b.  One set of launches for the whole
+batch instead of one per scene: the loss section of a train step is some 60 small kernels per scene and direction, which at
+8 scenes per GPU is enough to leave the device waiting for the host."""
 import math
 
 import torch
@@ -26,6 +32,15 @@ def render_loss(pr, use_ray_mask=True, weight=0.01, fine=True):
     return out
 
 
+def _mean(x, scenes):
+    """Mean over one scene's elements: a scalar (scenes None) or [B]."""
+    return x.mean() if scenes is None else x.reshape(scenes, -1).mean(1)
+
+
+def _sum(x, scenes):
+    return x.sum() if scenes is None else x.reshape(scenes, -1).sum(1)
+
+
 def _bilinear_border_ac(maps, coords):
     """maps [rfn,1,h,w], coords [rfn,pn,2] -> [rfn,pn]; interpolate_feats(..., 'border', align_corners=True) with
     coords used as (x, y) (ref: ops.py:14-34; the reference passes (row, col) here, loss.py:104-110, kept)."""
@@ -35,30 +50,40 @@ def _bilinear_border_ac(maps, coords):
     return F.grid_sample(maps, g, mode='bilinear', padding_mode='border', align_corners=True)[:, 0, 0]
 
 
-def depth_loss(pr, true_depth, depth_range, weight=1.0):
-    """ref: loss.py:87-144 (DepthLoss, l2 in normalised inverse depth; non-'gso' scenes)."""
-    depth_gt = _bilinear_border_ac(true_depth, pr['depth_coords'])
+def depth_loss(pr, true_depth, depth_range, weight=1.0, scenes=None):
+    """ref: loss.py:87-144 (DepthLoss, l2 in normalised inverse depth; non-'gso' scenes).
+    scenes=B: true_depth [B*rfn,1,h,w], depth_range [B*rfn,2], pr['depth_coords'] [B,rfn,pn,2], pr['depth_mean*'] [B,rfn,pn]."""
+    coords = pr['depth_coords'] if scenes is None else pr['depth_coords'].flatten(0, 1)
+    flat = (lambda x: x) if scenes is None else (lambda x: x.flatten(0, 1))
+    depth_gt = _bilinear_border_ac(true_depth, coords)
     near, far = -1 / depth_range[:, 0:1], -1 / depth_range[:, 1:2]
 
     def norm(d):
         d = -1 / torch.clamp(d, min=1e-5)
         return torch.clamp((d - near) / (far - near), min=0, max=1.0)
     gt = norm(depth_gt)
-    out = {'loss_depth': ((gt - pr['depth_mean']) ** 2).mean() * weight}
+    out = {'loss_depth': _mean((gt - flat(pr['depth_mean'])) ** 2, scenes) * weight}
     if 'depth_mean_fine' in pr:
-        out['loss_depth_fine'] = ((gt - pr['depth_mean_fine']) ** 2).mean() * weight
+        out['loss_depth_fine'] = _mean((gt - flat(pr['depth_mean_fine'])) ** 2, scenes) * weight
     return out
 
 
-def sdf_loss(pr, sdf_gt, w_sdf=1.0, w_eik=0.1):
-    """ref: loss.py:149-178 (SDFLoss: SmoothL1 on valid = sdf_gt != -1, eikonal term, sdf_mae, variance)."""
+def sdf_loss(pr, sdf_gt, w_sdf=1.0, w_eik=0.1, scenes=None):
+    """ref: loss.py:149-178 (SDFLoss: SmoothL1 on valid = sdf_gt != -1, eikonal term, sdf_mae, variance).
+    scenes=B: sdf_gt [B,R,R,R], pr['volume'] [B,1,R,R,R], pr['sdf_gradient_error'] [B,...]; pr['s'] is shared."""
     valid = sdf_gt != -1.0
-    vol = pr['volume'][0, 0]
-    out = {'sdf_mae': (torch.abs(vol * valid - sdf_gt * valid).sum() / valid.sum().clamp(min=1))[None],
-           'loss_sdf': F.smooth_l1_loss(sdf_gt * valid, vol * valid)[None] * w_sdf,
-           'loss_eikonal': pr['sdf_gradient_error'].mean()[None] * w_eik,
-           'variance': pr['s'][None]}
-    return out
+    if scenes is None:
+        vol = pr['volume'][0, 0]
+        out = {'sdf_mae': (torch.abs(vol * valid - sdf_gt * valid).sum() / valid.sum().clamp(min=1))[None],
+               'loss_sdf': F.smooth_l1_loss(sdf_gt * valid, vol * valid)[None] * w_sdf,
+               'loss_eikonal': pr['sdf_gradient_error'].mean()[None] * w_eik,
+               'variance': pr['s'][None]}
+        return out
+    vol = pr['volume'][:, 0]
+    return {'sdf_mae': _sum(torch.abs(vol * valid - sdf_gt * valid), scenes) / _sum(valid, scenes).clamp(min=1),
+            'loss_sdf': _mean(F.smooth_l1_loss(sdf_gt * valid, vol * valid, reduction='none'), scenes) * w_sdf,
+            'loss_eikonal': _mean(pr['sdf_gradient_error'], scenes) * w_eik,
+            'variance': pr['s'].reshape(1, -1).expand(scenes, -1)}
 
 
 def _quat_to_rot(q):
@@ -78,26 +103,39 @@ def _geodesic_deg(m1, m2):
     return torch.min(th, 2 * math.pi - th) * (180 / math.pi)
 
 
-def vgn_loss(vgn_pred, grasp_info, weight=1e-2):
+def vgn_loss(vgn_pred, grasp_info, weight=1e-2, scenes=None):
     """ref: loss.py:180-252 (VGNLoss).  vgn_pred = (label[N], rot[N,4], width[N]) gathered at the GT voxels
-    (GraspNeRF.select); grasp_info = (index, label[N], rotations[N,2,4], width[N])."""
+    (GraspNeRF.select); grasp_info = (index, label[N], rotations[N,2,4], width[N]).
+    scenes=B: every tensor with a leading B (label [B,N], rot [B,N,4], rotations [B,N,2,4] ...)."""
     label_pred, rot_pred, width_pred = vgn_pred
     _, label, rots, width = grasp_info
+    if scenes is not None:
+        n = label.shape[1]
+        label_pred, rot_pred, width_pred, label, rots, width = (x.flatten(0, 1) for x in (label_pred, rot_pred, width_pred, label, rots, width))
     l_qual = F.binary_cross_entropy(label_pred, label, reduction='none')
     qloss = lambda t: 1.0 - torch.abs(torch.sum(rot_pred * t, dim=1))
     l_rot = label * torch.min(qloss(rots[:, 0]), qloss(rots[:, 1]))
     l_width = label * 0.01 * F.mse_loss(width_pred, width, reduction='none')
     loss = l_qual + l_rot + l_width
-    out = {'loss_vgn': loss.mean()[None] * weight, 'vgn_total_loss': loss.mean()[None], 'vgn_qual_loss': l_qual.mean()[None],
-           'vgn_rot_loss': l_rot.mean()[None], 'vgn_width_loss': l_width.mean()[None],
-           'vgn_qual_acc': (100 * (torch.round(label_pred) == label).float().sum() / label.shape[0])[None]}
-    num = torch.count_nonzero(label)
     pr_m = _quat_to_rot(rot_pred)
     err = torch.min(_geodesic_deg(_quat_to_rot(rots[:, 0]), pr_m), _geodesic_deg(_quat_to_rot(rots[:, 1]), pr_m))
-    out['vgn_rot_err'] = ((label * err).sum() / num.clamp(min=1))[None]          # 0 when no positive label; no host sync
+    if scenes is None:
+        out = {'loss_vgn': loss.mean()[None] * weight, 'vgn_total_loss': loss.mean()[None], 'vgn_qual_loss': l_qual.mean()[None],
+               'vgn_rot_loss': l_rot.mean()[None], 'vgn_width_loss': l_width.mean()[None],
+               'vgn_qual_acc': (100 * (torch.round(label_pred) == label).float().sum() / label.shape[0])[None]}
+        num = torch.count_nonzero(label)
+        out['vgn_rot_err'] = ((label * err).sum() / num.clamp(min=1))[None]      # 0 when no positive label; no host sync
+        return out
+    out = {'loss_vgn': _mean(loss, scenes) * weight, 'vgn_total_loss': _mean(loss, scenes), 'vgn_qual_loss': _mean(l_qual, scenes),
+           'vgn_rot_loss': _mean(l_rot, scenes), 'vgn_width_loss': _mean(l_width, scenes),
+           'vgn_qual_acc': 100 * _sum((torch.round(label_pred) == label).float(), scenes) / n}
+    out['vgn_rot_err'] = _sum(label * err, scenes) / _sum(label != 0, scenes).clamp(min=1)
     return out
 
 
-def total_loss(terms):
-    """Sum of every entry whose key starts with 'loss' (ref: train/trainer.py:147-155)."""
-    return sum(v.mean() for k, v in terms.items() if k.startswith('loss'))
+def total_loss(terms, scenes=None):
+    """Sum of every entry whose key starts with 'loss' (ref: train/trainer.py:147-155).  scenes=B: the terms are [B] vectors
+    (one entry per scene) and the result is the SUM over the scenes of the per-scene totals."""
+    if scenes is None:
+        return sum(v.mean() for k, v in terms.items() if k.startswith('loss'))
+    return torch.stack([v.reshape(scenes, -1).mean(1) for k, v in terms.items() if k.startswith('loss')]).sum()

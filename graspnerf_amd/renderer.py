@@ -443,26 +443,33 @@ class NeuralRayRenderer(nn.Module):
                 'rmask': ex['ray_mask'].reshape(R), 'gt': ex['pixel_colors_gt'].reshape(R, 3) if 'pixel_colors_gt' in ex else None,
                 's': P[agg + 'deviation_network.variance'].reshape(1, 1)}, ex
 
+    _SHARED_KEYS = ('s', 's_fine')                                         # one value for all scenes of a forward
+    _PER_VIEW_KEYS = ('depth_mean', 'depth_coords', 'depth_mean_2', 'depth_mean_fine', 'depth_mean_fine_2')   # [rfn,...], no leading 1
+
     @staticmethod
-    def _scene_dicts(o, B, rn, suffix=''):
-        """Per-scene output dicts (renderer.py:110-138 keys, leading 1) out of a pass's [B*rn, ...] results."""
-        outs = []
-        for b in range(B):
-            sl = slice(b * rn, (b + 1) * rn)
-            d = {'sdf_values': o['sdf'][sl][None], 'alpha_values': o['alpha'][sl][None], 'colors_nr': o['col'][sl][None],
-                 'hit_prob_nr': o['hit'][sl][None], 'pixel_colors_nr': o['pix'][sl][None], 'sdf_gradient_error': o['gerr'][b:b + 1],
-                 's': o['s'], 'render_depth': o['rdepth'][sl][None], 'ray_mask': o['rmask'][sl][None]}
-            if o['gt'] is not None:
-                d['pixel_colors_gt'] = o['gt'][sl][None]
-            outs.append({k + suffix: v for k, v in d.items()})
-        return outs
+    def _stacked(o, B, rn, suffix=''):
+        """A pass's [B*rn, ...] results as scene-major stacks: the keys of renderer.py:110-138 with a leading B where the
+        reference has its leading 1 (qn)."""
+        un = lambda x: x.reshape(B, rn, *x.shape[1:])
+        d = {'sdf_values': un(o['sdf']), 'alpha_values': un(o['alpha']), 'colors_nr': un(o['col']), 'hit_prob_nr': un(o['hit']),
+             'pixel_colors_nr': un(o['pix']), 'sdf_gradient_error': o['gerr'], 's': o['s'], 'render_depth': un(o['rdepth']),
+             'ray_mask': un(o['rmask'])}
+        if o['gt'] is not None:
+            d['pixel_colors_gt'] = un(o['gt'])
+        return {k + suffix: v for k, v in d.items()}
+
+    @classmethod
+    def unstack(cls, st, B):
+        """Scene-major stacks -> list of B per-scene output dicts with the reference's shapes (views of the stacks)."""
+        one = lambda k, v, b: v if k in cls._SHARED_KEYS else v[b] if k in cls._PER_VIEW_KEYS else v[b:b + 1]
+        return [{k: one(k, v, b) for k, v in st.items()} for b in range(B)]
 
     def _render_train(self, hot, prep, que_b, fine_u, ray_feats, img_feats):
         """renderer.py:140-162 + 201-220 for B scenes in training mode: ray chunks of ray_batch_num (the reference's loop,
         outputs concatenated along the ray axis, the [1,1] scalars become [1,n_chunks]); per chunk the coarse pass (coarse
         depths sampled, fine depths resampled from `fine_u` and sorted inside the forward kernels), then the fine pass.
         que_b: coords [B,rn,2], pose [B,3,4], K [B,3,3], depth_range [B,2] (+ imgs [B,3,H,W]); fine_u [B,rn,fdn] on the device.
-        -> list of B per-scene dicts with '' and '_fine' keys."""
+        -> scene-major stacks ([B, ...], `unstack` makes the per-scene dicts) with '' and '_fine' keys."""
         P = self._params()
         B, rn = que_b['coords'].shape[:2]
         chunk = self.cfg['ray_batch_num']
@@ -472,17 +479,13 @@ class NeuralRayRenderer(nn.Module):
             n = q['coords'].shape[1]
             coarse, ex = self._train_pass(hot, prep, q, None, 'coarse', True, ray_feats, img_feats, P)
             fine, _ = self._train_pass(hot, prep, q, ex['fine_depth'], 'fine', False, ray_feats, img_feats, P)
-            outs = self._scene_dicts(coarse, B, n)
-            for o, f in zip(outs, self._scene_dicts(fine, B, n, '_fine')):
-                o.update(f)
-            parts.append(outs)
-        outs = [{k: torch.cat([p[b][k] for p in parts], 1) for k in parts[0][b]} for b in range(B)] if len(parts) > 1 else parts[0]
-        for o in outs:
-            if not self.cfg['render_depth']:
-                o.pop('render_depth', None), o.pop('render_depth_fine', None)
-            if not self.cfg['use_ray_mask']:                                # renderer.py:129-132
-                o.pop('ray_mask', None), o.pop('ray_mask_fine', None)
-        return outs
+            parts.append(dict(self._stacked(coarse, B, n), **self._stacked(fine, B, n, '_fine')))
+        st = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]} if len(parts) > 1 else parts[0]
+        if not self.cfg['render_depth']:
+            st.pop('render_depth', None), st.pop('render_depth_fine', None)
+        if not self.cfg['use_ray_mask']:                                    # renderer.py:129-132
+            st.pop('ray_mask', None), st.pop('ray_mask_fine', None)
+        return st
 
     def _render_autograd(self, que, ref, _prep=None):
         """One scene in training mode (the reference's API): the is_train inverse-CDF samples are drawn exactly as the
@@ -501,7 +504,7 @@ class NeuralRayRenderer(nn.Module):
         bq = {'coords': que['coords'], 'pose': que['poses'], 'K': que['Ks'], 'depth_range': que['depth_range']}
         if 'imgs' in que:
             bq['imgs'] = que['imgs']
-        return self._render_train(hot, prep, bq, fine_u, ref['ray_feats'][None], ref['img_feats'][None])[0]
+        return self._render_train(hot, prep, bq, fine_u, ref['ray_feats'][None], ref['img_feats'][None])    # B = 1: the stacks ARE the reference's shapes
 
     @staticmethod
     def draw_fine_u(rn, fdn, chunk):
@@ -621,11 +624,12 @@ class NeuralRayRenderer(nn.Module):
         return out
 
 
-    def forward_scenes(self, datas):
+    def forward_scenes(self, datas, stacked=False):
         """Training forward of several scenes in ONE pass (trainer-internal; the reference's API is one scene per forward):
         batched backbones, one weight re-pack, batched HIP twin pairs, one per-ray tail over the rays of all scenes.  Same
         values and the same RNG stream as `[self.forward(d) for d in datas]` (which it falls back to whenever the batch is
-        not uniform, off the GPU, or autograd is off).  -> list of per-scene output dicts, or None when the scenes cannot
+        not uniform, off the GPU, or autograd is off).  -> list of per-scene output dicts (stacked=True: ONE dict of
+        scene-major stacks, leading B where the reference has its leading 1; `unstack` gives the list), or None when the scenes cannot
         be batched (the caller must then run forward + backward scene by scene: the HIP twin pairs keep their saved states
         in per-module workspaces, so a second training forward before the first one's backward would overwrite them)."""
         c = self.cfg
@@ -670,18 +674,15 @@ class NeuralRayRenderer(nn.Module):
                  'K': torch.cat([q['Ks'] for q in ques]), 'depth_range': torch.cat([q['depth_range'] for q in ques])}
         if 'imgs' in ques[0]:
             que_b['imgs'] = torch.cat([q['imgs'] for q in ques])
-        outs = self._render_train(hot, prep, que_b, fine_u, ray_feats, img_feats)
-        vol = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
+        st = self._render_train(hot, prep, que_b, fine_u, ray_feats, img_feats)
+        st['volume'] = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
         if want_depth:
             xy = coords.to(torch.float32)
             mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
                       for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
-        for b, o in enumerate(outs):
-            o['volume'] = vol[b:b + 1]
-            if want_depth:
-                o.update({'depth_mean': mc[b, ..., 0], 'depth_coords': coords[b][None].repeat(V, 1, 1), 'depth_mean_2': mc[b, ..., 1],
-                          'depth_mean_fine': mf[b, ..., 0], 'depth_mean_fine_2': mf[b, ..., 1]})
-        return outs
+            st.update({'depth_mean': mc[..., 0], 'depth_coords': coords[:, None].expand(B, V, *coords.shape[1:]), 'depth_mean_2': mc[..., 1],
+                       'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]})
+        return st if stacked else self.unstack(st, B)
 
 
 class GraspNeRF(nn.Module):
@@ -732,12 +733,25 @@ class GraspNeRF(nn.Module):
         render_outputs['vgn_pred'] = vgn_pred if 'full_vol' in data else self.select(vgn_pred, data['grasp_info'][0])
         return render_outputs
 
-    def forward_scenes(self, datas):
-        """Several scenes in one training forward (NeuralRayRenderer.forward_scenes + one batched grasp-head call)."""
-        outs = self.nr_net.forward_scenes(datas)
-        if outs is None:
+    def forward_scenes(self, datas, stacked=False):
+        """Several scenes in one training forward (NeuralRayRenderer.forward_scenes + one batched grasp-head call).
+        stacked=True: one dict of scene-major stacks, 'vgn_pred' = (label [B,N], rot [B,N,4], width [B,N]) gathered at every
+        scene's GT voxels in one indexing call; declined (None, before anything runs) when a scene wants the full volumes or
+        the scenes carry different numbers of grasps."""
+        if stacked and (any('full_vol' in d for d in datas) or len({tuple(d['grasp_info'][0].shape) for d in datas}) != 1):
             return None
-        q, r, w = self.grasp_head(torch.cat([o['volume'] for o in outs]))
+        st = self.nr_net.forward_scenes(datas, stacked=True)
+        if st is None:
+            return None
+        B = len(datas)
+        q, r, w = self.grasp_head(st['volume'])
+        if stacked:
+            idx = torch.stack([d['grasp_info'][0] for d in datas])          # [B,N,3]
+            b = torch.arange(B, device=q.device)[:, None]
+            i, j, k = idx[..., 0], idx[..., 1], idx[..., 2]
+            st['vgn_pred'] = (q[b, 0, i, j, k], r[b, :, i, j, k], w[b, 0, i, j, k])
+            return st
+        outs = self.nr_net.unstack(st, B)
         for b, (o, d) in enumerate(zip(outs, datas)):
             pred = (q[b:b + 1], r[b:b + 1], w[b:b + 1])
             o['vgn_pred'] = pred if 'full_vol' in d else self.select(pred, d['grasp_info'][0])

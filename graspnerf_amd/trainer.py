@@ -26,6 +26,19 @@ def train_losses(out, data, cfg=None):
     return terms
 
 
+def train_losses_stacked(st, datas):
+    """`train_losses` of B scenes at once on the scene-major stacks of forward_scenes(..., stacked=True): the same terms,
+    each a [B] vector with one entry per scene (losses.py `scenes=B`)."""
+    B = len(datas)
+    refs = [d['ref_imgs_info'] for d in datas]
+    terms = {}
+    terms.update(losses.render_loss(st))                                   # the reference's qn axis is the scene axis here
+    terms.update(losses.depth_loss(st, torch.cat([r['true_depth'] for r in refs]), torch.cat([r['depth_range'] for r in refs]), scenes=B))
+    terms.update(losses.sdf_loss(st, torch.stack([r['sdf_gt'] for r in refs]), scenes=B))
+    terms.update(losses.vgn_loss(st['vgn_pred'], tuple(torch.stack(x) for x in zip(*[d['grasp_info'] for d in datas])), scenes=B))
+    return terms
+
+
 def exp_decay_lr(step, lr_init=1e-4, decay_step=100000, decay_rate=0.5, lr_min=1e-5):
     return max(lr_init * (decay_rate ** (step // decay_step)), lr_min)
 
@@ -67,10 +80,17 @@ class Trainer:
             g['lr'] = lr
         self.optimizer.zero_grad(set_to_none=True)
         datas = [dict(d, step=self.step_id) for d in scenes]
-        outs = None
+        outs = st = None
         if self.batched and hasattr(self.net, 'forward_scenes') and len(datas) > 1:
-            outs = self.net.forward_scenes(datas)          # all scenes of the rank in one forward (None: cannot batch)
-        if outs is not None:
+            # all scenes of the rank in one forward (None: cannot batch): first choice scene-major stacks and ONE set of
+            # loss launches for the batch, second the per-scene dicts and the per-scene losses
+            st = self.net.forward_scenes(datas, stacked=True)
+            outs = self.net.forward_scenes(datas) if st is None else None
+        if st is not None:
+            terms = train_losses_stacked(st, datas)
+            losses.total_loss(terms, scenes=len(datas)).backward()
+            all_terms = terms
+        elif outs is not None:
             all_terms = [train_losses(o, d) for o, d in zip(outs, datas)]
             sum(losses.total_loss(t) for t in all_terms).backward()
         else:
@@ -86,8 +106,12 @@ class Trainer:
         # stall the host 80 times in front of the all-reduce and the optimiser)
         if not all_terms:                                  # empty shard (global batch < world): took part in the all-reduce only
             return {'lr': lr}
-        keys = list(all_terms[0])
-        means = torch.stack([torch.stack([t[k].detach().float().mean() for k in keys]) for t in all_terms]).mean(0).tolist()
+        if isinstance(all_terms, dict):                    # [B] vectors: the mean over the local scenes is the mean of each
+            keys = list(all_terms)
+            means = torch.stack([all_terms[k].detach().float().mean() for k in keys]).tolist()
+        else:
+            keys = list(all_terms[0])
+            means = torch.stack([torch.stack([t[k].detach().float().mean() for k in keys]) for t in all_terms]).mean(0).tolist()
         log = dict(zip(keys, means))
         log['lr'] = lr
         return log

@@ -527,7 +527,7 @@ class ReferenceRenderer(NeuralRayRenderer):
     def _need_gpu(self, t):
         pass
 
-    def forward_scenes(self, datas):
+    def forward_scenes(self, datas, stacked=False):
         return None                                                        # scene by scene, like the reference
 
 

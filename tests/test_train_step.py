@@ -284,21 +284,28 @@ def test_hip_and_autograd_training_paths_agree():
 
 @pytest.mark.gpu
 def test_batched_training_forward_equals_per_scene_loop():
-    """Trainer: all scenes of a rank in one forward / backward (forward_scenes) against the reference-style loop of
-    per-scene forwards -- same RNG stream, same losses, same accumulated gradients."""
-    from graspnerf_amd.trainer import train_losses
+    """Trainer: all scenes of a rank in one forward / backward (forward_scenes: per-scene dicts + per-scene losses, and the
+    scene-major stacks + stacked losses Trainer.step runs) against the reference-style loop of per-scene forwards -- same
+    RNG stream, same losses, same accumulated gradients."""
+    from graspnerf_amd.trainer import train_losses, train_losses_stacked
     from graspnerf_amd import losses
     net = build('cuda').train()
     datas = [scene_data('cuda', 0), scene_data('cuda', 1), scene_data('cuda', 2)]
     assert net.forward_scenes(datas) is None                   # 64 rays > ray_batch_num 40: several chunks, not batchable
     net.nr_net.cfg['ray_batch_num'] = 4096
     res = {}
-    for batched in (False, True):
+    for batched in (False, True, 'stacked'):
         net.zero_grad(set_to_none=True)
         for a in (net.nr_net.agg_net, net.nr_net.fine_agg_net):
             a.step = 0
         torch.manual_seed(21)
-        if batched:
+        if batched == 'stacked':
+            st = net.forward_scenes(datas, stacked=True)
+            assert isinstance(st, dict) and st['pixel_colors_nr'].shape == (3, 64, 3) and st['vgn_pred'][1].shape[:1] == (3,)
+            tv = train_losses_stacked(st, datas)
+            losses.total_loss(tv, scenes=3).backward()
+            terms = [{k: v[b] for k, v in tv.items()} for b in range(3)]
+        elif batched:
             outs = net.forward_scenes(datas)
             assert outs is not None
             terms = [train_losses(o, d) for o, d in zip(outs, datas)]
@@ -312,17 +319,20 @@ def test_batched_training_forward_equals_per_scene_loop():
         torch.cuda.synchronize()
         res[batched] = ([{k: float(v.detach().mean()) for k, v in t.items() if k.startswith('loss')} for t in terms],
                         {k: p.grad.detach().clone() for k, p in net.named_parameters()})
-    for la, lb in zip(res[False][0], res[True][0]):
-        for k in la:
-            assert abs(la[k] - lb[k]) <= 1e-4 * abs(la[k]) + 1e-7, (k, la[k], lb[k])
-    for k, g in res[False][1].items():
-        if any(s in k for s in ('dist_decoder', 'agg_net', 'vgn_net')):
-            d = (res[True][1][k] - g).abs().max().item()
-            assert d <= 3e-3 * g.abs().max().item() + 1e-6, (k, d, g.abs().max().item())
-        else:
-            # the 2D backbones run through MIOpen, which picks other (Winograd) algorithms for the batched call
-            d = (res[True][1][k] - g).norm().item()
-            assert d <= 3e-2 * g.norm().item() + 1e-6, (k, d, g.norm().item())
+    for mode in (True, 'stacked'):
+        for la, lb in zip(res[False][0], res[mode][0]):
+            for k in la:
+                assert abs(la[k] - lb[k]) <= 1e-4 * abs(la[k]) + 1e-7, (mode, k, la[k], lb[k])
+        for k, g in res[False][1].items():
+            if any(s in k for s in ('dist_decoder', 'agg_net', 'vgn_net')):
+                d = (res[mode][1][k] - g).abs().max().item()
+                assert d <= 3e-3 * g.abs().max().item() + 1e-6, (mode, k, d, g.abs().max().item())
+            else:
+                # the 2D backbones run through MIOpen, which picks other (Winograd) algorithms for the batched call
+                d = (res[mode][1][k] - g).norm().item()
+                assert d <= 3e-2 * g.norm().item() + 1e-6, (mode, k, d, g.norm().item())
+    uneven = [dict(datas[0]), dict(datas[1], grasp_info=tuple(x[:-1] for x in datas[1]['grasp_info']))]
+    assert net.forward_scenes(uneven, stacked=True) is None, 'different grasp counts: declined before anything runs'
 
 
 @pytest.mark.gpu
@@ -406,9 +416,9 @@ def test_full_size_train_step_matches_the_reference_statement():
     """BASELINE.json configs[4] at its real size (6 views 288x512, 40^3 volume, 512 rays x (40+40) samples): one scene through
     the product's HIP twin pairs against the differentiable PyTorch statement (pure autograd incl. the double backward) -- every
     loss term and the gradient of every parameter of the volumetric path and the grasp head; then two scenes batched
-    (forward_scenes, what the trainer and bench.py's train_step run) against the per-scene loop."""
+    (forward_scenes stacked + stacked losses, what the trainer and bench.py's train_step run) against the per-scene loop."""
     from graspnerf_amd.renderer import GraspNeRF
-    from graspnerf_amd.trainer import train_losses
+    from graspnerf_amd.trainer import train_losses, train_losses_stacked
     from graspnerf_amd import losses
     from reference_autograd import use_reference_statement
     cfg = _full_size_cfg()
@@ -451,9 +461,9 @@ def test_full_size_train_step_matches_the_reference_statement():
         net.zero_grad(set_to_none=True)
         torch.manual_seed(9)
         if batched:
-            outs = net.forward_scenes(datas)
-            assert outs is not None
-            sum(losses.total_loss(train_losses(o, d)) for o, d in zip(outs, datas)).backward()
+            st = net.forward_scenes(datas, stacked=True)
+            assert st is not None
+            losses.total_loss(train_losses_stacked(st, datas), scenes=2).backward()
         else:
             for d in datas:
                 losses.total_loss(train_losses(net(d), d)).backward()
