@@ -117,7 +117,22 @@ constexpr int R_GEO2WT = R_WFCT + 256;      // geometry_fc.2 weight transposed: 
 constexpr int R_OUTVJP = R_GEO2WT + 1024;   // w = out_geometry_fc.0^T @ out_geometry_fc.1 [16]: both d sdf / d LayerNorm output
                                             // and the folded forward (two linears without activation, ibrnet.py:410-412)
 constexpr int R_OUTB = R_OUTVJP + 16;       // folded bias: out_fc.1 . out_fc.0.bias + out_fc.1.bias
-constexpr int TOTAL = R_OUTB + 4;
+// C16 section: the copy of the CHAIN section k_chain stages into LDS.  Same offsets (relative to C16) and the same biases /
+// tables, but the A fragments of every layer with >= 4 k-steps are stored as FP16 PAIRS for the f16 matrix cores
+// (v_mfma_f32_16x16x32_f16 / v_mfma_f32_16x16x16_f16 run at 16x the rate of the fp32-input MFMA, which on gfx950 is the
+// vector rate): a weight w is carried as  h = fp16(w), m = fp16((w - h) * 2^11)  (round to nearest: h + m 2^-11 equals w
+// to 1 fp32 ulp, exactly for 3 of 4 values), an activation the same way (split in registers), and  w x  is the sum of
+// the four partial products, each exact in the fp32 accumulator.  Inside a layer's slot (size unchanged: 4 bytes per weight):
+//     [K32 blocks: 8 k-steps each][one K16 block: 4 k-steps][left-over k-steps as fp32 fragments, layout of frag_floats(J', NB)]
+//     K32 block b, output block nb, part p (0 = h, 1 = m): 8 halfs per lane at 16-byte index ((b NB + nb) 2 + p) 64 + lane,
+//     element i <-> the block's k-step i (lane group g holds input slot phi(k0 + i, g), as in the fp32 form);
+//     K16 block likewise with 4 halfs per lane at 8-byte index (nb 2 + p) 64 + lane.
+// Which k-steps form the blocks of which layer: gnr_pack.cpp `c16_plan` and the call sites in k_chain.  The fp32 CHAIN
+// section stays in the blob: k_depth_mean and the backward twins read their forward fragments from it.
+constexpr int C16 = R_OUTB + 4;
+constexpr int TOTAL = C16 + CHAIN_END;
+constexpr int k32_floats(int NB) { return NB * 512; }     // one K32 pair block
+constexpr int k16_floats(int NB) { return NB * 256; }     // one K16 pair block
 }  // namespace pk
 
 // per-point descriptor (k_points_* -> k_chain): 8 floats

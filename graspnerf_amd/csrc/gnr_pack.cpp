@@ -2,6 +2,7 @@
 // blob consumed by the gfx950 kernels.  See gnr_layout.h for the execution model.
 // Parameter shapes/order: ref dist_decoder.py:64-88, aggregate_net.py:29-33, ibrnet.py:382-423.
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <functional>
 #include <vector>
@@ -52,6 +53,122 @@ void pack_bias(float* dst, const float* b, int NB, const IdxFn& psi, double osca
         }
 }
 
+// ---- fp16 pairs (C16 section, gnr_layout.h) ---------------------------------------------------------------------
+inline uint16_t f32_to_f16(float f) {                       // round to nearest even, subnormals kept, overflow -> inf
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, ef = (x >> 23) & 0xffu, mant = x & 0x7fffffu;
+    if (ef == 0xffu) return (uint16_t)(sign | 0x7c00u | (mant ? 0x200u : 0u));
+    const int e = (int)ef - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        const uint32_t m = mant | 0x800000u;
+        const int shift = 14 - e;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)e << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) return std::ldexp((float)m, -24) * (sign ? -1.f : 1.f);
+    if (e == 31) return sign ? -INFINITY : INFINITY;
+    uint32_t x = sign | ((e - 15 + 127) << 23) | (m << 13);
+    float f;
+    std::memcpy(&f, &x, 4);
+    return f;
+}
+
+inline float frag_at(const float* frag, int NB, int j, int nb, int lane) {     // the element pack_frag wrote for (j, nb, lane)
+    if (NB == 1) return frag[((j / 4) * 64 + lane) * 4 + (j % 4)];
+    if (NB == 3) return frag[(j * 64 + lane) * 4 + nb];
+    return frag[(j * 64 + lane) * NB + nb];
+}
+
+// which k-steps of a layer become K32 / K16 pair blocks and which stay fp32 (k_chain's call sites use the same split)
+#ifndef GNR_SPLIT_K16
+#define GNR_SPLIT_K16 0          // 1: 4-k-step remainders as v_mfma_f32_16x16x16_f16 pair blocks instead of fp32 fragments.  OFF: with that
+                                 // instruction in the chain the outputs changed from launch to launch on gfx950 (see gnr_kernels.hip)
+#endif
+struct C16Plan { int off, J, NB; std::vector<int> k32; int k16; std::vector<int> rest; };
+
+// fp32 fragment of one layer -> its C16 form, written over the layer's slot in the C16 copy.  false: a weight is outside the fp16 range.
+bool to_pairs(float* dst, const float* src, const C16Plan& pl) {
+    const int NB = pl.NB;
+    std::vector<float> out(frag_floats(pl.J, NB), 0.f);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
+    bool ok = true;
+    auto put = [&](uint16_t* base, int width, int nb, int lane, int i, float w) {      // base: start of the block (halfs)
+        const uint16_t h = f32_to_f16(w);
+        const float hf = f16_to_f32(h);
+        if (!std::isfinite(hf)) { ok = false; return; }
+        const uint16_t m = f32_to_f16((w - hf) * 2048.f);
+        base[(((size_t)nb * 2 + 0) * 64 + lane) * width + i] = h;
+        base[(((size_t)nb * 2 + 1) * 64 + lane) * width + i] = m;
+    };
+    size_t pos = 0;                                                              // floats
+    for (int k0 : pl.k32) {
+        for (int nb = 0; nb < NB; ++nb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) put(o16 + 2 * pos, 8, nb, lane, i, frag_at(src, NB, k0 + i, nb, lane));
+        pos += pk::k32_floats(NB);
+    }
+    if (pl.k16 >= 0) {
+        for (int nb = 0; nb < NB; ++nb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) put(o16 + 2 * pos, 4, nb, lane, i, frag_at(src, NB, pl.k16 + i, nb, lane));
+        pos += pk::k16_floats(NB);
+    }
+    const int Jr = (int)pl.rest.size();
+    for (int jr = 0; jr < Jr; ++jr)
+        for (int nb = 0; nb < NB; ++nb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const float v = frag_at(src, NB, pl.rest[jr], nb, lane);
+                size_t idx;
+                if (NB == 1) idx = ((jr / 4) * 64 + lane) * 4 + (jr % 4);
+                else if (NB == 3) idx = (jr * 64 + lane) * 4 + nb;
+                else idx = ((size_t)jr * 64 + lane) * NB + nb;
+                out[pos + idx] = v;
+            }
+    if (pos + (Jr ? frag_floats(Jr, NB) : 0) > out.size()) return false;
+    std::memcpy(dst, out.data(), sizeof(float) * out.size());
+    return ok;
+}
+
+std::vector<C16Plan> c16_plan() {
+    using namespace gnr::pk;
+    std::vector<C16Plan> v;
+    for (int br = 0; br < 3; ++br) {
+        v.push_back({DEC1 + br * frag_floats(8, 2), 8, 2, {0}, -1, {}});
+        v.push_back({DEC2 + br * frag_floats(8, 2), 8, 2, {0}, -1, {}});
+    }
+    v.push_back({PE1, 9, 2, {0}, -1, {8}});                  // ray features | (hit, vis)
+#if GNR_SPLIT_K16
+    v.push_back({RDF2, 4, 3, {}, 0, {}});
+    v.push_back({RGB2, 4, 1, {}, 0, {}});
+    v.push_back({HOIST, 36, 4, {0, 8, 16, 24}, 32, {}});
+    v.push_back({GEO1, 23, 4, {0, 8}, 16, {20, 21, 22}});
+#else
+    v.push_back({HOIST, 36, 4, {0, 8, 16, 24}, -1, {32, 33, 34, 35}});
+    v.push_back({GEO1, 23, 4, {0, 8}, -1, {16, 17, 18, 19, 20, 21, 22}});
+#endif
+    v.push_back({NR1, 8, 1, {0}, -1, {}});
+    v.push_back({BASE1, 17, 4, {0, 9}, -1, {8}});            // x[0..7] | e1[0..7] | x[8] (rgb)
+    v.push_back({BASE2, 16, 2, {0, 8}, -1, {}});
+    v.push_back({VIS1, 8, 2, {0}, -1, {}});
+    v.push_back({VIS2, 8, 2, {0}, -1, {}});
+    v.push_back({VISB1, 8, 2, {0}, -1, {}});
+    v.push_back({RGB1, 10, 1, {0}, -1, {8, 9}});
+    v.push_back({GEO2, 16, 1, {0, 8}, -1, {}});
+    return v;                                                // RDF1 (one k-step) stays fp32
+}
+
 // per-lane-group table of one output row over a natural-layout input of J slots: T[g][j]
 void pack_row(float* dst, const float* wrow, int J, double iscale = 1.0) {
     for (int g = 0; g < 4; ++g)
@@ -75,7 +192,7 @@ extern "C" int gnr_layout_offset(const char* name) {
         {"R_WQ", R_WQ}, {"R_WK", R_WK}, {"R_WV", R_WV}, {"R_WFC", R_WFC}, {"R_LNW", R_LNW}, {"R_LNB", R_LNB},
         {"R_OUT0W", R_OUT0W}, {"R_OUT0B", R_OUT0B}, {"R_OUT1W", R_OUT1W}, {"R_OUT1B", R_OUT1B},
         {"R_GEO2W", R_GEO2W}, {"R_GEO1E", R_GEO1E}, {"R_VARIANCE", R_VARIANCE}, {"R_PE", R_PE}, {"R_WQT", R_WQT},
-        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"R_OUTB", R_OUTB}, {"TOTAL", TOTAL}};
+        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"R_OUTB", R_OUTB}, {"C16", C16}, {"TOTAL", TOTAL}};
     for (const E& e : tab)
         if (!std::strcmp(e.n, name)) return e.o;
     return -1;
@@ -362,5 +479,9 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
         for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT1_W + f] * (double)c[can::OUT0_B + f];
         p[pk::R_OUTB] = (float)acc;
     }
+    // --- C16 section: the CHAIN section with the wide layers' fragments as fp16 pairs (what k_chain stages into LDS)
+    std::memcpy(p + pk::C16, p, sizeof(float) * pk::CHAIN_END);
+    for (const C16Plan& pl : c16_plan())
+        if (!to_pairs(p + pk::C16 + pl.off, p + pl.off, pl)) return GNR_ERR_ARG;      // a weight beyond the fp16 range (|w| >= 65520)
     return GNR_OK;
 }

@@ -98,7 +98,11 @@ def _f1_check(co, fi, inds, que, fdn, u, what):
     assert ray_ok.mean() > 0.9, f'{what}: {100 * (1 - ray_ok.mean()):.1f} % of the rays touch the bin-width guard'
     err = np.abs(fd - np.sort(fd_o.numpy(), -1))
     worst = (err.max(1) - tol.max(1))[ray_ok]
-    assert worst.max() <= 0, f'{what}: resampled depth off by {err[ray_ok].max():.3e} (bound exceeded by {worst.max():.3e})'
+    if worst.max() > 0:
+        r = np.flatnonzero(ray_ok)[int(np.argmax(worst))]
+        k = int(np.argmax(err[r] - tol[r].max()))
+        raise AssertionError(f'{what}: resampled depth off by {err[r].max():.3e} on ray {r} (bound {tol[r].max():.3e}, sens max {det["sens"].numpy()[r].max():.3e}, '
+                             f'sample {k}: err {err[r, k]:.3e}, den_raw {np.sort(det["den_raw"].numpy()[r])[:3]}, margins {np.sort(margin[r])[:3]})')
     return det
 
 

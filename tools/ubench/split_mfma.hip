@@ -1,0 +1,269 @@
+// Micro-benchmark for the "f32 operands as fp16 pairs on the f16 matrix cores" idea:
+//  (1) does v_mfma_f32_16x16x32_f16 overlap with VALU work of the partner wave / of the same wave (the fp32-input MFMA does not)?
+//  (2) a chain of 32->32 ELU layers on a 16-point tile, weights in LDS, 2 waves per SIMD:
+//      fp32 MFMA (16 x v_mfma_f32_16x16x4_f32 per layer)  vs  fp16 pairs (h + m*2^-11: 4 products x 2 blocks of 16x16x32 per layer)
+//  (3) numerics: error of the pair product against fp64, and whether MFMA flushes fp16 subnormals.
+// Build: hipcc --offload-arch=gfx950 -O3 -o split_mfma split_mfma.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <math.h>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#define DEV __device__ __forceinline__
+
+DEV float elu_s(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), 1.4426950408889634f, -1.4426950408889634f), 0.f); }
+
+// ---- (1) pair / mix
+__global__ __launch_bounds__(512) void k_pair(float* out, int iters, int mode) {
+    const int wave = threadIdx.x >> 6;
+    float a = threadIdx.x * 1e-3f, b = 1.0001f;
+    if (wave < 4) {
+        if (!(mode & 1)) return;
+        h8 ha, hb;
+        for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(a + i); hb[i] = (_Float16)(b + i); }
+        f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+        for (int i = 0; i < iters; ++i) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c3, 0, 0, 0);
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = c0.x + c1.y + c2.z + c3.w;
+    } else {
+        if (!(mode & 2)) return;
+        float x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3, x4 = a + 4, x5 = a + 5, x6 = a + 6, x7 = a + 7;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a);
+                x4 = fmaf(x4, b, a); x5 = fmaf(x5, b, a); x6 = fmaf(x6, b, a); x7 = fmaf(x7, b, a);
+            }
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    }
+}
+
+template <int K, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_mix(float* out, int iters) {
+    float a = threadIdx.x * 1e-3f, b = 1.0001f;
+    h8 ha, hb;
+    for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(a + i); hb[i] = (_Float16)(b + i); }
+    f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = a + j;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m == 0) c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c0, 0, 0, 0);
+            if (m == 1) c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c1, 0, 0, 0);
+            if (m == 2) c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c2, 0, 0, 0);
+            if (m == 3) c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c3, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < K; ++j) x[j & 7] = fmaf(x[j & 7], b, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = c0.x + c1.y + c2.z + c3.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j];
+    out[blockIdx.x * THREADS + threadIdx.x] = s;
+}
+
+// ---- (2) layer chains.  LDS holds NL layers; fp32: [8 ksteps][64 lanes][2] floats; pairs: [2 nb][2 parts][64 lanes] h8
+constexpr int NL = 16;
+#ifndef PAD
+#define PAD 0
+#endif
+#if PAD == 1
+#define MFMA_PAD() asm volatile("s_nop 7" ::: "memory")
+#elif PAD == 2
+#define MFMA_PAD() asm volatile("s_nop 7\n s_nop 7\n s_nop 7" ::: "memory")
+#else
+#define MFMA_PAD()
+#endif
+template <int MODE>   // 0 fp32 MFMA, 1 fp16 pairs (4 products), 2 fp16 triples of the activations x pairs of the weights (6 products)
+__global__ __launch_bounds__(512) void k_layers(float* out, const float* w, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < NL * 1024; i += 512) lds[i] = w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.01f * (lane + j);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+        for (int l = 0; l < NL; ++l) {
+            asm volatile("" ::: "memory");
+            f4 acc[2] = {{0.1f, 0.2f, 0.3f, 0.4f}, {0.1f, 0.2f, 0.3f, 0.4f}};
+            if constexpr (MODE == 0) {
+                const f2* w2 = reinterpret_cast<const f2*>(lds + l * 1024) + lane;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f2 a = w2[j * 64];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[j], acc[1], 0, 0, 0);
+                }
+            } else {
+                // split the 8 activations: h = f16(x), m = f16((x - h) * 2^11) (, l = f16(((x - h) * 2^11 - m) * 2^11))
+                h8 xh, xm, xl;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const f2 x = {v[j], v[j + 1]};
+                    const h2 h = __builtin_convertvector(x, h2);
+                    const float r0 = (v[j] - (float)h.x) * 2048.f, r1 = (v[j + 1] - (float)h.y) * 2048.f;
+                    const f2 r = {r0, r1};
+                    const h2 m = __builtin_convertvector(r, h2);
+                    xh[j] = h.x; xh[j + 1] = h.y; xm[j] = m.x; xm[j + 1] = m.y;
+                    if constexpr (MODE == 2) {
+                        const f2 r2 = {(r0 - (float)m.x) * 2048.f, (r1 - (float)m.y) * 2048.f};
+                        const h2 q = __builtin_convertvector(r2, h2);
+                        xl[j] = q.x; xl[j + 1] = q.y;
+                    }
+                }
+                const h8* wp = reinterpret_cast<const h8*>(lds + l * 1024) + lane;     // [nb][part][64]
+                f4 lo[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, lo2[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const h8 wh = wp[(nb * 2) * 64], wm = wp[(nb * 2 + 1) * 64];
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[nb], 0, 0, 0); MFMA_PAD();
+                    lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xm, lo[nb], 0, 0, 0); MFMA_PAD();
+                    lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, xh, lo[nb], 0, 0, 0); MFMA_PAD();
+                    lo2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, xm, lo2[nb], 0, 0, 0); MFMA_PAD();
+                    if constexpr (MODE == 2) lo2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, lo2[nb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[nb] += lo[nb] * (1.f / 2048.f) + lo2[nb] * (1.f / (2048.f * 2048.f));
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                v[nb * 4 + 0] = elu_s(acc[nb].x); v[nb * 4 + 1] = elu_s(acc[nb].y);
+                v[nb * 4 + 2] = elu_s(acc[nb].z); v[nb * 4 + 3] = elu_s(acc[nb].w);
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+// ---- (3) numerics: D = W x for one 16x32 by 32x16 product, three ways
+__global__ void k_num(const float* W, const float* X, float* d32, float* dpair, float* dsub) {
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    f4 c = {0, 0, 0, 0};
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(W[r * 32 + 4 * j + g], X[(4 * j + g) * 16 + r], c, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) d32[(4 * g + t) * 16 + r] = c[t];
+    h8 wh, wm, xh, xm;
+    for (int i = 0; i < 8; ++i) {
+        const float w = W[r * 32 + 8 * g + i], x = X[(8 * g + i) * 16 + r];
+        wh[i] = (_Float16)w; wm[i] = (_Float16)((w - (float)wh[i]) * 2048.f);
+        xh[i] = (_Float16)x; xm[i] = (_Float16)((x - (float)xh[i]) * 2048.f);
+    }
+    f4 a = {0, 0, 0, 0}, lo = a, lo2 = a;
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, a, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xm, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, xh, lo, 0, 0, 0);
+    lo2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, xm, lo2, 0, 0, 0);
+    a += lo * (1.f / 2048.f) + lo2 * (1.f / (2048.f * 2048.f));
+    for (int t = 0; t < 4; ++t) dpair[(4 * g + t) * 16 + r] = a[t];
+    // subnormal probe: 2^-20 (fp16 subnormal) * 1.0 summed over K = 32 -> 32 * 2^-20 if subnormals are honoured, 0 if flushed
+    h8 s, one;
+    for (int i = 0; i < 8; ++i) { s[i] = (_Float16)9.5367431640625e-07f; one[i] = (_Float16)1.f; }
+    f4 z = {0, 0, 0, 0};
+    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(s, one, z, 0, 0, 0);
+    if (lane == 0) { dsub[0] = z.x; }
+    z = (f4){0, 0, 0, 0};
+    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(one, s, z, 0, 0, 0);
+    if (lane == 0) { dsub[1] = z.x; }
+}
+
+template <typename F>
+static float timeit(F f) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    f();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) f();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / 5;
+}
+
+int main() {
+    float* out;
+    hipMalloc(&out, 256 * 512 * 4);
+    const int iters = 20000;
+    for (int mode = 1; mode <= 3; ++mode) {
+        float ms = timeit([&] { hipLaunchKernelGGL(k_pair, dim3(256), dim3(512), 0, 0, out, iters, mode); });
+        printf("pair mode %d (1 = f16 MFMA waves only, 2 = VALU waves only, 3 = both on the same SIMDs): %.3f ms\n", mode, ms);
+    }
+#define MIX(K, T) { float ms = timeit([&] { hipLaunchKernelGGL((k_mix<K, T>), dim3(256), dim3(T), 0, 0, out, iters); }); \
+                 printf("mix: %d wave(s)/SIMD, per 16x16x32 f16 MFMA %2d fma: %.3f ms  (%.1f cyc per MFMA slot per wave @2.4GHz)\n", T / 256, K, ms, ms * 2.4e6 / (iters * 4)); }
+    MIX(0, 256) MIX(2, 256) MIX(4, 256) MIX(6, 256) MIX(8, 256)
+    MIX(0, 512) MIX(2, 512) MIX(4, 512) MIX(6, 512) MIX(8, 512) MIX(12, 512)
+    // layers
+    std::vector<float> hw(NL * 1024);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.05f * sinf(0.37f * i);
+    float* dw;
+    hipMalloc(&dw, hw.size() * 4);
+    hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    const int lit = 200;
+    {
+        float ms = timeit([&] { hipLaunchKernelGGL(k_layers<0>, dim3(256), dim3(512), NL * 4096, 0, out, dw, lit); });
+        printf("layer 32->32 + ELU, fp32 MFMA      : %.3f ms  = %.0f cycles per layer per SIMD (2 waves)\n", ms, ms * 2.4e6 / (lit * NL * 2));
+        ms = timeit([&] { hipLaunchKernelGGL(k_layers<1>, dim3(256), dim3(512), NL * 4096, 0, out, dw, lit); });
+        printf("layer 32->32 + ELU, fp16 pairs x4  : %.3f ms  = %.0f cycles per layer per SIMD\n", ms, ms * 2.4e6 / (lit * NL * 2));
+        ms = timeit([&] { hipLaunchKernelGGL(k_layers<2>, dim3(256), dim3(512), NL * 4096, 0, out, dw, lit); });
+        printf("layer 32->32 + ELU, x triples (5)  : %.3f ms  = %.0f cycles per layer per SIMD\n", ms, ms * 2.4e6 / (lit * NL * 2));
+    }
+    // determinism of the layer chains (same inputs, several launches; all 131072 outputs compared bitwise)
+    for (int mode = 0; mode < 2; ++mode) {
+        std::vector<std::vector<float>> runs;
+        for (int rpt = 0; rpt < 4; ++rpt) {
+            if (mode == 0) hipLaunchKernelGGL(k_layers<0>, dim3(256), dim3(512), NL * 4096, 0, out, dw, 3);
+            else hipLaunchKernelGGL(k_layers<1>, dim3(256), dim3(512), NL * 4096, 0, out, dw, 3);
+            std::vector<float> h(256 * 512);
+            hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
+            runs.push_back(h);
+        }
+        int nd = 0; double mx = 0, ref = 0;
+        for (size_t r = 1; r < runs.size(); ++r)
+            for (size_t i = 0; i < runs[0].size(); ++i) { if (runs[r][i] != runs[0][i]) { ++nd; mx = fmax(mx, fabs(runs[r][i] - runs[0][i])); } ref = fmax(ref, fabs(runs[0][i])); }
+        printf("determinism (PAD=%d), %s: %d of %zu outputs differ between launches, max |diff| %.3g (|out| up to %.3g)\n", PAD, mode ? "fp16 pairs" : "fp32 MFMA", nd, 3 * runs[0].size(), mx, ref);
+    }
+    // numerics
+    std::vector<float> W(16 * 32), X(32 * 16);
+    unsigned s = 12345;
+    auto rnd = [&] { s = s * 1664525u + 1013904223u; return ((s >> 8) / 16777216.f) * 2.f - 1.f; };
+    for (auto& v : W) v = rnd() * 0.3f;
+    for (auto& v : X) v = rnd() * 3.f;
+    float *dW, *dX, *d32, *dp, *ds;
+    hipMalloc(&dW, W.size() * 4); hipMalloc(&dX, X.size() * 4); hipMalloc(&d32, 1024); hipMalloc(&dp, 1024); hipMalloc(&ds, 16);
+    hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_num, dim3(1), dim3(64), 0, 0, dW, dX, d32, dp, ds);
+    std::vector<float> r32(256), rp(256);
+    float sub[2];
+    hipMemcpy(r32.data(), d32, 1024, hipMemcpyDeviceToHost);
+    hipMemcpy(rp.data(), dp, 1024, hipMemcpyDeviceToHost);
+    hipMemcpy(sub, ds, 8, hipMemcpyDeviceToHost);
+    double e32 = 0, ep = 0, scale = 0;
+    for (int i = 0; i < 16; ++i)
+        for (int n = 0; n < 16; ++n) {
+            double ref = 0, mag = 0;
+            for (int k = 0; k < 32; ++k) { ref += (double)W[i * 32 + k] * X[k * 16 + n]; mag += fabs((double)W[i * 32 + k] * X[k * 16 + n]); }
+            e32 = fmax(e32, fabs(r32[i * 16 + n] - ref) / mag);
+            ep = fmax(ep, fabs(rp[i * 16 + n] - ref) / mag);
+            scale = fmax(scale, mag);
+        }
+    printf("numerics (max |err| / sum|w x| over a 16x32x16 product): fp32 MFMA %.3g, fp16 pairs %.3g   (2^-24 = %.3g)\n", e32, ep, ldexp(1.0, -24));
+    printf("subnormal probe: A subnormal -> %.6g, B subnormal -> %.6g (expected %.6g if honoured)\n", sub[0], sub[1], 32 * 9.5367431640625e-07);
+    return 0;
+}
