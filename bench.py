@@ -34,7 +34,16 @@ from graspnerf_amd.synth import make_scene, CONFIGS       # noqa: E402
 from graspnerf_amd.sharding import scene_shard, max_over_ranks   # noqa: E402
 
 METRIC = 'scenes/sec TSDF+render fwd, 6-view 40^3 grid'
-PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak = the fp32 vector rate
+PEAK_F16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak (v_mfma_f32_16x16x32_f16)
+# MFMAs k_chain<6,*> issues per 16-point tile (SQ_INSTS_MFMA / tiles in profiles/r02_e_pmc_counters.json agrees):
+# fp16-pair layers = 3 partial products per K32 block, the 1..7-k-step remainders stay v_mfma_f32_16x16x4_f32
+MFMA_PER_TILE = {False: (6 * 99 + 78, 6 * 19 + 44), True: (6 * 102 + 78, 6 * 25 + 44)}      # render? -> (16x16x32 f16, 16x16x4 f32)
+
+
+def executed_mfma_flops(points, render):
+    f16, f32 = MFMA_PER_TILE[render]
+    return (points / 16.0) * (f16 * 2.0 * 16 * 16 * 32 + f32 * 2.0 * 16 * 16 * 4)
 PEAK_HBM_TBPS = 8.0
 # algorithmic (un-hoisted) MACs per (view, point) and per point executed by k_chain
 MAC_VIEW_VOL, MAC_VIEW_RAY, MAC_POINT_CHAIN = 27736, 28464, 6528
@@ -75,6 +84,9 @@ def recorded_pmc(batch):
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
             'mfma_pipe_busy': round(k['SQ_VALU_MFMA_BUSY_CYCLES'] / (k['GRBM_GUI_ACTIVE'] / 8 * 1024), 3),
             'l2_hit_rate': round(k['TCC_HIT_sum'] / (k['TCC_HIT_sum'] + k['TCC_MISS_sum']), 3),
+            # SQ_ACTIVE_INST_VALU counts quad-cycles over all wavefronts: x4 / (cycles x SIMDs) = share of the SIMDs' time a
+            # VALU (non-matrix) instruction is executing
+            'valu_busy': round(4 * k['SQ_ACTIVE_INST_VALU'] / (k['GRBM_GUI_ACTIVE'] / 8 * 1024), 3) if 'SQ_ACTIVE_INST_VALU' in k else None,
             'mfma_per_launch': k['SQ_INSTS_MFMA'], 'valu_incl_mfma_per_launch': k['SQ_INSTS_VALU']}
     except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError, StopIteration):
         return None, None
@@ -465,7 +477,17 @@ def main():
                          'kernel': 'k_chain<6,false> on the volume points', 'ms_per_launch': round(ms, 4),
                          'launches_timed': n_vol, 'ms_per_launch_standalone': round(ms_alone, 4),
                          'flops_per_launch': fl,
-                         'note': 'algorithmic (un-hoisted) fp32 FLOPs: 2*(6*27736+6528) per point, SURVEY.md §8d',
+                         'note': 'achieved = algorithmic (un-hoisted) fp32 FLOPs, 2*(6*27736+6528) per point (SURVEY.md §8d), over the launch '
+                                 'time; peak = the fp32-instruction peak of the part (fp32-input MFMA = fp32 vector rate).  frac > 1 is not '
+                                 'an accounting error: the wide layers run on the f16 matrix cores with every fp32 operand carried as '
+                                 'an fp16 pair (h + m 2^-11, equal to the operand to 1 fp32 ulp) and three exact partial products per MAC '
+                                 '(DESIGN.md §4.2b; error against fp64 below that of the fp32 MFMA chain, profiles/r02_e_split_mfma_ubench.txt).  '
+                                 'What the kernel executes on the matrix pipe is in f16_mfma; what binds it now is VALU issue '
+                                 '(operand splitting, activations, projection / bilinear), see counters',
+                         'f16_mfma': {'executed_tflops': round(executed_mfma_flops(B * res ** 3, False) / (ms * 1e-3) / 1e12, 1),
+                                      'peak': PEAK_F16_MFMA_TFLOPS,
+                                      'frac': round(executed_mfma_flops(B * res ** 3, False) / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                                      'executed_flops_per_launch': executed_mfma_flops(B * res ** 3, False)},
                          'render_launch': {'kernel': 'k_chain<6,true> on the ray points (2 launches per step)', 'ms_per_launch': round(ms_ren, 4),
                                            'achieved': round(fl_ren / (ms_ren * 1e-3) / 1e12, 3),
                                            'frac': round(fl_ren / (ms_ren * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'flops_per_launch': fl_ren}},

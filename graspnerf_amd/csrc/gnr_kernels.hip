@@ -30,12 +30,17 @@ DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4
 // fp32-input MFMA and fp32 VALU share the SIMD's FMA datapath on gfx950 (tools/ubench/mfma_valu.hip:
 // MFMA-only 1.23 ms + VALU-only 0.93 ms = 2.03 ms when issued by partner waves of one SIMD), so every
 // VALU instruction of the chain costs throughput: activations are written for minimum instruction count.
-// ELU(x) = med3(x, e^x - 1, 0): for x > 0 the order is 0 < x <= e^x-1, for x <= 0 it is x <= e^x-1 <= 0.
-DEV float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+// ELU(x) = max(x, min(e^x, 1) - 1): e^x - 1 >= x everywhere, and for x > 0 the clamped exponential gives exactly 0.  The clamp
+// is the output modifier of v_exp_f32, so an activation is v_exp (clamp), v_fma, v_max (v_max issues faster than the
+// v_med3 of the earlier  med3(x, e^x - 1, 0)  form; same values bit for bit).
+DEV float elu1(float x) { return fmaxf(x, __builtin_amdgcn_fmed3f(__expf(x), 0.f, 1.f) - 1.f); }
 // scaled form used inside the MFMA chain: input x' = log2e*x (the packer folds log2e into the producing
 // layer), output log2e*ELU(x) (divided out of the consumer's weights): 3 VALU ops per activation.
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-DEV float elu_s(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), kLog2e, -kLog2e), 0.f); }
+DEV float elu_s(float xs) { return fmaxf(xs, fmaf(__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(xs), 0.f, 1.f), kLog2e, -kLog2e)); }
+// the same activation as med3(x', log2e (2^x' - 1), 0): for inputs that come straight out of an MFMA (fmaxf would first
+// canonicalise them with an extra v_max x, x)
+DEV float elu_m(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), kLog2e, -kLog2e), 0.f); }
 DEV float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV float sigmoid1(float x) { return rcp1(1.f + __expf(-x)); }
 // softplus = max(x,0) + log(1 + e^-|x|)   (== torch's threshold-20 form to fp32 rounding)
@@ -107,14 +112,17 @@ DEV void load_bias(const float* __restrict__ b, int g, f4 (&acc)[NB]) {
     for (int nb = 0; nb < NB; ++nb) acc[nb] = reinterpret_cast<const f4*>(b)[nb * 4 + g];
 }
 
-template <int NB>
+template <int NB, bool FROM_MFMA = true>
 DEV void elu_to(const f4 (&acc)[NB], float (&out)[NB * 4]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        out[nb * 4 + 0] = elu_s(acc[nb].x);
-        out[nb * 4 + 1] = elu_s(acc[nb].y);
-        out[nb * 4 + 2] = elu_s(acc[nb].z);
-        out[nb * 4 + 3] = elu_s(acc[nb].w);
+        if constexpr (FROM_MFMA) {
+            out[nb * 4 + 0] = elu_m(acc[nb].x); out[nb * 4 + 1] = elu_m(acc[nb].y);
+            out[nb * 4 + 2] = elu_m(acc[nb].z); out[nb * 4 + 3] = elu_m(acc[nb].w);
+        } else {
+            out[nb * 4 + 0] = elu_s(acc[nb].x); out[nb * 4 + 1] = elu_s(acc[nb].y);
+            out[nb * 4 + 2] = elu_s(acc[nb].z); out[nb * 4 + 3] = elu_s(acc[nb].w);
+        }
     }
 }
 
@@ -151,7 +159,10 @@ DEV float dot4(const float* __restrict__ T, int g, const float (&h)[4]) {
                                 // compiler's hazard tables (ROCm 7.2) do not cover; without it every launch is bit-identical.
 #endif
 #ifndef GNR_SPLIT_MM
-#define GNR_SPLIT_MM 1          // 0: drop the Wm xm products (<= 2^-22 relative each)
+#define GNR_SPLIT_MM 0          // 1: also the fourth partial product Wm xm 2^-22 (one more MFMA per block and a multiply per output:
+                                // +10 % kernel time).  OFF: it is <= 2^-22 |w x|, 2^-25 on average, and without it the pair form is still
+                                // closer to fp64 than the fp32 MFMA chain (tools/ubench/split_mfma.hip, 51 200 dot products of K = 32:
+                                // max / rms error relative to sum|w x|  fp32 MFMA 2.0e-7 / 2.4e-8, 4 products 9.9e-8 / 1.8e-8, 3 products 1.2e-7 / 2.1e-8)
 #endif
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -163,8 +174,8 @@ constexpr float kPairS = 2048.f, kPairSi = 1.f / 2048.f;
 DEV void split2(float x0, float x1, h2& h, h2& m) {
     const f2 x = {x0, x1};
     h = __builtin_convertvector(x, h2);                                              // v_cvt_pk_f16_f32, round to nearest
-    const float r0 = __builtin_fmaf((float)h.x, -1.f, x0), r1 = __builtin_fmaf((float)h.y, -1.f, x1);   // exact (v_fma_mix_f32)
-    const f2 r = {r0 * kPairS, r1 * kPairS};
+    // (x - h) 2^11, exact: written as an fma on the scaled x so that it selects v_fma_mix_f32 (reads the fp16 half directly)
+    const f2 r = {__builtin_fmaf((float)h.x, -kPairS, x0 * kPairS), __builtin_fmaf((float)h.y, -kPairS, x1 * kPairS)};
     m = __builtin_convertvector(r, h2);
 }
 template <int O, int N>
@@ -606,11 +617,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 load_bias<2, LF>(lds + pk::B_DEC1 + br * 32, g, acc);
                 if constexpr (SP) mm16<1, 2, false, LF>(lds + pk::DEC1 + br * frag_floats(8, 2), lane, &frp, nullptr, acc);
                 else mm<8, 2, 0, LF>(lds + pk::DEC1 + br * frag_floats(8, 2), lane, FR, acc);
-                elu_to<2>(acc, h1);
+                elu_to<2, !SP>(acc, h1);
                 load_bias<2, LF>(lds + pk::B_DEC2 + br * 32, g, acc);
                 if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, false, LF>(lds + pk::DEC2 + br * frag_floats(8, 2), lane, &hp, nullptr, acc); }
                 else mm<8, 2, 0, LF>(lds + pk::DEC2 + br * frag_floats(8, 2), lane, h1, acc);
-                elu_to<2>(acc, h2);
+                elu_to<2, !SP>(acc, h2);
                 if (br < 2) {
                     o5[2 * br] = gsum(dot8(lds + pk::T_DEC3 + (2 * br) * 32, g, h2)) + lds[pk::T_DEC3_B + 2 * br];
                     o5[2 * br + 1] = gsum(dot8(lds + pk::T_DEC3 + (2 * br + 1) * 32, g, h2)) + lds[pk::T_DEC3_B + 2 * br + 1];
@@ -656,11 +667,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 load_bias<1, LF>(lds + pk::B_RDF1, g, acc1);
                 const float ddg[1] = {g == 0 ? vg.dd[0] : (g == 1 ? vg.dd[1] : (g == 2 ? vg.dd[2] : vg.dd[3]))};
                 mm<1, 1, 0, LF>(lds + pk::RDF1, lane, ddg, acc1);
-                elu_to<1>(acc1, d1);
+                elu_to<1, true>(acc1, d1);
                 load_bias<3, LF>(lds + pk::B_RDF2, g, acc3);
                 if constexpr (SP4) { const P4 dp = split4<0>(d1); mm16<0, 3, true, LF>(lds + pk::RDF2, lane, nullptr, &dp, acc3); }
                 else mm<4, 3, 0, LF>(lds + pk::RDF2, lane, d1, acc3);
-                elu_to<3>(acc3, df);
+                elu_to<3, !SP4>(acc3, df);
 #pragma unroll
                 for (int j = 0; j < 9; ++j) Sv[j] = fmaf(df[j], kLn2, XI[j]);
             }
@@ -673,7 +684,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 load_bias<1, LF>(lds + pk::B_NR1, g, acc1);
                 if constexpr (SP) { const P8 ep = split8<0>(e); mm16<1, 1, false, LF>(lds + pk::NR1, lane, &ep, nullptr, acc1); }
                 else mm<8, 1, 0, LF>(lds + pk::NR1, lane, e, acc1);
-                elu_to<1>(acc1, n1);
+                elu_to<1, !SP>(acc1, n1);
                 Sv[17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
             }
             Sv[18] = m;
@@ -795,20 +806,20 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 f4 acc4[4] = {G[0], G[1], G[2], G[3]};
                 float b1[16];
                 if constexpr (SP) {
-                    const P8 xe[2] = {split8<0>(X), split8<0>(E)};
-                    mm16<2, 4, false, LF>(lds + pk::BASE1, lane, xe, nullptr, acc4);
                     const float x8[1] = {X[8]};
                     mm<1, 4, 0, LF>(lds + pk::BASE1 + 2 * pk::k32_floats(4), lane, x8, acc4);
+                    const P8 xe[2] = {split8<0>(X), split8<0>(E)};
+                    mm16<2, 4, false, LF>(lds + pk::BASE1, lane, xe, nullptr, acc4);
                 } else {
                     mm<9, 4, 0, LF>(lds + pk::BASE1, lane, X, acc4);
                     mm<8, 4, 9, LF>(lds + pk::BASE1, lane, E, acc4);
                 }
-                elu_to<4>(acc4, b1);
+                elu_to<4, !SP>(acc4, b1);
                 f4 acc[2];
                 load_bias<2, LF>(lds + pk::B_BASE2, g, acc);
                 if constexpr (SP) { const P8 bp[2] = {split8<0>(b1), split8<8>(b1)}; mm16<2, 2, false, LF>(lds + pk::BASE2, lane, bp, nullptr, acc); }
                 else mm<16, 2, 0, LF>(lds + pk::BASE2, lane, b1, acc);
-                elu_to<2>(acc, Hh);
+                elu_to<2, !SP>(acc, Hh);
             }
             float vis1;
             {
@@ -819,11 +830,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 load_bias<2, LF>(lds + pk::B_VIS1, g, acc);
                 if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, false, LF>(lds + pk::VIS1, lane, &xp, nullptr, acc); }
                 else mm<8, 2, 0, LF>(lds + pk::VIS1, lane, xin, acc);
-                elu_to<2>(acc, v1);
+                elu_to<2, !SP>(acc, v1);
                 load_bias<2, LF>(lds + pk::B_VIS2, g, acc);
                 if constexpr (SP) { const P8 vp8 = split8<0>(v1); mm16<1, 2, false, LF>(lds + pk::VIS2, lane, &vp8, nullptr, acc); }
                 else mm<8, 2, 0, LF>(lds + pk::VIS2, lane, v1, acc);
-                elu_to<2>(acc, res);
+                elu_to<2, !SP>(acc, res);
                 const float logit = elu1(gsum(dot8(lds + pk::T_VIS2R, g, v1)) + lds[pk::T_SCAL + 1]);
                 vis1 = sigmoid1(logit) * m;                                    // ibrnet.py:479
 #pragma unroll
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 load_bias<2, LF>(lds + pk::B_VISB1, g, acc);
                 if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, false, LF>(lds + pk::VISB1, lane, &xp, nullptr, acc); }
                 else mm<8, 2, 0, LF>(lds + pk::VISB1, lane, xin, acc);
-                elu_to<2>(acc, t1);
+                elu_to<2, !SP>(acc, t1);
                 v2 = sigmoid1(gsum(dot8(lds + pk::T_VISB2, g, t1)) + lds[pk::T_SCAL + 2]) * m;   // :481
             }
             vsum += v2;
@@ -850,15 +861,15 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 f4 acc1[1];
                 float c1[4], c2[4];
                 load_bias<1, LF>(lds + pk::B_RGB1, g, acc1);
-                if constexpr (SP) { const P8 hp = split8<0>(Hh); mm16<1, 1, false, LF>(lds + pk::RGB1, lane, &hp, nullptr, acc1); }
-                else mm<8, 1, 0, LF>(lds + pk::RGB1, lane, Hh, acc1);
                 const float ex[2] = {g == 0 ? v2 : (g == 1 ? vg.dd[0] : (g == 2 ? vg.dd[1] : vg.dd[2])), g == 0 ? vg.dd[3] : 0.f};
                 mm<2, 1, 8, LF>(lds + pk::RGB1, lane, ex, acc1);
-                elu_to<1>(acc1, c1);
+                if constexpr (SP) { const P8 hp = split8<0>(Hh); mm16<1, 1, false, LF>(lds + pk::RGB1, lane, &hp, nullptr, acc1); }
+                else mm<8, 1, 0, LF>(lds + pk::RGB1, lane, Hh, acc1);
+                elu_to<1, !SP>(acc1, c1);
                 load_bias<1, LF>(lds + pk::B_RGB2, g, acc1);
                 if constexpr (SP4) { const P4 cp = split4<0>(c1); mm16<0, 1, true, LF>(lds + pk::RGB2, lane, nullptr, &cp, acc1); }
                 else mm<4, 1, 0, LF>(lds + pk::RGB2, lane, c1, acc1);
-                elu_to<1>(acc1, c2);
+                elu_to<1, !SP4>(acc1, c2);
                 clog = gsum(dot4(lds + pk::T_RGB3, g, c2)) + lds[pk::T_SCAL + 3];
                 if (m == 0.f) clog = -1e9f;
             }
@@ -935,18 +946,18 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 const float zr[3] = {Z[20], Z[21], Z[22]};
                 mm<3, 4, 0, LF>(lds + pk::GEO1 + 2 * pk::k32_floats(4) + pk::k16_floats(4), lane, zr, U);
             } else {
-                mm16<2, 4, false, LF>(lds + pk::GEO1, lane, zp, nullptr, U);
                 const float zr[7] = {Z[16], Z[17], Z[18], Z[19], Z[20], Z[21], Z[22]};
                 mm<7, 4, 0, LF>(lds + pk::GEO1 + 2 * pk::k32_floats(4), lane, zr, U);
+                mm16<2, 4, false, LF>(lds + pk::GEO1, lane, zp, nullptr, U);
             }
         } else mm<23, 4, 0, LF>(lds + pk::GEO1, lane, Z, U);
-        elu_to<4>(U, u64);
+        elu_to<4, !SP>(U, u64);
         f4 g16[1];
         load_bias<1, LF>(lds + pk::B_GEO2, g, g16);
         if constexpr (SP) { const P8 up[2] = {split8<0>(u64), split8<8>(u64)}; mm16<2, 1, false, LF>(lds + pk::GEO2, lane, up, nullptr, g16); }
         else mm<16, 1, 0, LF>(lds + pk::GEO2, lane, u64, g16);
         float gg[4];
-        elu_to<1>(g16, gg);
+        elu_to<1, !SP>(g16, gg);
 
         // ================= record
         if (row_ok) {
@@ -1480,10 +1491,10 @@ __global__ __launch_bounds__(256) void k_depth_mean(DepthMeanArgs a) {
     float h1[8], h2[8];
     load_bias<2>(B1, g, acc);
     mm<8, 2>(W1, lane, FR, acc);
-    elu_to<2>(acc, h1);
+    elu_to<2, true>(acc, h1);
     load_bias<2>(B2, g, acc);
     mm<8, 2>(W2, lane, h1, acc);
-    elu_to<2>(acc, h2);
+    elu_to<2, true>(acc, h2);
     const float m0 = softplus1(gsum(dot8(T3, g, h2)) + TB[0]);
     const float m1 = softplus1(gsum(dot8(T3 + 32, g, h2)) + TB[1]);
     if (ok && g == 0) {

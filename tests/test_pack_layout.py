@@ -336,3 +336,120 @@ def test_training_tail_entry_points_validate_arguments():
     assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 0, None) == -2
     assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, None, 10, None) == -1
     assert b'geo_dual_bwd' in L.gnr_last_error()
+
+
+# ---- C16 section: the same layers as fp16 pairs for v_mfma_f32_16x16x32_f16 (gnr_layout.h) --------------------------------
+# ISA lane mapping of the K = 32 instruction: A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15], e = 0..7
+# (8 halfs per lane), D as for the fp32 instruction.  A layer = K32 pair blocks (+ left-over fp32 k-steps).
+def pair_parts(packed, base, NB, block, nb, part):
+    """[64 lanes][8] float64 values of one part (0 = h, 1 = m) of a K32 block."""
+    raw = packed[base + block * NB * 512: base + (block + 1) * NB * 512].view(np.float16).reshape(NB, 2, 64, 8)
+    return raw[nb, part].astype(np.float64)
+
+
+def emulate_pairs(packed, base, NB, blocks_in, acc):
+    """blocks_in[b][e][lane] fp32 activations of K32 block b -> acc[nb][t][lane] += W x with the kernel's arithmetic: operands as
+    fp16 pairs (h = fp16(x), m = fp16((x - h) 2^11)), partial products Wh xh + (Wh xm + Wm xh) 2^-11 (Wm xm dropped: GNR_SPLIT_MM 0)."""
+    out = acc.astype(np.float64).copy()
+    for b, xin in enumerate(blocks_in):                       # xin [8][64]
+        xh = xin.astype(np.float16)
+        xm = ((xin.astype(np.float32) - xh.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+        xh, xm = xh.astype(np.float64), xm.astype(np.float64)
+        for nb in range(NB):
+            wh, wm = pair_parts(packed, base, NB, b, nb, 0), pair_parts(packed, base, NB, b, nb, 1)
+            for l in range(64):
+                col = l & 15
+                for t in range(4):
+                    i = 4 * (l >> 4) + t
+                    s_h = s_l = 0.0
+                    for k in range(4):
+                        la, lb = i + 16 * k, col + 16 * k                  # lanes holding A[i][8k..8k+7] and B[8k..8k+7][col]
+                        s_h += np.dot(wh[la], xh[:, lb])
+                        s_l += np.dot(wh[la], xm[:, lb]) + np.dot(wm[la], xh[:, lb])
+                    out[nb, t, l] += s_h + s_l / 2048.0
+    return out
+
+
+C16_LAYERS = [
+    # name, frag offset (+add), bias, NB, key, K32 blocks as lists of fp32 k-steps, left-over k-steps, phi, psi, iscale, oscale
+    ('dec1_mean', ('DEC1', 0), ('B_DEC1', 0), 2, 'dist_decoder.mean_decoder.0', [list(range(8))], [], lambda j, g: 8 * g + j, lambda nb, i: 16 * nb + i, TRUE, LOG2E),
+    ('dec2_var', ('DEC2', 1024), ('B_DEC2', 32), 2, 'dist_decoder.var_decoder.2', [list(range(8))], [], nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
+    ('pe1', ('PE1', 0), ('B_PE1', 0), 2, 'agg_net.prob_embed.0', [list(range(8))], [8],
+     lambda j, g: 8 * g + j if j < 8 else (32 if g == 0 else (33 if g == 1 else -1)), lambda nb, i: 16 * nb + i, TRUE, 1.0),
+    ('base2', ('BASE2', 0), ('B_BASE2', 0), 2, 'agg_net.agg_impl.base_fc.2', [list(range(8)), list(range(8, 16))], [], nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
+    ('vis2', ('VIS2', 0), ('B_VIS2', 0), 2, None, [list(range(8))], [], nat, lambda nb, i: 16 * nb + i, TILDE, LOG2E),
+    ('rgb1', ('RGB1', 0), ('B_RGB1', 0), 1, 'agg_net.agg_impl.rgb_fc.0', [list(range(8))], [8, 9],
+     lambda j, g: nat(j, g) if j < 8 else ((32 if g == 0 else 32 + g) if j == 8 else (36 if g == 0 else -1)), lambda nb, i: i,
+     lambda i: LOG2E if i < 32 else 1.0, LOG2E),
+    ('geo1', ('GEO1', 0), ('B_GEO1', 0), 4, 'agg_net.agg_impl.geometry_fc.0', [list(range(8)), list(range(8, 16))], list(range(16, 23)),
+     lambda j, g: nat(j, g) if j < 8 else (32 + nat(j - 8, g) if j < 16 else
+                                           ((64 if j == 16 else -1) if g == 0 else 65 + 3 * (j - 16) + (g - 1))),
+     lambda nb, i: 16 * nb + i, lambda i: LOG2E if i < 32 else (LOG2E ** 2 if i < 64 else 1.0), LOG2E),
+    ('geo2', ('GEO2', 0), ('B_GEO2', 0), 1, 'agg_net.agg_impl.geometry_fc.2', [list(range(8)), list(range(8, 16))], [], nat, lambda nb, i: i, TILDE, LOG2E),
+]
+
+
+@pytest.mark.parametrize('spec', C16_LAYERS, ids=[l[0] for l in C16_LAYERS])
+def test_pair_fragments(spec, packed_and_sd):
+    """Every kind of layer of the C16 image (what k_chain stages into LDS): K32 pair blocks + left-over fp32 k-steps, emulated
+    with the kernel's fp16-pair arithmetic, against the dense fp64 layer.  The tolerance is what separates 'pairs' from
+    'one fp16 operand': 3e-7 of sum|w x| (a plain fp16 operand would be off by 5e-4)."""
+    packed, sd = packed_and_sd
+    name, (fname, fadd), (bname, badd), NB, key, blocks, rest, phi, psi, iscale, oscale = spec
+    if key is None:
+        W, b = sd['agg_net.agg_impl.vis_fc.2.weight'][:32], sd['agg_net.agg_impl.vis_fc.2.bias'][:32]
+    else:
+        W, b = sd[key + '.weight'], sd[key + '.bias']
+    c16 = off('C16')
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((16, W.shape[1])).astype(np.float32)
+    xk = (x * np.array([iscale(i) for i in range(W.shape[1])])).astype(np.float32)
+    J = max([k for blk in blocks for k in blk] + rest) + 1
+    Bin = to_B(xk, J, phi)                                                  # [j][lane]
+    base = c16 + off(fname) + fadd
+    acc = bias_acc(packed, c16 + off(bname) + badd, NB)
+    acc = emulate_pairs(packed, base, NB, [Bin[blk] for blk in blocks], acc)
+    if rest:                                                                # left-over k-steps: plain fp32 fragments behind the pair blocks
+        acc = emulate(packed, base + len(blocks) * NB * 512, len(rest), NB, Bin[rest], acc)
+    y = from_D(acc, NB, psi, W.shape[0])
+    ref = oscale * (x.astype(np.float64) @ W.T.astype(np.float64) + b)
+    mag = oscale * (np.abs(x.astype(np.float64)) @ np.abs(W.T.astype(np.float64)) + np.abs(b))
+    assert np.max(np.abs(y - ref) / mag) < 3e-7
+
+
+def test_c16_image_keeps_biases_and_tables(packed_and_sd):
+    packed, _ = packed_and_sd
+    c16, fe, ce = off('C16'), off('FRAG_END'), off('CHAIN_END')
+    assert np.array_equal(packed[c16 + fe: c16 + ce], packed[fe:ce])
+    assert np.array_equal(packed[c16 + off('RDF1'): c16 + off('RDF2')], packed[off('RDF1'): off('RDF2')])     # one k-step: stays fp32
+    assert off('TOTAL') == c16 + ce
+
+
+def test_packer_refuses_weights_beyond_fp16_range(weights_np):
+    big = dict(weights_np)
+    big['agg_net.agg_impl.base_fc.2.weight'] = big['agg_net.agg_impl.base_fc.2.weight'].copy()
+    big['agg_net.agg_impl.base_fc.2.weight'][0, 0] = 7.0e4
+    with pytest.raises(Exception):
+        weights.pack(weights.canonical_blob(big, 'coarse'))
+
+
+def test_base_fc0_split_in_pair_form(packed_and_sd):
+    """C16 image of base_fc.0: HOIST = 4 K32 pair blocks + 4 left-over k-steps; BASE1 = [x slots 0..7 | e1 slots (k-steps 9..16)] as
+    two K32 pair blocks + the rgb slot (k-step 8) as one fp32 k-step -- against the dense layer on [glob, x, prob_embed.2(e1)]."""
+    packed, sd = packed_and_sd
+    W, b = sd['agg_net.agg_impl.base_fc.0.weight'], sd['agg_net.agg_impl.base_fc.0.bias']
+    Wp, bp = sd['agg_net.prob_embed.2.weight'], sd['agg_net.prob_embed.2.bias']
+    c16 = off('C16')
+    z = np.random.default_rng(4).standard_normal((16, 207)).astype(np.float32)
+    B_h = to_B(z, 36, lambda j, g: (35 * (j // 9) + xfeat(j % 9, g)) if xfeat(j % 9, g) >= 0 else -1)
+    G = emulate_pairs(packed, c16 + off('HOIST'), 4, [B_h[8 * k: 8 * k + 8] for k in range(4)], bias_acc(packed, c16 + off('B_HOIST'), 4))
+    G = emulate(packed, c16 + off('HOIST') + 4 * 4 * 512, 4, 4, B_h[32:36], G)
+    B_v = to_B(z, 17, lambda j, g: ((140 + xfeat(j, g)) if xfeat(j, g) >= 0 else -1) if j < 9 else 175 + nat(j - 9, g))
+    acc = emulate(packed, c16 + off('BASE1') + 2 * 4 * 512, 1, 4, B_v[8:9], G)
+    acc = emulate_pairs(packed, c16 + off('BASE1'), 4, [B_v[0:8], B_v[9:17]], acc)
+    y = from_D(acc, 4, lambda nb, i: 16 * nb + i, 64)
+    zt = z.astype(np.float64).copy()
+    zt[:, 175:] = z[:, 175:].astype(np.float64) @ Wp.T.astype(np.float64) + bp
+    ref = LOG2E * (zt @ W.T.astype(np.float64) + b)
+    mag = LOG2E * (np.abs(zt) @ np.abs(W.T.astype(np.float64)) + np.abs(b))
+    assert np.max(np.abs(y - ref) / mag) < 5e-7
