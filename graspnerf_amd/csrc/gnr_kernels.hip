@@ -1024,14 +1024,26 @@ constexpr int FD = 784;          // [64]  unsorted fine depth
 constexpr int END = 848;
 }
 
-// logits of one query against key j for the 4 heads; `ok` false reproduces the reference's
-// query-row mask (whole row = -1e9 -> uniform softmax; ibrnet.py:19-23,492-493)
+// logits of one query against key j for the 4 heads (natural domain; the backward twins' recomputation, gnr_bwd.inc); `ok`
+// false reproduces the reference's query-row mask (whole row = -1e9 -> uniform softmax; ibrnet.py:19-23,492-493)
 DEV void head_logits(const float (&q)[16], const float* __restrict__ Kj, bool ok, float (&s)[4]) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const f4 k = reinterpret_cast<const f4*>(Kj)[h];
         const float d = 0.5f * (q[4 * h] * k.x + q[4 * h + 1] * k.y + q[4 * h + 2] * k.z + q[4 * h + 3] * k.w);
         s[h] = ok ? d : -1e9f;
+    }
+}
+
+// log2-domain logits of one query against key j for the 4 heads.  `q` arrives pre-scaled: qs = (log2e / 2) q, so that
+// s_h = log2e (q_h . k_h) / 2 feeds v_exp_f32 directly, and qs = 0 on rows the reference masks (query-row mask: the whole
+// row = -1e9 -> uniform softmax, ibrnet.py:19-23,492-493, SURVEY H3 -- equal logits of any value give the same softmax,
+// and exp(0) = 1 is what exp(-1e9 - (-1e9)) gave)
+DEV void head_logits_s(const float (&qs)[16], const float* __restrict__ Kj, float (&s)[4]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const f4 k = reinterpret_cast<const f4*>(Kj)[h];
+        s[h] = qs[4 * h] * k.x + qs[4 * h + 1] * k.y + qs[4 * h + 2] * k.z + qs[4 * h + 3] * k.w;
     }
 }
 
@@ -1059,7 +1071,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     float* Vb = sc + dn * 16;                         // [dn][16]
     float* Qb = sc + dn * 32;                         // [dn][16]   (RENDER)
     float* Ob = sc + dn * 48;                         // [dn][16]   dO  (RENDER)
-    float* St = sc + dn * 64;                         // [dn][12]   max[4], +-1/sum[4] (sign of [0] = row ok), rs[4] (RENDER)
+    float* St = sc + dn * 64;                         // [dn][12]   shift[4] (log2 domain), 1/sum[4], rs[4] (RENDER)
     // squared key norms per head: in the dO slots until the VJP needs them (RENDER), else 4 extra floats per sample
     float* KN = RENDER ? Ob : sc + dn * 32;
     constexpr int KNS = RENDER ? 16 : 4;
@@ -1098,6 +1110,10 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         }
         q[f] = sq; kk[f] = sk; vv[f] = sv;
     }
+    // the query as the three sweeps use it (see head_logits): (log2e / 2) q, zero on masked rows
+    float qs[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) qs[f] = rowok ? q[f] * (0.5f * kLog2e) : 0.f;
     if (act) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1107,7 +1123,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             reinterpret_cast<f4*>(Vb + i * 16)[c] = v4;
             KN[i * KNS + c] = k4.x * k4.x + k4.y * k4.y + k4.z * k4.z + k4.w * k4.w;
             if constexpr (RENDER) {
-                const f4 q4 = {q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]};
+                const f4 q4 = {qs[4 * c], qs[4 * c + 1], qs[4 * c + 2], qs[4 * c + 3]};
                 reinterpret_cast<f4*>(Qb + i * 16)[c] = q4;
             }
         }
@@ -1129,28 +1145,28 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const float qn = q[4 * h] * q[4 * h] + q[4 * h + 1] * q[4 * h + 1] + q[4 * h + 2] * q[4 * h + 2] + q[4 * h + 3] * q[4 * h + 3];
-            amax[h] = rowok ? 0.5f * sqrtf(qn * kmax[h]) : -1e9f;
+            amax[h] = rowok ? (0.5f * kLog2e) * sqrtf(qn * kmax[h]) : 0.f;          // log2 domain, like the logits
         }
     }
+    // accumulators of the sweeps are float4 per head: the compiler issues them as v_pk_fma_f32 (two lanes of fp32 per
+    // instruction; no MFMA in this kernel, so the packed form is a gain here)
     float o[16], ainv[4];
     {
         float l[4];
+        f4 o4[4];
         auto sweep = [&]() {
 #pragma unroll
-            for (int h = 0; h < 4; ++h) l[h] = 0.f;
-#pragma unroll
-            for (int f = 0; f < 16; ++f) o[f] = 0.f;
+            for (int h = 0; h < 4; ++h) { l[h] = 0.f; o4[h] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll UA
             for (int j = 0; j < dn; ++j) {
                 float sj[4];
-                head_logits(q, Kb + j * 16, rowok, sj);
+                head_logits_s(qs, Kb + j * 16, sj);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
-                    const float pj = __expf(sj[h] - amax[h]);
+                    const float pj = __builtin_amdgcn_exp2f(sj[h] - amax[h]);
                     l[h] += pj;
-                    o[4 * h] = fmaf(pj, vj.x, o[4 * h]); o[4 * h + 1] = fmaf(pj, vj.y, o[4 * h + 1]);
-                    o[4 * h + 2] = fmaf(pj, vj.z, o[4 * h + 2]); o[4 * h + 3] = fmaf(pj, vj.w, o[4 * h + 3]);
+                    o4[h] += pj * vj;
                 }
             }
         };
@@ -1160,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             for (int h = 0; h < 4; ++h) amax[h] = -3.0e38f;
             for (int j = 0; j < dn; ++j) {
                 float sj[4];
-                head_logits(q, Kb + j * 16, rowok, sj);
+                head_logits_s(qs, Kb + j * 16, sj);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) amax[h] = fmaxf(amax[h], sj[h]);
             }
@@ -1169,7 +1185,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             ainv[h] = 1.f / l[h];
-            o[4 * h] *= ainv[h]; o[4 * h + 1] *= ainv[h]; o[4 * h + 2] *= ainv[h]; o[4 * h + 3] *= ainv[h];
+            o[4 * h] = o4[h].x * ainv[h]; o[4 * h + 1] = o4[h].y * ainv[h]; o[4 * h + 2] = o4[h].z * ainv[h]; o[4 * h + 3] = o4[h].w * ainv[h];
         }
     }
     // ---- fc + residual, LayerNorm(eps 1e-6), out_geometry_fc (two linears), clip   ibrnet.py:97-100,494-495
@@ -1230,30 +1246,31 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         // row pass: rs_h = sum_j P dA ;  dQ = (sum_j P dA k_j - rs sum_j P k_j) / 2
         float dQ[16], rsv[4] = {0.f, 0.f, 0.f, 0.f};
         {
-            float A1[16], B1[16];
+            f4 A1[4], B1[4];
 #pragma unroll
-            for (int f = 0; f < 16; ++f) { A1[f] = 0.f; B1[f] = 0.f; }
+            for (int h = 0; h < 4; ++h) { A1[h] = (f4){0.f, 0.f, 0.f, 0.f}; B1[h] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll UB
             for (int j = 0; j < dn; ++j) {
                 float sj[4];
-                head_logits(q, Kb + j * 16, rowok, sj);
+                head_logits_s(qs, Kb + j * 16, sj);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
                     const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
-                    const float pj = __expf(sj[h] - amax[h]) * ainv[h];
+                    const float pj = __builtin_amdgcn_exp2f(sj[h] - amax[h]) * ainv[h];
                     const float dA = dO[4 * h] * vj.x + dO[4 * h + 1] * vj.y + dO[4 * h + 2] * vj.z + dO[4 * h + 3] * vj.w;
                     const float pd = pj * dA;
                     rsv[h] += pd;
-                    A1[4 * h] = fmaf(pd, kj.x, A1[4 * h]); A1[4 * h + 1] = fmaf(pd, kj.y, A1[4 * h + 1]);
-                    A1[4 * h + 2] = fmaf(pd, kj.z, A1[4 * h + 2]); A1[4 * h + 3] = fmaf(pd, kj.w, A1[4 * h + 3]);
-                    B1[4 * h] = fmaf(pj, kj.x, B1[4 * h]); B1[4 * h + 1] = fmaf(pj, kj.y, B1[4 * h + 1]);
-                    B1[4 * h + 2] = fmaf(pj, kj.z, B1[4 * h + 2]); B1[4 * h + 3] = fmaf(pj, kj.w, B1[4 * h + 3]);
+                    A1[h] += pd * kj;
+                    B1[h] += pj * kj;
                 }
             }
             const float sc2 = rowok ? 0.5f : 0.f;       // masked query rows: d logits = 0
 #pragma unroll
-            for (int f = 0; f < 16; ++f) dQ[f] = (A1[f] - rsv[f >> 2] * B1[f]) * sc2;
+            for (int h = 0; h < 4; ++h) {
+                const f4 d4 = (A1[h] - rsv[h] * B1[h]) * sc2;
+                dQ[4 * h] = d4.x; dQ[4 * h + 1] = d4.y; dQ[4 * h + 2] = d4.z; dQ[4 * h + 3] = d4.w;
+            }
         }
         __syncthreads();                                  // every lane is past the key-norm sweep: the dO slots are free
         if (act) {
@@ -1262,8 +1279,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
                 const f4 d4 = {dO[4 * c], dO[4 * c + 1], dO[4 * c + 2], dO[4 * c + 3]};
                 reinterpret_cast<f4*>(Ob + i * 16)[c] = d4;
             }
-            // 1/sum is positive: its sign carries the row-ok flag of this query row to the column pass
-            const f4 m4 = {amax[0], amax[1], amax[2], amax[3]}, i4 = {rowok ? ainv[0] : -ainv[0], ainv[1], ainv[2], ainv[3]};
+            const f4 m4 = {amax[0], amax[1], amax[2], amax[3]}, i4 = {ainv[0], ainv[1], ainv[2], ainv[3]};
             const f4 r4 = {rsv[0], rsv[1], rsv[2], rsv[3]};
             reinterpret_cast<f4*>(St + i * 12)[0] = m4;
             reinterpret_cast<f4*>(St + i * 12)[1] = i4;
@@ -1271,29 +1287,33 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         }
         __syncthreads();
         // column pass (lane = key j = i): dK_j = sum_i dL_ij q_i / 2 ; dV_j = sum_i P_ij dO_i
+        // Qb holds the pre-scaled queries (log2e / 2) q_i (zero rows where masked): the logit needs no further factor, and
+        // sum_i dL_ij q_i / 2 = ln2 sum_i [P_ij (dA_ij - rs_i)] qs_i ; masked rows contribute nothing to dK (their qs is zero)
         float dK[16], dV[16];
+        {
+            f4 dK4[4], dV4[4];
 #pragma unroll
-        for (int f = 0; f < 16; ++f) { dK[f] = 0.f; dV[f] = 0.f; }
+            for (int h = 0; h < 4; ++h) { dK4[h] = (f4){0.f, 0.f, 0.f, 0.f}; dV4[h] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll UB
-        for (int qi = 0; qi < dn; ++qi) {
-            const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
-            f4 il4 = reinterpret_cast<const f4*>(St + qi * 12)[1];
-            const f4 rs4 = reinterpret_cast<const f4*>(St + qi * 12)[2];
-            const bool ok = il4.x > 0.f;
-            il4.x = fabsf(il4.x);
+            for (int qi = 0; qi < dn; ++qi) {
+                const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
+                const f4 il4 = reinterpret_cast<const f4*>(St + qi * 12)[1];
+                const f4 rs4 = reinterpret_cast<const f4*>(St + qi * 12)[2];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const f4 qv = reinterpret_cast<const f4*>(Qb + qi * 16)[h];
+                    const f4 dov = reinterpret_cast<const f4*>(Ob + qi * 16)[h];
+                    const float s = qv.x * kk[4 * h] + qv.y * kk[4 * h + 1] + qv.z * kk[4 * h + 2] + qv.w * kk[4 * h + 3];
+                    const float pj = __builtin_amdgcn_exp2f(s - mx4[h]) * il4[h];
+                    const float dA = dov.x * vv[4 * h] + dov.y * vv[4 * h + 1] + dov.z * vv[4 * h + 2] + dov.w * vv[4 * h + 3];
+                    dK4[h] += (pj * (dA - rs4[h])) * qv;
+                    dV4[h] += pj * dov;
+                }
+            }
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const f4 qv = reinterpret_cast<const f4*>(Qb + qi * 16)[h];
-                const f4 dov = reinterpret_cast<const f4*>(Ob + qi * 16)[h];
-                float s = 0.5f * (qv.x * kk[4 * h] + qv.y * kk[4 * h + 1] + qv.z * kk[4 * h + 2] + qv.w * kk[4 * h + 3]);
-                s = ok ? s : -1e9f;
-                const float pj = __expf(s - mx4[h]) * il4[h];
-                const float dA = dov.x * vv[4 * h] + dov.y * vv[4 * h + 1] + dov.z * vv[4 * h + 2] + dov.w * vv[4 * h + 3];
-                const float dL = ok ? pj * (dA - rs4[h]) * 0.5f : 0.f;
-                dK[4 * h] = fmaf(dL, qv.x, dK[4 * h]); dK[4 * h + 1] = fmaf(dL, qv.y, dK[4 * h + 1]);
-                dK[4 * h + 2] = fmaf(dL, qv.z, dK[4 * h + 2]); dK[4 * h + 3] = fmaf(dL, qv.w, dK[4 * h + 3]);
-                dV[4 * h] = fmaf(pj, dov.x, dV[4 * h]); dV[4 * h + 1] = fmaf(pj, dov.y, dV[4 * h + 1]);
-                dV[4 * h + 2] = fmaf(pj, dov.z, dV[4 * h + 2]); dV[4 * h + 3] = fmaf(pj, dov.w, dV[4 * h + 3]);
+                dK[4 * h] = dK4[h].x * kLn2; dK[4 * h + 1] = dK4[h].y * kLn2; dK[4 * h + 2] = dK4[h].z * kLn2; dK[4 * h + 3] = dK4[h].w * kLn2;
+                dV[4 * h] = dV4[h].x; dV[4 * h + 1] = dV4[h].y; dV[4 * h + 2] = dV4[h].z; dV[4 * h + 3] = dV4[h].w;
             }
         }
         // dT = dy (residual) + Wq^T dQ + Wk^T dK + Wv^T dV ; dc = dT * ELU'(c) with ELU' = g>0 ? 1 : g+1
