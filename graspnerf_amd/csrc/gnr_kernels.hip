@@ -151,13 +151,6 @@ DEV float dot4(const float* __restrict__ T, int g, const float (&h)[4]) {
 #ifndef GNR_SPLIT16
 #define GNR_SPLIT16 1
 #endif
-#ifndef GNR_SPLIT_K16
-#define GNR_SPLIT_K16 0         // 1: 4-k-step remainders (ray_dir_fc.2, rgb_fc.2, tails of HOIST / GEO1) as v_mfma_f32_16x16x16_f16 pair
-                                // blocks instead of fp32 MFMAs (must match gnr_pack.cpp).  OFF: with the legacy K=16 instruction next to
-                                // the K=32 ones the chain's outputs differed from launch to launch on the same inputs (tools/dbg/chain_det.py:
-                                // 2 000 - 36 000 of 64 000 voxels, 2e-7 ... 2e-5, at one and at two wavefronts per SIMD) -- a dependency the
-                                // compiler's hazard tables (ROCm 7.2) do not cover; without it every launch is bit-identical.
-#endif
 #ifndef GNR_SPLIT_MM
 #define GNR_SPLIT_MM 0          // 1: also the fourth partial product Wm xm 2^-22 (one more MFMA per block and a multiply per output:
                                 // +10 % kernel time).  OFF: it is <= 2^-22 |w x|, 2^-25 on average, and without it the pair form is still
@@ -165,10 +158,8 @@ DEV float dot4(const float* __restrict__ T, int g, const float (&h)[4]) {
                                 // max / rms error relative to sum|w x|  fp32 MFMA 2.0e-7 / 2.4e-8, 4 products 9.9e-8 / 1.8e-8, 3 products 1.2e-7 / 2.1e-8)
 #endif
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 struct P8 { h8 h, m; };
-struct P4 { h4 h, m; };
 constexpr float kPairS = 2048.f, kPairSi = 1.f / 2048.f;
 
 DEV void split2(float x0, float x1, h2& h, h2& m) {
@@ -189,34 +180,40 @@ DEV P8 split8(const float (&v)[N]) {
     p.m = (h8){m[0].x, m[0].y, m[1].x, m[1].y, m[2].x, m[2].y, m[3].x, m[3].y};
     return p;
 }
-template <int O, int N>
-DEV P4 split4(const float (&v)[N]) {
-    static_assert(O + 4 <= N, "split4 reads 4 slots");
-    h2 h[2], m[2];
+// CNT < 8 slots starting at O, the rest of the block zero (pairs of zeros cost nothing)
+template <int O, int CNT, int N>
+DEV P8 split8z(const float (&v)[N]) {
+    static_assert(O + CNT <= N && CNT >= 1 && CNT < 8, "split8z reads CNT slots");
+    h2 h[4], m[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) split2(v[O + 2 * q], v[O + 2 * q + 1], h[q], m[q]);
-    P4 p;
-    p.h = (h4){h[0].x, h[0].y, h[1].x, h[1].y};
-    p.m = (h4){m[0].x, m[0].y, m[1].x, m[1].y};
+    for (int q = 0; q < 4; ++q) {
+        if (2 * q + 1 < CNT) split2(v[O + 2 * q], v[O + 2 * q + 1], h[q], m[q]);
+        else if (2 * q < CNT) split2(v[O + 2 * q], 0.f, h[q], m[q]);
+        else { h[q] = (h2){(_Float16)0.f, (_Float16)0.f}; m[q] = h[q]; }
+    }
+    P8 p;
+    p.h = (h8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+    p.m = (h8){m[0].x, m[0].y, m[1].x, m[1].y, m[2].x, m[2].y, m[3].x, m[3].y};
     return p;
 }
 DEV f4 mfma32h(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-DEV f4 mfma16h(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 
-// acc[nb] += W x over KB K32 blocks (inputs x8[0..KB)) and, if K16, one K16 block (input x4), NB output blocks.
-// w: the layer's slot in the C16 image.  The left-over fp32 k-steps of a layer are added by the caller with mm<>.
-template <int KB, int NB, bool K16, bool LF>
-DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, const P4* __restrict__ x4, f4 (&acc)[NB]) {
+// acc[nb] += W x over KB K32 blocks (inputs x8[0..KB)), NB output blocks.  w: the layer's slot in the C16 image.  The
+// left-over fp32 k-steps of a layer are added by the caller with mm<>.
+// Only the K = 32 instruction: with the legacy v_mfma_f32_16x16x16_f16 (tried for the 4-k-step tails) next to it the chain's
+// outputs differed from launch to launch on the same inputs (tools/dbg/chain_det.py: 2 000 - 36 000 of 64 000 voxels by
+// 2e-7 ... 2e-5, at one and at two wavefronts per SIMD) -- a dependency the compiler's hazard tables (ROCm 7.2) do not
+// cover; tails are zero-padded into a K32 block instead.
+template <int KB, int NB, bool LF>
+DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, f4 (&acc)[NB]) {
     if constexpr (LF) asm volatile("" ::: "memory");
     const h8* w8 = reinterpret_cast<const h8*>(w) + lane;
-    const h4* w4 = reinterpret_cast<const h4*>(w + KB * pk::k32_floats(NB)) + lane;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         f4 lo = {0.f, 0.f, 0.f, 0.f};
 #if GNR_SPLIT_MM
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) lo = mfma32h(w8[((kb * NB + nb) * 2 + 1) * 64], x8[kb].m, lo);
-        if constexpr (K16) lo = mfma16h(w4[(nb * 2 + 1) * 64], x4->m, lo);
         lo *= kPairSi;
 #endif
 #pragma unroll
@@ -225,12 +222,6 @@ DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, 
             lo = mfma32h(wh, x8[kb].m, lo);
             lo = mfma32h(wm, x8[kb].h, lo);
             acc[nb] = mfma32h(wh, x8[kb].h, acc[nb]);
-        }
-        if constexpr (K16) {
-            const h4 wh = w4[(nb * 2) * 64], wm = w4[(nb * 2 + 1) * 64];
-            lo = mfma16h(wh, x4->m, lo);
-            lo = mfma16h(wm, x4->h, lo);
-            acc[nb] = mfma16h(wh, x4->h, acc[nb]);
         }
         acc[nb].x = fmaf(lo.x, kPairSi, acc[nb].x); acc[nb].y = fmaf(lo.y, kPairSi, acc[nb].y);
         acc[nb].z = fmaf(lo.z, kPairSi, acc[nb].z); acc[nb].w = fmaf(lo.w, kPairSi, acc[nb].w);
@@ -487,12 +478,13 @@ template <int V, bool RENDER, bool SAVE = false>
 __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
-    constexpr bool SP = GNR_SPLIT16 != 0, SP4 = SP && GNR_SPLIT_K16 != 0;                    // fp16-pair layers on the f16 matrix cores (C16 image) / fp32 MFMA (CHAIN image)
+    constexpr bool SP = GNR_SPLIT16 != 0;
+#define LO(o) (SP ? pk::c16_off(o) : (o))                  /* offset of a CHAIN-section name inside the staged image */                    // fp16-pair layers on the f16 matrix cores (C16 image) / fp32 MFMA (CHAIN image)
     // ---- stage the C16 (or CHAIN) section of the packed weights into LDS (once per workgroup)
     {
         const f4* src = reinterpret_cast<const f4*>(a.wpk + (SP ? pk::C16 : 0));
         f4* dst = reinterpret_cast<f4*>(lds);
-        for (int i = threadIdx.x; i < pk::CHAIN_END / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (SP ? pk::C16_END : pk::CHAIN_END) / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -614,19 +606,19 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             for (int br = 0; br < 3; ++br) {
                 f4 acc[2];
                 float h1[8], h2[8];
-                load_bias<2, LF>(lds + pk::B_DEC1 + br * 32, g, acc);
-                if constexpr (SP) mm16<1, 2, false, LF>(lds + pk::DEC1 + br * frag_floats(8, 2), lane, &frp, nullptr, acc);
-                else mm<8, 2, 0, LF>(lds + pk::DEC1 + br * frag_floats(8, 2), lane, FR, acc);
+                load_bias<2, LF>(lds + LO(pk::B_DEC1) + br * 32, g, acc);
+                if constexpr (SP) mm16<1, 2, LF>(lds + LO(pk::DEC1) + br * frag_floats(8, 2), lane, &frp, acc);
+                else mm<8, 2, 0, LF>(lds + LO(pk::DEC1) + br * frag_floats(8, 2), lane, FR, acc);
                 elu_to<2, !SP>(acc, h1);
-                load_bias<2, LF>(lds + pk::B_DEC2 + br * 32, g, acc);
-                if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, false, LF>(lds + pk::DEC2 + br * frag_floats(8, 2), lane, &hp, nullptr, acc); }
-                else mm<8, 2, 0, LF>(lds + pk::DEC2 + br * frag_floats(8, 2), lane, h1, acc);
+                load_bias<2, LF>(lds + LO(pk::B_DEC2) + br * 32, g, acc);
+                if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, &hp, acc); }
+                else mm<8, 2, 0, LF>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, h1, acc);
                 elu_to<2, !SP>(acc, h2);
                 if (br < 2) {
-                    o5[2 * br] = gsum(dot8(lds + pk::T_DEC3 + (2 * br) * 32, g, h2)) + lds[pk::T_DEC3_B + 2 * br];
-                    o5[2 * br + 1] = gsum(dot8(lds + pk::T_DEC3 + (2 * br + 1) * 32, g, h2)) + lds[pk::T_DEC3_B + 2 * br + 1];
+                    o5[2 * br] = gsum(dot8(lds + LO(pk::T_DEC3) + (2 * br) * 32, g, h2)) + lds[LO(pk::T_DEC3_B) + 2 * br];
+                    o5[2 * br + 1] = gsum(dot8(lds + LO(pk::T_DEC3) + (2 * br + 1) * 32, g, h2)) + lds[LO(pk::T_DEC3_B) + 2 * br + 1];
                 } else {
-                    o5[4] = gsum(dot8(lds + pk::T_DEC3 + 4 * 32, g, h2)) + lds[pk::T_DEC3_B + 4];
+                    o5[4] = gsum(dot8(lds + LO(pk::T_DEC3) + 4 * 32, g, h2)) + lds[LO(pk::T_DEC3_B) + 4];
                 }
             }
             float hit, vis;
@@ -646,11 +638,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             {
                 f4 acc[2];
                 float e1[8];
-                load_bias<2, LF>(lds + pk::B_PE1, g, acc);
-                if constexpr (SP) mm16<1, 2, false, LF>(lds + pk::PE1, lane, &frp, nullptr, acc);
-                else mm<8, 2, 0, LF>(lds + pk::PE1, lane, FR, acc);
+                load_bias<2, LF>(lds + LO(pk::B_PE1), g, acc);
+                if constexpr (SP) mm16<1, 2, LF>(lds + LO(pk::PE1), lane, &frp, acc);
+                else mm<8, 2, 0, LF>(lds + LO(pk::PE1), lane, FR, acc);
                 const float extra[1] = {g == 0 ? (hit - 0.5f) * 2.f : (g == 1 ? (vis - 0.5f) * 2.f : 0.f)};
-                mm<1, 2, 8, LF>(lds + pk::PE1, lane, extra, acc);
+                mm<1, 2, 8, LF>(lds + LO(pk::PE1), lane, extra, acc);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     e1[nb * 4 + 0] = fmaxf(acc[nb].x, 0.f); e1[nb * 4 + 1] = fmaxf(acc[nb].y, 0.f);
@@ -664,14 +656,15 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             {
                 f4 acc1[1], acc3[3];
                 float d1[4], df[12];
-                load_bias<1, LF>(lds + pk::B_RDF1, g, acc1);
+                load_bias<1, LF>(lds + LO(pk::B_RDF1), g, acc1);
                 const float ddg[1] = {g == 0 ? vg.dd[0] : (g == 1 ? vg.dd[1] : (g == 2 ? vg.dd[2] : vg.dd[3]))};
-                mm<1, 1, 0, LF>(lds + pk::RDF1, lane, ddg, acc1);
+                mm<1, 1, 0, LF>(lds + LO(pk::RDF1), lane, ddg, acc1);
                 elu_to<1, true>(acc1, d1);
-                load_bias<3, LF>(lds + pk::B_RDF2, g, acc3);
-                if constexpr (SP4) { const P4 dp = split4<0>(d1); mm16<0, 3, true, LF>(lds + pk::RDF2, lane, nullptr, &dp, acc3); }
-                else mm<4, 3, 0, LF>(lds + pk::RDF2, lane, d1, acc3);
-                elu_to<3, !SP4>(acc3, df);
+                load_bias<3, LF>(lds + LO(pk::B_RDF2), g, acc3);
+                // 4 k-steps: stays on the fp32 MFMA (zero-padded into a K32 pair block: 3.68 vs 3.71 ms alone, but 3.80 together
+                // with the padded tails of HOIST / GEO1, which gain more: 3.63)
+                mm<4, 3, 0, LF>(lds + LO(pk::RDF2), lane, d1, acc3);
+                elu_to<3, true>(acc3, df);
 #pragma unroll
                 for (int j = 0; j < 9; ++j) Sv[j] = fmaf(df[j], kLn2, XI[j]);
             }
@@ -681,11 +674,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 float e[8], n1[4];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) e[j] = Sv[9 + j];
-                load_bias<1, LF>(lds + pk::B_NR1, g, acc1);
-                if constexpr (SP) { const P8 ep = split8<0>(e); mm16<1, 1, false, LF>(lds + pk::NR1, lane, &ep, nullptr, acc1); }
-                else mm<8, 1, 0, LF>(lds + pk::NR1, lane, e, acc1);
+                load_bias<1, LF>(lds + LO(pk::B_NR1), g, acc1);
+                if constexpr (SP) { const P8 ep = split8<0>(e); mm16<1, 1, LF>(lds + LO(pk::NR1), lane, &ep, acc1); }
+                else mm<8, 1, 0, LF>(lds + LO(pk::NR1), lane, e, acc1);
                 elu_to<1, !SP>(acc1, n1);
-                Sv[17] = sigmoid1(gsum(dot4(lds + pk::T_NR2, g, n1)) + lds[pk::T_SCAL + 0]);
+                Sv[17] = sigmoid1(gsum(dot4(lds + LO(pk::T_NR2), g, n1)) + lds[LO(pk::T_SCAL) + 0]);
             }
             Sv[18] = m;
             if (SAVE && a.save1) {
@@ -726,18 +719,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         }
         // view-invariant 140 columns of base_fc.0, once per point (+ bias)
         f4 G[4];
-        load_bias<4, LF>(lds + pk::B_HOIST, g, G);
+        load_bias<4, LF>(lds + LO(pk::B_HOIST), g, G);
         if constexpr (SP) {
-            const P8 sp[4] = {split8<0>(SV), split8<8>(SV), split8<16>(SV), split8<24>(SV)};
-            if constexpr (SP4) {
-                const P4 sq = split4<32>(SV);
-                mm16<4, 4, true, LF>(lds + pk::HOIST, lane, sp, &sq, G);
-            } else {
-                mm16<4, 4, false, LF>(lds + pk::HOIST, lane, sp, nullptr, G);
-                const float sr[4] = {SV[32], SV[33], SV[34], SV[35]};
-                mm<4, 4, 0, LF>(lds + pk::HOIST + 4 * pk::k32_floats(4), lane, sr, G);
-            }
-        } else mm<36, 4, 0, LF>(lds + pk::HOIST, lane, SV, G);
+            const P8 sp[5] = {split8<0>(SV), split8<8>(SV), split8<16>(SV), split8<24>(SV), split8z<32, 4>(SV)};
+            mm16<5, 4, LF>(lds + LO(pk::HOIST), lane, sp, G);
+        } else mm<36, 4, 0, LF>(lds + LO(pk::HOIST), lane, SV, G);
         if (SAVE && a.saveG) {
             float* sp = a.saveG + ((size_t)b * tps + ts) * 17 * 64 + lane;
 #pragma unroll
@@ -807,18 +793,18 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 float b1[16];
                 if constexpr (SP) {
                     const float x8[1] = {X[8]};
-                    mm<1, 4, 0, LF>(lds + pk::BASE1 + 2 * pk::k32_floats(4), lane, x8, acc4);
+                    mm<1, 4, 0, LF>(lds + LO(pk::BASE1) + 2 * pk::k32_floats(4), lane, x8, acc4);
                     const P8 xe[2] = {split8<0>(X), split8<0>(E)};
-                    mm16<2, 4, false, LF>(lds + pk::BASE1, lane, xe, nullptr, acc4);
+                    mm16<2, 4, LF>(lds + LO(pk::BASE1), lane, xe, acc4);
                 } else {
-                    mm<9, 4, 0, LF>(lds + pk::BASE1, lane, X, acc4);
-                    mm<8, 4, 9, LF>(lds + pk::BASE1, lane, E, acc4);
+                    mm<9, 4, 0, LF>(lds + LO(pk::BASE1), lane, X, acc4);
+                    mm<8, 4, 9, LF>(lds + LO(pk::BASE1), lane, E, acc4);
                 }
                 elu_to<4, !SP>(acc4, b1);
                 f4 acc[2];
-                load_bias<2, LF>(lds + pk::B_BASE2, g, acc);
-                if constexpr (SP) { const P8 bp[2] = {split8<0>(b1), split8<8>(b1)}; mm16<2, 2, false, LF>(lds + pk::BASE2, lane, bp, nullptr, acc); }
-                else mm<16, 2, 0, LF>(lds + pk::BASE2, lane, b1, acc);
+                load_bias<2, LF>(lds + LO(pk::B_BASE2), g, acc);
+                if constexpr (SP) { const P8 bp[2] = {split8<0>(b1), split8<8>(b1)}; mm16<2, 2, LF>(lds + LO(pk::BASE2), lane, bp, acc); }
+                else mm<16, 2, 0, LF>(lds + LO(pk::BASE2), lane, b1, acc);
                 elu_to<2, !SP>(acc, Hh);
             }
             float vis1;
@@ -827,15 +813,15 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 float xin[8], v1[8], res[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * w;
-                load_bias<2, LF>(lds + pk::B_VIS1, g, acc);
-                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, false, LF>(lds + pk::VIS1, lane, &xp, nullptr, acc); }
-                else mm<8, 2, 0, LF>(lds + pk::VIS1, lane, xin, acc);
+                load_bias<2, LF>(lds + LO(pk::B_VIS1), g, acc);
+                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF>(lds + LO(pk::VIS1), lane, &xp, acc); }
+                else mm<8, 2, 0, LF>(lds + LO(pk::VIS1), lane, xin, acc);
                 elu_to<2, !SP>(acc, v1);
-                load_bias<2, LF>(lds + pk::B_VIS2, g, acc);
-                if constexpr (SP) { const P8 vp8 = split8<0>(v1); mm16<1, 2, false, LF>(lds + pk::VIS2, lane, &vp8, nullptr, acc); }
-                else mm<8, 2, 0, LF>(lds + pk::VIS2, lane, v1, acc);
+                load_bias<2, LF>(lds + LO(pk::B_VIS2), g, acc);
+                if constexpr (SP) { const P8 vp8 = split8<0>(v1); mm16<1, 2, LF>(lds + LO(pk::VIS2), lane, &vp8, acc); }
+                else mm<8, 2, 0, LF>(lds + LO(pk::VIS2), lane, v1, acc);
                 elu_to<2, !SP>(acc, res);
-                const float logit = elu1(gsum(dot8(lds + pk::T_VIS2R, g, v1)) + lds[pk::T_SCAL + 1]);
+                const float logit = elu1(gsum(dot8(lds + LO(pk::T_VIS2R), g, v1)) + lds[LO(pk::T_SCAL) + 1]);
                 vis1 = sigmoid1(logit) * m;                                    // ibrnet.py:479
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Hh[j] += res[j];                    // :480
@@ -846,11 +832,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 float xin[8], t1[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * vis1;
-                load_bias<2, LF>(lds + pk::B_VISB1, g, acc);
-                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, false, LF>(lds + pk::VISB1, lane, &xp, nullptr, acc); }
-                else mm<8, 2, 0, LF>(lds + pk::VISB1, lane, xin, acc);
+                load_bias<2, LF>(lds + LO(pk::B_VISB1), g, acc);
+                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF>(lds + LO(pk::VISB1), lane, &xp, acc); }
+                else mm<8, 2, 0, LF>(lds + LO(pk::VISB1), lane, xin, acc);
                 elu_to<2, !SP>(acc, t1);
-                v2 = sigmoid1(gsum(dot8(lds + pk::T_VISB2, g, t1)) + lds[pk::T_SCAL + 2]) * m;   // :481
+                v2 = sigmoid1(gsum(dot8(lds + LO(pk::T_VISB2), g, t1)) + lds[LO(pk::T_SCAL) + 2]) * m;   // :481
             }
             vsum += v2;
             float clog = 0.f;
@@ -860,17 +846,16 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 project_view<true>(vp, p, qd, a.H, a.W, vg);
                 f4 acc1[1];
                 float c1[4], c2[4];
-                load_bias<1, LF>(lds + pk::B_RGB1, g, acc1);
+                load_bias<1, LF>(lds + LO(pk::B_RGB1), g, acc1);
                 const float ex[2] = {g == 0 ? v2 : (g == 1 ? vg.dd[0] : (g == 2 ? vg.dd[1] : vg.dd[2])), g == 0 ? vg.dd[3] : 0.f};
-                mm<2, 1, 8, LF>(lds + pk::RGB1, lane, ex, acc1);
-                if constexpr (SP) { const P8 hp = split8<0>(Hh); mm16<1, 1, false, LF>(lds + pk::RGB1, lane, &hp, nullptr, acc1); }
-                else mm<8, 1, 0, LF>(lds + pk::RGB1, lane, Hh, acc1);
+                mm<2, 1, 8, LF>(lds + LO(pk::RGB1), lane, ex, acc1);
+                if constexpr (SP) { const P8 hp = split8<0>(Hh); mm16<1, 1, LF>(lds + LO(pk::RGB1), lane, &hp, acc1); }
+                else mm<8, 1, 0, LF>(lds + LO(pk::RGB1), lane, Hh, acc1);
                 elu_to<1, !SP>(acc1, c1);
-                load_bias<1, LF>(lds + pk::B_RGB2, g, acc1);
-                if constexpr (SP4) { const P4 cp = split4<0>(c1); mm16<0, 1, true, LF>(lds + pk::RGB2, lane, nullptr, &cp, acc1); }
-                else mm<4, 1, 0, LF>(lds + pk::RGB2, lane, c1, acc1);
-                elu_to<1, !SP4>(acc1, c2);
-                clog = gsum(dot4(lds + pk::T_RGB3, g, c2)) + lds[pk::T_SCAL + 3];
+                load_bias<1, LF>(lds + LO(pk::B_RGB2), g, acc1);
+                mm<4, 1, 0, LF>(lds + LO(pk::RGB2), lane, c1, acc1);               // 4 k-steps, one output block: stays on the fp32 MFMA
+                elu_to<1, true>(acc1, c2);
+                clog = gsum(dot4(lds + LO(pk::T_RGB3), g, c2)) + lds[LO(pk::T_SCAL) + 3];
                 if (m == 0.f) clog = -1e9f;
             }
 #pragma unroll
@@ -937,25 +922,16 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         }
         f4 U[4];
         float u64[16];
-        load_bias<4, LF>(lds + pk::B_GEO1, g, U);
+        load_bias<4, LF>(lds + LO(pk::B_GEO1), g, U);
         if constexpr (SP) {
-            const P8 zp[2] = {split8<0>(Z), split8<8>(Z)};
-            if constexpr (SP4) {
-                const P4 zq = split4<16>(Z);
-                mm16<2, 4, true, LF>(lds + pk::GEO1, lane, zp, &zq, U);
-                const float zr[3] = {Z[20], Z[21], Z[22]};
-                mm<3, 4, 0, LF>(lds + pk::GEO1 + 2 * pk::k32_floats(4) + pk::k16_floats(4), lane, zr, U);
-            } else {
-                const float zr[7] = {Z[16], Z[17], Z[18], Z[19], Z[20], Z[21], Z[22]};
-                mm<7, 4, 0, LF>(lds + pk::GEO1 + 2 * pk::k32_floats(4), lane, zr, U);
-                mm16<2, 4, false, LF>(lds + pk::GEO1, lane, zp, nullptr, U);
-            }
-        } else mm<23, 4, 0, LF>(lds + pk::GEO1, lane, Z, U);
+            const P8 zp[3] = {split8<0>(Z), split8<8>(Z), split8z<16, 7>(Z)};
+            mm16<3, 4, LF>(lds + LO(pk::GEO1), lane, zp, U);
+        } else mm<23, 4, 0, LF>(lds + LO(pk::GEO1), lane, Z, U);
         elu_to<4, !SP>(U, u64);
         f4 g16[1];
-        load_bias<1, LF>(lds + pk::B_GEO2, g, g16);
-        if constexpr (SP) { const P8 up[2] = {split8<0>(u64), split8<8>(u64)}; mm16<2, 1, false, LF>(lds + pk::GEO2, lane, up, nullptr, g16); }
-        else mm<16, 1, 0, LF>(lds + pk::GEO2, lane, u64, g16);
+        load_bias<1, LF>(lds + LO(pk::B_GEO2), g, g16);
+        if constexpr (SP) { const P8 up[2] = {split8<0>(u64), split8<8>(u64)}; mm16<2, 1, LF>(lds + LO(pk::GEO2), lane, up, g16); }
+        else mm<16, 1, 0, LF>(lds + LO(pk::GEO2), lane, u64, g16);
         float gg[4];
         elu_to<1, !SP>(g16, gg);
 
@@ -982,6 +958,8 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         }
     }
 }
+
+#undef LO
 
 // ---------------------------------------------------------------------------------------
 // k_ray: one lane per sample of a ray / voxel column.  A 256-thread workgroup packs floor(256/slots) rays

@@ -117,22 +117,29 @@ constexpr int R_GEO2WT = R_WFCT + 256;      // geometry_fc.2 weight transposed: 
 constexpr int R_OUTVJP = R_GEO2WT + 1024;   // w = out_geometry_fc.0^T @ out_geometry_fc.1 [16]: both d sdf / d LayerNorm output
                                             // and the folded forward (two linears without activation, ibrnet.py:410-412)
 constexpr int R_OUTB = R_OUTVJP + 16;       // folded bias: out_fc.1 . out_fc.0.bias + out_fc.1.bias
-// C16 section: the copy of the CHAIN section k_chain stages into LDS.  Same offsets (relative to C16) and the same biases /
-// tables, but the A fragments of every layer with >= 4 k-steps are stored as FP16 PAIRS for the f16 matrix cores
-// (v_mfma_f32_16x16x32_f16 / v_mfma_f32_16x16x16_f16 run at 16x the rate of the fp32-input MFMA, which on gfx950 is the
-// vector rate): a weight w is carried as  h = fp16(w), m = fp16((w - h) * 2^11)  (round to nearest: h + m 2^-11 equals w
-// to 1 fp32 ulp, exactly for 3 of 4 values), an activation the same way (split in registers), and  w x  is the sum of
-// the four partial products, each exact in the fp32 accumulator.  Inside a layer's slot (size unchanged: 4 bytes per weight):
-//     [K32 blocks: 8 k-steps each][one K16 block: 4 k-steps][left-over k-steps as fp32 fragments, layout of frag_floats(J', NB)]
+// C16 section: the image k_chain stages into LDS.  The CHAIN section's slots in the same order with the same biases / tables,
+// but the A fragments of every layer with >= 4 k-steps are stored as FP16 PAIRS for the f16 matrix cores
+// (v_mfma_f32_16x16x32_f16 runs at 16x the rate of the fp32-input MFMA, which on gfx950 is the vector rate): a weight w is
+// carried as  h = fp16(w), m = fp16((w - h) * 2^11)  (round to nearest: h + m 2^-11 equals w to 1 fp32 ulp, exactly for 3 of
+// 4 values), an activation the same way (split in registers), and  w x  is the sum of the partial products, each exact in
+// the fp32 accumulator.  Inside a layer's slot:
+//     [K32 blocks: up to 8 k-steps each, missing ones zero][left-over k-steps as fp32 fragments, layout of frag_floats(J', NB)]
 //     K32 block b, output block nb, part p (0 = h, 1 = m): 8 halfs per lane at 16-byte index ((b NB + nb) 2 + p) 64 + lane,
-//     element i <-> the block's k-step i (lane group g holds input slot phi(k0 + i, g), as in the fp32 form);
-//     K16 block likewise with 4 halfs per lane at 8-byte index (nb 2 + p) 64 + lane.
+//     element i <-> the block's i-th k-step (lane group g holds input slot phi(k_i, g), as in the fp32 form).
+// A full block takes exactly the room of its 8 fp32 k-steps (4 bytes per weight), so most slots keep their size; the
+// two per-point layers whose 4- / 7-k-step tails are zero-padded into a block of their own grow (c16_off shifts what
+// follows).  ray_dir_fc.2 (4 k-steps, per view) stays fp32: padded as well it costs more than it saves (measured).
 // Which k-steps form the blocks of which layer: gnr_pack.cpp `c16_plan` and the call sites in k_chain.  The fp32 CHAIN
 // section stays in the blob: k_depth_mean and the backward twins read their forward fragments from it.
-constexpr int C16 = R_OUTB + 4;
-constexpr int TOTAL = C16 + CHAIN_END;
 constexpr int k32_floats(int NB) { return NB * 512; }     // one K32 pair block
-constexpr int k16_floats(int NB) { return NB * 256; }     // one K16 pair block
+constexpr int C16_GROW_HOIST = 5 * k32_floats(4) - frag_floats(36, 4);      // 36 k-steps -> 4 blocks + a padded one
+constexpr int C16_GROW_GEO1 = 3 * k32_floats(4) - frag_floats(23, 4);       // 23 k-steps -> 2 blocks + a padded one
+// offset inside the C16 image of what sits at offset `o` of the CHAIN section
+constexpr int c16_off(int o) { return o + (o > HOIST ? C16_GROW_HOIST : 0) + (o > GEO1 ? C16_GROW_GEO1 : 0); }
+constexpr int C16 = R_OUTB + 4;
+constexpr int C16_END = c16_off(CHAIN_END);
+static_assert(C16_END % 4 == 0 && C16_END * 4 <= 160 * 1024, "the C16 image must fit the 160 KiB LDS");
+constexpr int TOTAL = C16 + C16_END;
 }  // namespace pk
 
 // per-point descriptor (k_points_* -> k_chain): 8 floats

@@ -92,40 +92,31 @@ inline float frag_at(const float* frag, int NB, int j, int nb, int lane) {     /
 }
 
 // which k-steps of a layer become K32 / K16 pair blocks and which stay fp32 (k_chain's call sites use the same split)
-#ifndef GNR_SPLIT_K16
-#define GNR_SPLIT_K16 0          // 1: 4-k-step remainders as v_mfma_f32_16x16x16_f16 pair blocks instead of fp32 fragments.  OFF: with that
-                                 // instruction in the chain the outputs changed from launch to launch on gfx950 (see gnr_kernels.hip)
-#endif
-struct C16Plan { int off, J, NB; std::vector<int> k32; int k16; std::vector<int> rest; };
+// which k-steps of a layer become K32 pair blocks (lists of <= 8 k-steps; a short list is zero-padded) and which stay fp32
+// fragments (k_chain's call sites use the same split)
+struct C16Plan { int off, J, NB; std::vector<std::vector<int>> k32; std::vector<int> rest; };
 
-// fp32 fragment of one layer -> its C16 form, written over the layer's slot in the C16 copy.  false: a weight is outside the fp16 range.
+// fp32 fragment of one layer (src) -> its C16 form at dst.  false: a weight is outside the fp16 range.
 bool to_pairs(float* dst, const float* src, const C16Plan& pl) {
-    const int NB = pl.NB;
-    std::vector<float> out(frag_floats(pl.J, NB), 0.f);
+    const int NB = pl.NB, Jr = (int)pl.rest.size();
+    std::vector<float> out(pl.k32.size() * pk::k32_floats(NB) + (Jr ? frag_floats(Jr, NB) : 0), 0.f);
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
     bool ok = true;
-    auto put = [&](uint16_t* base, int width, int nb, int lane, int i, float w) {      // base: start of the block (halfs)
-        const uint16_t h = f32_to_f16(w);
-        const float hf = f16_to_f32(h);
-        if (!std::isfinite(hf)) { ok = false; return; }
-        const uint16_t m = f32_to_f16((w - hf) * 2048.f);
-        base[(((size_t)nb * 2 + 0) * 64 + lane) * width + i] = h;
-        base[(((size_t)nb * 2 + 1) * 64 + lane) * width + i] = m;
-    };
     size_t pos = 0;                                                              // floats
-    for (int k0 : pl.k32) {
+    for (const std::vector<int>& ks : pl.k32) {
         for (int nb = 0; nb < NB; ++nb)
             for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 8; ++i) put(o16 + 2 * pos, 8, nb, lane, i, frag_at(src, NB, k0 + i, nb, lane));
+                for (int i = 0; i < (int)ks.size(); ++i) {
+                    const float w = frag_at(src, NB, ks[i], nb, lane);
+                    const uint16_t h = f32_to_f16(w);
+                    const float hf = f16_to_f32(h);
+                    if (!std::isfinite(hf)) { ok = false; continue; }
+                    uint16_t* base = o16 + 2 * pos;
+                    base[(((size_t)nb * 2 + 0) * 64 + lane) * 8 + i] = h;
+                    base[(((size_t)nb * 2 + 1) * 64 + lane) * 8 + i] = f32_to_f16((w - hf) * 2048.f);
+                }
         pos += pk::k32_floats(NB);
     }
-    if (pl.k16 >= 0) {
-        for (int nb = 0; nb < NB; ++nb)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 4; ++i) put(o16 + 2 * pos, 4, nb, lane, i, frag_at(src, NB, pl.k16 + i, nb, lane));
-        pos += pk::k16_floats(NB);
-    }
-    const int Jr = (int)pl.rest.size();
     for (int jr = 0; jr < Jr; ++jr)
         for (int nb = 0; nb < NB; ++nb)
             for (int lane = 0; lane < 64; ++lane) {
@@ -136,37 +127,31 @@ bool to_pairs(float* dst, const float* src, const C16Plan& pl) {
                 else idx = ((size_t)jr * 64 + lane) * NB + nb;
                 out[pos + idx] = v;
             }
-    if (pos + (Jr ? frag_floats(Jr, NB) : 0) > out.size()) return false;
     std::memcpy(dst, out.data(), sizeof(float) * out.size());
     return ok;
 }
+
+std::vector<int> ksteps(int k0, int n) { std::vector<int> v(n); for (int i = 0; i < n; ++i) v[i] = k0 + i; return v; }
 
 std::vector<C16Plan> c16_plan() {
     using namespace gnr::pk;
     std::vector<C16Plan> v;
     for (int br = 0; br < 3; ++br) {
-        v.push_back({DEC1 + br * frag_floats(8, 2), 8, 2, {0}, -1, {}});
-        v.push_back({DEC2 + br * frag_floats(8, 2), 8, 2, {0}, -1, {}});
+        v.push_back({DEC1 + br * frag_floats(8, 2), 8, 2, {ksteps(0, 8)}, {}});
+        v.push_back({DEC2 + br * frag_floats(8, 2), 8, 2, {ksteps(0, 8)}, {}});
     }
-    v.push_back({PE1, 9, 2, {0}, -1, {8}});                  // ray features | (hit, vis)
-#if GNR_SPLIT_K16
-    v.push_back({RDF2, 4, 3, {}, 0, {}});
-    v.push_back({RGB2, 4, 1, {}, 0, {}});
-    v.push_back({HOIST, 36, 4, {0, 8, 16, 24}, 32, {}});
-    v.push_back({GEO1, 23, 4, {0, 8}, 16, {20, 21, 22}});
-#else
-    v.push_back({HOIST, 36, 4, {0, 8, 16, 24}, -1, {32, 33, 34, 35}});
-    v.push_back({GEO1, 23, 4, {0, 8}, -1, {16, 17, 18, 19, 20, 21, 22}});
-#endif
-    v.push_back({NR1, 8, 1, {0}, -1, {}});
-    v.push_back({BASE1, 17, 4, {0, 9}, -1, {8}});            // x[0..7] | e1[0..7] | x[8] (rgb)
-    v.push_back({BASE2, 16, 2, {0, 8}, -1, {}});
-    v.push_back({VIS1, 8, 2, {0}, -1, {}});
-    v.push_back({VIS2, 8, 2, {0}, -1, {}});
-    v.push_back({VISB1, 8, 2, {0}, -1, {}});
-    v.push_back({RGB1, 10, 1, {0}, -1, {8, 9}});
-    v.push_back({GEO2, 16, 1, {0, 8}, -1, {}});
-    return v;                                                // RDF1 (one k-step) stays fp32
+    v.push_back({PE1, 9, 2, {ksteps(0, 8)}, {8}});                               // ray features | (hit, vis)
+    v.push_back({NR1, 8, 1, {ksteps(0, 8)}, {}});
+    v.push_back({BASE1, 17, 4, {ksteps(0, 8), ksteps(9, 8)}, {8}});              // x[0..7] | e1[0..7] | x[8] (rgb)
+    v.push_back({BASE2, 16, 2, {ksteps(0, 8), ksteps(8, 8)}, {}});
+    v.push_back({VIS1, 8, 2, {ksteps(0, 8)}, {}});
+    v.push_back({VIS2, 8, 2, {ksteps(0, 8)}, {}});
+    v.push_back({VISB1, 8, 2, {ksteps(0, 8)}, {}});
+    v.push_back({RGB1, 10, 1, {ksteps(0, 8)}, {8, 9}});
+    v.push_back({HOIST, 36, 4, {ksteps(0, 8), ksteps(8, 8), ksteps(16, 8), ksteps(24, 8), ksteps(32, 4)}, {}});      // 4-k-step tail zero-padded
+    v.push_back({GEO1, 23, 4, {ksteps(0, 8), ksteps(8, 8), ksteps(16, 7)}, {}});                                     // 7-k-step tail zero-padded
+    v.push_back({GEO2, 16, 1, {ksteps(0, 8), ksteps(8, 8)}, {}});
+    return v;                                                // RDF1 (one k-step), RDF2 and RGB2 (4 k-steps) stay fp32
 }
 
 // per-lane-group table of one output row over a natural-layout input of J slots: T[g][j]
@@ -192,7 +177,12 @@ extern "C" int gnr_layout_offset(const char* name) {
         {"R_WQ", R_WQ}, {"R_WK", R_WK}, {"R_WV", R_WV}, {"R_WFC", R_WFC}, {"R_LNW", R_LNW}, {"R_LNB", R_LNB},
         {"R_OUT0W", R_OUT0W}, {"R_OUT0B", R_OUT0B}, {"R_OUT1W", R_OUT1W}, {"R_OUT1B", R_OUT1B},
         {"R_GEO2W", R_GEO2W}, {"R_GEO1E", R_GEO1E}, {"R_VARIANCE", R_VARIANCE}, {"R_PE", R_PE}, {"R_WQT", R_WQT},
-        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"R_OUTB", R_OUTB}, {"C16", C16}, {"TOTAL", TOTAL}};
+        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"R_OUTB", R_OUTB}, {"C16", C16}, {"C16_END", C16_END}, {"TOTAL", TOTAL}};
+    if (!std::strncmp(name, "C16.", 4)) {                     // where a CHAIN-section name sits in the blob's C16 image
+        for (const E& e : tab)
+            if (!std::strcmp(e.n, name + 4) && e.o <= CHAIN_END) return C16 + c16_off(e.o);
+        return -1;
+    }
     for (const E& e : tab)
         if (!std::strcmp(e.n, name)) return e.o;
     return -1;
@@ -479,9 +469,15 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
         for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT1_W + f] * (double)c[can::OUT0_B + f];
         p[pk::R_OUTB] = (float)acc;
     }
-    // --- C16 section: the CHAIN section with the wide layers' fragments as fp16 pairs (what k_chain stages into LDS)
-    std::memcpy(p + pk::C16, p, sizeof(float) * pk::CHAIN_END);
+    // --- C16 section: the CHAIN section's slots (three of them grown, gnr_layout.h c16_off) with the wide layers' fragments as
+    //     fp16 pairs: what k_chain stages into LDS
+    std::memset(p + pk::C16, 0, sizeof(float) * pk::C16_END);
+    {
+        const int cuts[4] = {0, pk::GEO1, pk::GEO2, pk::CHAIN_END};               // the slot behind each grown layer starts a new run
+        for (int r = 0; r < 3; ++r)
+            std::memcpy(p + pk::C16 + pk::c16_off(cuts[r]), p + cuts[r], sizeof(float) * (cuts[r + 1] - cuts[r]));
+    }
     for (const C16Plan& pl : c16_plan())
-        if (!to_pairs(p + pk::C16 + pl.off, p + pl.off, pl)) return GNR_ERR_ARG;      // a weight beyond the fp16 range (|w| >= 65520)
+        if (!to_pairs(p + pk::C16 + pk::c16_off(pl.off), p + pl.off, pl)) return GNR_ERR_ARG;      // a weight beyond the fp16 range (|w| >= 65520)
     return GNR_OK;
 }

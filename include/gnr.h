@@ -93,6 +93,9 @@ typedef struct GnrRenderOut {
  * (ref: dist_decoder.py:64-88, aggregate_net.py:29-33, ibrnet.py:382-423, neus.py:9)      */
 int gnr_canonical_weights_floats(void);   /* 36958 */
 int gnr_packed_weights_floats(void);
+/* Host-side packer: MFMA fragments of every layer (fp32), the tables of the per-ray kernel, and the image the chain kernel
+ * stages into LDS, in which the wide layers' weights are stored as fp16 pairs w = h + m 2^-11 (1 fp32 ulp; csrc/gnr_layout.h
+ * section C16).  GNR_ERR_ARG if a pointer is null or an effective weight is outside the fp16 range (|w| >= 65520). */
 int gnr_pack_weights(const float* canonical_host, float* packed_host);
 /* float offset of a named section of the packed blob (see csrc/gnr_layout.h), -1 if unknown */
 int gnr_layout_offset(const char* name);

@@ -381,7 +381,7 @@ C16_LAYERS = [
     ('rgb1', ('RGB1', 0), ('B_RGB1', 0), 1, 'agg_net.agg_impl.rgb_fc.0', [list(range(8))], [8, 9],
      lambda j, g: nat(j, g) if j < 8 else ((32 if g == 0 else 32 + g) if j == 8 else (36 if g == 0 else -1)), lambda nb, i: i,
      lambda i: LOG2E if i < 32 else 1.0, LOG2E),
-    ('geo1', ('GEO1', 0), ('B_GEO1', 0), 4, 'agg_net.agg_impl.geometry_fc.0', [list(range(8)), list(range(8, 16))], list(range(16, 23)),
+    ('geo1', ('GEO1', 0), ('B_GEO1', 0), 4, 'agg_net.agg_impl.geometry_fc.0', [list(range(8)), list(range(8, 16)), list(range(16, 23))], [],
      lambda j, g: nat(j, g) if j < 8 else (32 + nat(j - 8, g) if j < 16 else
                                            ((64 if j == 16 else -1) if g == 0 else 65 + 3 * (j - 16) + (g - 1))),
      lambda nb, i: 16 * nb + i, lambda i: LOG2E if i < 32 else (LOG2E ** 2 if i < 64 else 1.0), LOG2E),
@@ -400,15 +400,15 @@ def test_pair_fragments(spec, packed_and_sd):
         W, b = sd['agg_net.agg_impl.vis_fc.2.weight'][:32], sd['agg_net.agg_impl.vis_fc.2.bias'][:32]
     else:
         W, b = sd[key + '.weight'], sd[key + '.bias']
-    c16 = off('C16')
     rng = np.random.default_rng(11)
     x = rng.standard_normal((16, W.shape[1])).astype(np.float32)
     xk = (x * np.array([iscale(i) for i in range(W.shape[1])])).astype(np.float32)
     J = max([k for blk in blocks for k in blk] + rest) + 1
     Bin = to_B(xk, J, phi)                                                  # [j][lane]
-    base = c16 + off(fname) + fadd
-    acc = bias_acc(packed, c16 + off(bname) + badd, NB)
-    acc = emulate_pairs(packed, base, NB, [Bin[blk] for blk in blocks], acc)
+    base = off('C16.' + fname) + fadd
+    acc = bias_acc(packed, off('C16.' + bname) + badd, NB)
+    pad = lambda rows: np.concatenate([rows, np.zeros((8 - len(rows), 64), rows.dtype)]) if len(rows) < 8 else rows    # short block: zero k-steps
+    acc = emulate_pairs(packed, base, NB, [pad(Bin[blk]) for blk in blocks], acc)
     if rest:                                                                # left-over k-steps: plain fp32 fragments behind the pair blocks
         acc = emulate(packed, base + len(blocks) * NB * 512, len(rest), NB, Bin[rest], acc)
     y = from_D(acc, NB, psi, W.shape[0])
@@ -419,10 +419,15 @@ def test_pair_fragments(spec, packed_and_sd):
 
 def test_c16_image_keeps_biases_and_tables(packed_and_sd):
     packed, _ = packed_and_sd
-    c16, fe, ce = off('C16'), off('FRAG_END'), off('CHAIN_END')
-    assert np.array_equal(packed[c16 + fe: c16 + ce], packed[fe:ce])
-    assert np.array_equal(packed[c16 + off('RDF1'): c16 + off('RDF2')], packed[off('RDF1'): off('RDF2')])     # one k-step: stays fp32
-    assert off('TOTAL') == c16 + ce
+    fe, ce = off('FRAG_END'), off('CHAIN_END')
+    assert np.array_equal(packed[off('C16.FRAG_END'): off('C16.CHAIN_END')], packed[fe:ce])
+    assert np.array_equal(packed[off('C16.RDF1'): off('C16.NR1')], packed[off('RDF1'): off('NR1')])       # ray_dir_fc: stays fp32
+    assert np.array_equal(packed[off('C16.RGB2'): off('C16.HOIST')], packed[off('RGB2'): off('HOIST')])   # 4 k-steps x 1 block: stays fp32
+    # two slots grow by their zero-padded tail blocks; the image ends the blob and fits the LDS
+    assert off('C16.GEO1') - off('C16.HOIST') == 5 * 4 * 512
+    assert off('C16.GEO2') - off('C16.GEO1') == 3 * 4 * 512
+    assert off('TOTAL') == off('C16') + off('C16_END') and off('C16.CHAIN_END') == off('C16') + off('C16_END')
+    assert off('C16_END') * 4 <= 160 * 1024
 
 
 def test_packer_refuses_weights_beyond_fp16_range(weights_np):
@@ -434,19 +439,18 @@ def test_packer_refuses_weights_beyond_fp16_range(weights_np):
 
 
 def test_base_fc0_split_in_pair_form(packed_and_sd):
-    """C16 image of base_fc.0: HOIST = 4 K32 pair blocks + 4 left-over k-steps; BASE1 = [x slots 0..7 | e1 slots (k-steps 9..16)] as
+    """C16 image of base_fc.0: HOIST = 4 K32 pair blocks + its 4-k-step tail zero-padded into a fifth; BASE1 = [x slots 0..7 | e1 slots (k-steps 9..16)] as
     two K32 pair blocks + the rgb slot (k-step 8) as one fp32 k-step -- against the dense layer on [glob, x, prob_embed.2(e1)]."""
     packed, sd = packed_and_sd
     W, b = sd['agg_net.agg_impl.base_fc.0.weight'], sd['agg_net.agg_impl.base_fc.0.bias']
     Wp, bp = sd['agg_net.prob_embed.2.weight'], sd['agg_net.prob_embed.2.bias']
-    c16 = off('C16')
     z = np.random.default_rng(4).standard_normal((16, 207)).astype(np.float32)
     B_h = to_B(z, 36, lambda j, g: (35 * (j // 9) + xfeat(j % 9, g)) if xfeat(j % 9, g) >= 0 else -1)
-    G = emulate_pairs(packed, c16 + off('HOIST'), 4, [B_h[8 * k: 8 * k + 8] for k in range(4)], bias_acc(packed, c16 + off('B_HOIST'), 4))
-    G = emulate(packed, c16 + off('HOIST') + 4 * 4 * 512, 4, 4, B_h[32:36], G)
+    tail = np.concatenate([B_h[32:36], np.zeros((4, 64), np.float32)])
+    G = emulate_pairs(packed, off('C16.HOIST'), 4, [B_h[8 * k: 8 * k + 8] for k in range(4)] + [tail], bias_acc(packed, off('C16.B_HOIST'), 4))
     B_v = to_B(z, 17, lambda j, g: ((140 + xfeat(j, g)) if xfeat(j, g) >= 0 else -1) if j < 9 else 175 + nat(j - 9, g))
-    acc = emulate(packed, c16 + off('BASE1') + 2 * 4 * 512, 1, 4, B_v[8:9], G)
-    acc = emulate_pairs(packed, c16 + off('BASE1'), 4, [B_v[0:8], B_v[9:17]], acc)
+    acc = emulate(packed, off('C16.BASE1') + 2 * 4 * 512, 1, 4, B_v[8:9], G)
+    acc = emulate_pairs(packed, off('C16.BASE1'), 4, [B_v[0:8], B_v[9:17]], acc)
     y = from_D(acc, 4, lambda nb, i: 16 * nb + i, 64)
     zt = z.astype(np.float64).copy()
     zt[:, 175:] = z[:, 175:].astype(np.float64) @ Wp.T.astype(np.float64) + bp
