@@ -36,9 +36,10 @@ from graspnerf_amd.sharding import scene_shard, max_over_ranks   # noqa: E402
 METRIC = 'scenes/sec TSDF+render fwd, 6-view 40^3 grid'
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak = the fp32 vector rate
 PEAK_F16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak (v_mfma_f32_16x16x32_f16)
-# MFMAs k_chain<6,*> issues per 16-point tile (SQ_INSTS_MFMA / tiles in profiles/r02_e_pmc_counters.json agrees):
-# fp16-pair layers = 3 partial products per K32 block, the 1..7-k-step remainders stay v_mfma_f32_16x16x4_f32
-MFMA_PER_TILE = {False: (6 * 99 + 78, 6 * 19 + 44), True: (6 * 102 + 78, 6 * 25 + 44)}      # render? -> (16x16x32 f16, 16x16x4 f32)
+# MFMAs k_chain<6,*> issues per 16-point tile (SQ_INSTS_MFMA / tiles in profiles/r02_f_pmc_counters.json agrees):
+# fp16-pair layers = 3 partial products per K32 block (per view 33 blocks, 34 with rgb_fc.0; per point 34: HOIST 5x4, GEO1 3x4,
+# GEO2 2), the 1..4-k-step remainders of the per-view layers stay v_mfma_f32_16x16x4_f32 (19 per view, 25 with rgb_fc)
+MFMA_PER_TILE = {False: (6 * 99 + 102, 6 * 19), True: (6 * 102 + 102, 6 * 25)}      # render? -> (16x16x32 f16, 16x16x4 f32)
 
 
 def executed_mfma_flops(points, render):
@@ -481,7 +482,7 @@ def main():
                                  'time; peak = the fp32-instruction peak of the part (fp32-input MFMA = fp32 vector rate).  frac > 1 is not '
                                  'an accounting error: the wide layers run on the f16 matrix cores with every fp32 operand carried as '
                                  'an fp16 pair (h + m 2^-11, equal to the operand to 1 fp32 ulp) and three exact partial products per MAC '
-                                 '(DESIGN.md §4.2b; error against fp64 below that of the fp32 MFMA chain, profiles/r02_e_split_mfma_ubench.txt).  '
+                                 '(DESIGN.md §4.1b; error against fp64 below that of the fp32 MFMA chain, profiles/r02_f_split_mfma_ubench.txt).  '
                                  'What the kernel executes on the matrix pipe is in f16_mfma; what binds it now is VALU issue '
                                  '(operand splitting, activations, projection / bilinear), see counters',
                          'f16_mfma': {'executed_tflops': round(executed_mfma_flops(B * res ** 3, False) / (ms * 1e-3) / 1e12, 1),

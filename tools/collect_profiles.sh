@@ -26,7 +26,10 @@ python tools/prof_summary.py $DB "$TAG: rocprofv3 --kernel-trace --stats -- pyth
 DB=$(find gpurun_out/$TAG/trace_train -name "*.db" | head -1)
 python tools/prof_summary.py $DB "$TAG: rocprofv3 --kernel-trace --stats -- python tools/train_step_bench.py --steps 3 --warmup 3 (8 scenes per step, 1x MI355X); kernels that started in the last 330 ms of the trace = the steady-state steps" --last-ms 330 > gpurun_out/$TAG/train_step_kernel_stats.txt
 python tools/pmc_summary.py gpurun_out/$TAG/pmc gpurun_out/$TAG/pmc_counters.json > gpurun_out/$TAG/pmc_summary.log
+# the counters the bench line replays must be the ones just collected: put them where bench.py looks (profiles/, newest by name)
+cp gpurun_out/$TAG/pmc_counters.json profiles/${TAG}_pmc_counters.json
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
+[ -x tools/ubench/split_mfma ] && timeout 60 tools/ubench/split_mfma > gpurun_out/$TAG/split_mfma_ubench.txt 2>&1
 head -14 gpurun_out/$TAG/bench_kernel_stats.txt
 head -30 gpurun_out/$TAG/train_step_kernel_stats.txt | cut -c1-130
 tail -1 gpurun_out/$TAG/bench.json | cut -c1-300
