@@ -327,6 +327,23 @@ class NeuralRayRenderer(nn.Module):
             bufs[name] = torch.empty(n, dtype=torch.float32, pin_memory=True)
         return bufs[name]
 
+    def _upload(self, name, host_tensor, dev):
+        """Host tensor -> device through a persistent pinned staging buffer (one per name): `x.pin_memory()` every step
+        goes through the caching host allocator, whose occasional fresh hipHostMalloc showed up as 30-60 ms outlier steps
+        (1 in 20).  The buffer is rewritten only after the previous copy out of it has completed."""
+        bufs = self.__dict__.setdefault('_stage_bufs', {})
+        ent = bufs.get(name)
+        if ent is None or ent[0].shape != host_tensor.shape or ent[0].dtype != host_tensor.dtype:
+            ent = [torch.empty(host_tensor.shape, dtype=host_tensor.dtype, pin_memory=True), None]
+            bufs[name] = ent
+        if ent[1] is not None:
+            ent[1].synchronize()
+        ent[0].copy_(host_tensor)
+        out = ent[0].to(dev, non_blocking=True)
+        ent[1] = torch.cuda.Event()
+        ent[1].record()
+        return out
+
     def repack_begin(self):
         """First half of the per-step weight re-pack, to be called BEFORE the 2D backbones are queued: the canonical blobs of
         both levels are gathered on the device and start their way to pinned host memory (stream-ordered, nothing waits).
@@ -500,7 +517,7 @@ class NeuralRayRenderer(nn.Module):
             for net in (self.agg_net, self.fine_agg_net):
                 net.train_step_bookkeeping()
         dev = ref['imgs'].device
-        fine_u = torch.cat(us, 1).pin_memory().to(dev, non_blocking=True)
+        fine_u = self._upload('fine_u1', torch.cat(us, 1), dev)
         bq = {'coords': que['coords'], 'pose': que['poses'], 'K': que['Ks'], 'depth_range': que['depth_range']}
         if 'imgs' in que:
             bq['imgs'] = que['imgs']
@@ -660,10 +677,10 @@ class NeuralRayRenderer(nn.Module):
                 net.train_step_bookkeeping()
             if want_depth:
                 coords.append(self.gen_depth_loss_coords(h, w, dev, keep_on_host=True))
-        upload = lambda x: x if x.is_cuda else x.pin_memory().to(dev, non_blocking=True)
-        fine_u = upload(torch.cat(us))
+        fine_u = self._upload('fine_u', torch.cat(us), dev)
         if want_depth:
-            coords = upload(torch.stack(coords))                            # [B,8192,2]
+            coords = torch.stack(coords)                                    # [B,8192,2]
+            coords = coords if coords.is_cuda else self._upload('depth_coords', coords, dev)
         stack = lambda k, src: torch.stack([torch.as_tensor(x[k], dtype=torch.float32, device=dev) for x in src])
         bref = {'imgs': imgs.reshape(B, V, 3, h, w), 'img_feats': img_feats.detach(), 'ray_feats': ray_feats.detach(),
                 'poses': stack('poses', refs), 'Ks': stack('Ks', refs), 'depth_range': stack('depth_range', refs),
