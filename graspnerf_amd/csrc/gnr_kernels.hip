@@ -6,8 +6,9 @@
 //   k_points_volume  per voxel centre descriptor, column order, top->down  (renderer.py:167-170)
 //   k_coarse_depth / k_points_rays   ray samples (render_ops.py:4-52,146-170)
 //   k_chain<V,RENDER> THE hot kernel: per-(point,view) projection + gather + mixture decoder +
-//                    prob-embed + IBRNet aggregation + geometry MLP, all layers as chained
-//                    v_mfma_f32_16x16x4_f32 with activations resident in registers
+//                    prob-embed + IBRNet aggregation + geometry MLP, all layers as chained MFMAs with
+//                    activations resident in registers: fp32 values, multiplied on the f16 matrix cores
+//                    as fp16 pairs (v_mfma_f32_16x16x32_f16; short remainders on v_mfma_f32_16x16x4_f32)
 //                    (dist_decoder.py:99-142, aggregate_net.py:35-70, ibrnet.py:456-489,506-512)
 //   k_ray<RENDER>    per ray / voxel column: 40-token self-attention + SDF head, and for rays the
 //                    in-forward VJP, NeuS alpha, compositing, ray mask and inverse-CDF resampling

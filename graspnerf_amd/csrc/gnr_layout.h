@@ -9,6 +9,8 @@
 //   B = v[j]  ->  D[i][r]; lane (r,g) register t of block nb then holds output feature
 //   psi(nb, 4g+t), i.e. the output is again in B-operand layout.  No cross-lane movement
 //   between layers; only the k-order of each dot product is permuted (fp32 reassociation).
+//   The wide layers execute the same scheme on v_mfma_f32_16x16x32_f16 with operands as fp16 pairs: see the C16 section
+//   below -- 8 consecutive k-steps of the fp32 form are one K32 block, lane mapping and output layout unchanged.
 //   "natural" layout: phi(j,g) = 16*(j/4) + 4*g + (j%4)   <->   psi(nb,i) = 16*nb + i.
 //
 // A-fragment storage of a layer with J k-steps and NB output blocks (floats):
