@@ -243,7 +243,7 @@ def test_error_codes(hot):
     assert hot.L.gnr_prepare(C.byref(scene), None, 0, None) == -1
 
 
-@pytest.mark.parametrize('V', [2, 4, 5, 8])
+@pytest.mark.parametrize('V', [2, 4, 5, 7, 8])
 def test_other_view_counts(V, hot, W):
     """k_chain is instantiated for 2..8 views; masks include views that see nothing (ragged validity)."""
     from graspnerf_amd.hotpath import batch_scenes
