@@ -188,6 +188,29 @@ TRAIN_CFG = {
 }                                                        # = configs/nrvgn_sdf.yaml of the reference, network part
 
 
+def f32_mfma_build_leg(value):
+    """The same step on the companion library (csrc/build.sh: -DGNR_SPLIT16=0, the chain on v_mfma_f32_16x16x4_f32 instead of fp16
+    pairs on the f16 cores), in a child process (GNR_LIB selects the library at load time), with its own parity gate: the
+    number an fp32-instruction-only implementation of the same kernels reaches on this box in this run."""
+    import subprocess
+    lib = os.path.join(ROOT, 'graspnerf_amd', 'csrc', 'libgnr_f32mfma.so')
+    if not os.path.exists(lib):
+        return {'skipped': 'libgnr_f32mfma.so not built'}
+    env = dict(os.environ, GNR_LIB=lib)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', '60', '--warmup', '10', '--no-train', '--no-backbones',
+                            '--no-cpu-baseline', '--no-f32-build'], env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                                  # noqa: BLE001  (a failed companion run must not lose the product's line)
+        return {'skipped': f'{type(e).__name__}: {e}'[:200]}
+    return {'library': 'graspnerf_amd/csrc/libgnr_f32mfma.so (-DGNR_SPLIT16=0)', 'value': d['value'], 'unit': d['unit'], 'steps': d['steps'],
+            'ms_per_step': d['ms_per_step'], 'parity_checked': d['parity_checked'],
+            'k_chain_volume_ms_per_launch': d['roofline']['ms_per_launch'], 'frac_of_fp32_mfma_peak': d['roofline']['frac'],
+            'product_speedup': round(value / d['value'], 3)}
+
+
 def build_model(dev):
     from graspnerf_amd.renderer import GraspNeRF
     from graspnerf_amd.synth import synth_state_dict
@@ -355,6 +378,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the configs[4] train-step sub-record')
     ap.add_argument('--no-backbones', action='store_true', help='skip the images -> grasps figure')
+    ap.add_argument('--no-f32-build', action='store_true', help='skip timing the fp32-MFMA companion build next to the product')
     ap.add_argument('--train-scenes', type=int, default=8)
     ap.add_argument('--train-steps', type=int, default=8)
     ap.add_argument('--train-warmup', type=int, default=10, help='the caching allocators and MIOpen settle over ~10 steps')
@@ -508,6 +532,8 @@ def main():
             out['train_step'] = rec
     if rank == 0 and world == 1 and not args.no_backbones:
         out['with_backbones'] = backbone_leg(hp, bref, bque, dev, B, step_ms)
+    if rank == 0 and world == 1 and not args.no_f32_build:
+        out['f32_mfma_build'] = f32_mfma_build_leg(out['value'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:    # the CPU leg is reported at N=1 only (the other ranks would wait)
         out['cpu_baseline'] = cpu_baseline(wnp)
     if rank == 0:
