@@ -197,8 +197,8 @@ def f32_mfma_build_leg(value):
     if not os.path.exists(lib):
         return {'skipped': 'libgnr_f32mfma.so not built'}
     env = dict(os.environ, GNR_LIB=lib)
-    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
-        env.pop(k, None)
+    for k in [k for k in env if k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE') or k.startswith(('TORCHELASTIC', 'MASTER_'))]:
+        env.pop(k)                                          # the child is a plain single-process run, also under torch.distributed.run
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', '60', '--warmup', '10', '--no-train', '--no-backbones',
                             '--no-cpu-baseline', '--no-f32-build'], env=env, capture_output=True, text=True, timeout=300)
