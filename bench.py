@@ -491,6 +491,9 @@ def main():
             'metric': METRIC, 'value': round(world * B * args.steps / dt, 3), 'unit': 'scenes/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': 'fp32 values end to end (inputs, activations, accumulators, outputs); inside k_chain the products of the wide layers are '
+                          'formed on the f16 matrix cores from fp32 operands carried as fp16 pairs (1 fp32 ulp; three exact partial products per MAC, '
+                          'DESIGN.md 4.1b); f32_mfma_build is the same step with those products on fp32 instructions',
             'parity_checked': parity is not None, 'parity': parity,
             'config': {'workload': f'{B} scenes/GPU/step, 6 views 288x512 (feature maps 72x128x32 x2), 40^3 TSDF volume + '
                                    f'512 rays x (40 coarse + 40 fine) samples incl. pixel_colors_gt, forward only, eval-mode resampling, '
