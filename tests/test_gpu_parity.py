@@ -310,7 +310,7 @@ def test_ragged_and_extreme_sizes(res, rn, dn, hot, W):
         assert np.array_equal(o['ray_mask'].cpu().numpy()[i], ref_o['ray_mask'].numpy()[0])
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(24))
 def test_random_geometry_sweep(seed, hot, W):
     """Randomised view counts, cameras (also close to / inside the workspace), per-view intrinsics and depth ranges,
     image / feature-map sizes without the 1/4 ratio, shifted boxes, fractional and out-of-image ray coordinates.
