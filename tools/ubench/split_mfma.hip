@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void k_layers(float* out, const float* w, int 
 }
 
 // ---- (3) numerics: D = W x for one 16x32 by 32x16 product, three ways
-__global__ void k_num(const float* W, const float* X, float* d32, float* dpair, float* dsub, float* dpair3) {
+__global__ void k_num(const float* W, const float* X, float* d32, float* dpair, float* dsub, float* dpair3, float* dunscaled) {
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
     f4 c = {0, 0, 0, 0};
     for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(W[r * 32 + 4 * j + g], X[(4 * j + g) * 16 + r], c, 0, 0, 0);
@@ -171,6 +171,19 @@ __global__ void k_num(const float* W, const float* X, float* d32, float* dpair, 
     const f4 a3 = a + lo * (1.f / 2048.f);                                   // three products: Wm xm dropped
     a += lo * (1.f / 2048.f) + lo2 * (1.f / (2048.f * 2048.f));
     for (int t = 0; t < 4; ++t) { dpair[(4 * g + t) * 16 + r] = a[t]; dpair3[(4 * g + t) * 16 + r] = a3[t]; }
+    {   // residuals carried UNscaled (m = fp16(x - h)): one accumulator, no folding -- exact only while the residual's low bits
+        // stay above the fp16 subnormal quantum 2^-24, i.e. for |x| >= 0.5
+        h8 wmu, xmu;
+        for (int i = 0; i < 8; ++i) {
+            const float w = W[r * 32 + 8 * g + i], x = X[(8 * g + i) * 16 + r];
+            wmu[i] = (_Float16)(w - (float)wh[i]); xmu[i] = (_Float16)(x - (float)xh[i]);
+        }
+        f4 u = {0, 0, 0, 0};
+        u = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, u, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xmu, u, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmu, xh, u, 0, 0, 0);
+        for (int t = 0; t < 4; ++t) dunscaled[(4 * g + t) * 16 + r] = u[t];
+    }
     // subnormal probe: 2^-20 (fp16 subnormal) * 1.0 summed over K = 32 -> 32 * 2^-20 if subnormals are honoured, 0 if flushed
     h8 s, one;
     for (int i = 0; i < 8; ++i) { s[i] = (_Float16)9.5367431640625e-07f; one[i] = (_Float16)1.f; }
@@ -243,11 +256,11 @@ int main() {
     std::vector<float> W(16 * 32), X(32 * 16);
     unsigned s = 12345;
     auto rnd = [&] { s = s * 1664525u + 1013904223u; return ((s >> 8) / 16777216.f) * 2.f - 1.f; };
-    float *dW, *dX, *d32, *dp, *ds, *dp3;
-    hipMalloc(&dW, W.size() * 4); hipMalloc(&dX, X.size() * 4); hipMalloc(&d32, 1024); hipMalloc(&dp, 1024); hipMalloc(&ds, 16); hipMalloc(&dp3, 1024);
-    std::vector<float> r32(256), rp(256), rp3(256);
+    float *dW, *dX, *d32, *dp, *ds, *dp3, *du;
+    hipMalloc(&dW, W.size() * 4); hipMalloc(&dX, X.size() * 4); hipMalloc(&d32, 1024); hipMalloc(&dp, 1024); hipMalloc(&ds, 16); hipMalloc(&dp3, 1024); hipMalloc(&du, 1024);
+    std::vector<float> r32(256), rp(256), rp3(256), ru(256);
     float sub[2];
-    double e32 = 0, ep = 0, ep3 = 0, q32 = 0, qp = 0, qp3 = 0;
+    double e32 = 0, ep = 0, ep3 = 0, q32 = 0, qp = 0, qp3 = 0, eu = 0, qu = 0;
     const int trials = 200;
     for (int tr = 0; tr < trials; ++tr) {
         const float ws = tr % 4 == 0 ? 0.03f : 0.3f, xs = tr % 3 == 0 ? 0.2f : 3.f;      // a few magnitude regimes
@@ -255,7 +268,8 @@ int main() {
         for (auto& v : X) v = rnd() * xs;
         hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k_num, dim3(1), dim3(64), 0, 0, dW, dX, d32, dp, ds, dp3);
+        hipLaunchKernelGGL(k_num, dim3(1), dim3(64), 0, 0, dW, dX, d32, dp, ds, dp3, du);
+        hipMemcpy(ru.data(), du, 1024, hipMemcpyDeviceToHost);
         hipMemcpy(r32.data(), d32, 1024, hipMemcpyDeviceToHost);
         hipMemcpy(rp.data(), dp, 1024, hipMemcpyDeviceToHost);
         hipMemcpy(rp3.data(), dp3, 1024, hipMemcpyDeviceToHost);
@@ -265,8 +279,9 @@ int main() {
                 double ref = 0, mag = 0;
                 for (int k = 0; k < 32; ++k) { ref += (double)W[i * 32 + k] * X[k * 16 + n]; mag += fabs((double)W[i * 32 + k] * X[k * 16 + n]); }
                 const double a = fabs(r32[i * 16 + n] - ref) / mag, b = fabs(rp[i * 16 + n] - ref) / mag, c = fabs(rp3[i * 16 + n] - ref) / mag;
-                e32 = fmax(e32, a); ep = fmax(ep, b); ep3 = fmax(ep3, c);
-                q32 += a * a; qp += b * b; qp3 += c * c;
+                const double uu = fabs(ru[i * 16 + n] - ref) / mag;
+                e32 = fmax(e32, a); ep = fmax(ep, b); ep3 = fmax(ep3, c); eu = fmax(eu, uu);
+                q32 += a * a; qp += b * b; qp3 += c * c; qu += uu * uu;
             }
     }
     const double nq = trials * 256.0;
@@ -274,6 +289,7 @@ int main() {
     printf("  fp32 MFMA chain (8 x 16x16x4)      max %.3g  rms %.3g\n", e32, sqrt(q32 / nq));
     printf("  fp16 pairs, 4 products             max %.3g  rms %.3g\n", ep, sqrt(qp / nq));
     printf("  fp16 pairs, 3 products (no Wm xm)  max %.3g  rms %.3g\n", ep3, sqrt(qp3 / nq));
+    printf("  unscaled residuals, 3 products     max %.3g  rms %.3g   (not used: see DESIGN.md 8)\n", eu, sqrt(qu / nq));
     printf("subnormal probe: A subnormal -> %.6g, B subnormal -> %.6g (expected %.6g if honoured)\n", sub[0], sub[1], 32 * 9.5367431640625e-07);
     return 0;
 }
