@@ -151,6 +151,86 @@ __global__ __launch_bounds__(512) void k_layers(float* out, const float* w, int 
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// ---- (2b) two INDEPENDENT activation vectors through the same layers in one wavefront: can the matrix work of one chain run
+// under the vector work (ELU, split) of the other?  ILV = 0: chain A's layer then chain B's layer (as written);
+// ILV = 1: software-pipelined -- the MFMAs of B's layer are issued between A's MFMAs and A's activation / split code
+DEV void pair_split(const float (&v)[8], h8& xh, h8& xm) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f2 x = {v[j], v[j + 1]};
+        const h2 h = __builtin_convertvector(x, h2);
+        const f2 r = {__builtin_fmaf((float)h.x, -2048.f, v[j] * 2048.f), __builtin_fmaf((float)h.y, -2048.f, v[j + 1] * 2048.f)};
+        const h2 m = __builtin_convertvector(r, h2);
+        xh[j] = h.x; xh[j + 1] = h.y; xm[j] = m.x; xm[j + 1] = m.y;
+    }
+}
+DEV void pair_mfma(const h8* wp, const h8& xh, const h8& xm, f4 (&acc)[2]) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const h8 wh = wp[(nb * 2) * 64], wm = wp[(nb * 2 + 1) * 64];
+        f4 lo = {0, 0, 0, 0};
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xm, lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, xh, lo, 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[nb], 0, 0, 0);
+        acc[nb] += lo * (1.f / 2048.f);
+    }
+}
+DEV void pair_elu(const f4 (&acc)[2], float (&v)[8]) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        v[nb * 4 + 0] = elu_s(acc[nb].x); v[nb * 4 + 1] = elu_s(acc[nb].y);
+        v[nb * 4 + 2] = elu_s(acc[nb].z); v[nb * 4 + 3] = elu_s(acc[nb].w);
+    }
+}
+template <int ILV>
+__global__ __launch_bounds__(512) void k_layers2(float* out, const float* w, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < NL * 1024; i += 512) lds[i] = w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    float va[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { va[j] = 0.01f * (lane + j); vb[j] = 0.02f * (lane - j); }
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (ILV == 0) {
+#pragma unroll 1
+            for (int l = 0; l < NL; ++l) {
+                asm volatile("" ::: "memory");
+                const h8* wp = reinterpret_cast<const h8*>(lds + l * 1024) + lane;
+                h8 xh, xm;
+                f4 acc[2] = {{0.1f, 0.2f, 0.3f, 0.4f}, {0.1f, 0.2f, 0.3f, 0.4f}};
+                pair_split(va, xh, xm); pair_mfma(wp, xh, xm, acc); pair_elu(acc, va);
+                __builtin_amdgcn_sched_barrier(0);
+                f4 acc2[2] = {{0.1f, 0.2f, 0.3f, 0.4f}, {0.1f, 0.2f, 0.3f, 0.4f}};
+                pair_split(vb, xh, xm); pair_mfma(wp, xh, xm, acc2); pair_elu(acc2, vb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // pipelined: B's MFMAs of layer l are in flight while A's ELU + split for layer l+1 execute, and vice versa
+            h8 ah, am, bh, bm;
+            pair_split(va, ah, am);
+            pair_split(vb, bh, bm);
+#pragma unroll 1
+            for (int l = 0; l < NL; ++l) {
+                asm volatile("" ::: "memory");
+                const h8* wp = reinterpret_cast<const h8*>(lds + l * 1024) + lane;
+                f4 acc[2] = {{0.1f, 0.2f, 0.3f, 0.4f}, {0.1f, 0.2f, 0.3f, 0.4f}}, acc2[2] = {{0.1f, 0.2f, 0.3f, 0.4f}, {0.1f, 0.2f, 0.3f, 0.4f}};
+                pair_mfma(wp, ah, am, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                pair_mfma(wp, bh, bm, acc2);                  // matrix work of B ...
+                pair_elu(acc, va); pair_split(va, ah, am);    // ... next to the vector work of A (same scheduling region)
+                __builtin_amdgcn_sched_barrier(0);
+                pair_elu(acc2, vb); pair_split(vb, bh, bm);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += va[j] + vb[j];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 // ---- (3) numerics: D = W x for one 16x32 by 32x16 product, three ways
 __global__ void k_num(const float* W, const float* X, float* d32, float* dpair, float* dsub, float* dpair3, float* dunscaled) {
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
@@ -236,6 +316,12 @@ int main() {
         printf("layer 32->32 + ELU, fp16 pairs x4  : %.3f ms  = %.0f cycles per layer per SIMD\n", ms, ms * 2.4e6 / (lit * NL * 2));
         ms = timeit([&] { hipLaunchKernelGGL(k_layers<2>, dim3(256), dim3(512), NL * 4096, 0, out, dw, lit); });
         printf("layer 32->32 + ELU, x triples (5)  : %.3f ms  = %.0f cycles per layer per SIMD\n", ms, ms * 2.4e6 / (lit * NL * 2));
+    }
+    {
+        float ms = timeit([&] { hipLaunchKernelGGL(k_layers2<0>, dim3(256), dim3(512), NL * 4096, 0, out, dw, lit); });
+        printf("two chains per wave, one after the other : %.3f ms  = %.0f cycles per layer per SIMD (2 waves x 2 chains)\n", ms, ms * 2.4e6 / (lit * NL * 4));
+        ms = timeit([&] { hipLaunchKernelGGL(k_layers2<1>, dim3(256), dim3(512), NL * 4096, 0, out, dw, lit); });
+        printf("two chains per wave, software-pipelined  : %.3f ms  = %.0f cycles per layer per SIMD\n", ms, ms * 2.4e6 / (lit * NL * 4));
     }
     // determinism of the layer chains (same inputs, several launches; all 131072 outputs compared bitwise)
     for (int mode = 0; mode < 2; ++mode) {
