@@ -23,7 +23,7 @@ class GnrRays(C.Structure):
                 ('ray_mask_view_num', C.c_int), ('ray_mask_point_num', C.c_int),
                 ('coords', C.c_void_p), ('que_pose', C.c_void_p), ('que_K', C.c_void_p),
                 ('que_depth_range', C.c_void_p), ('que_imgs', C.c_void_p), ('fine_u', C.c_void_p),
-                ('ray_batch_num', C.c_int)]
+                ('ray_batch_num', C.c_int), ('fine_depth_use_all', C.c_int)]
 
 
 RENDER_OUT_FIELDS = ['depth', 'sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr',

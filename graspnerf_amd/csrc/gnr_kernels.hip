@@ -311,6 +311,22 @@ __global__ void k_coarse_depth(const float* __restrict__ que_dr, float* __restri
     depth[i] = __fdiv_rn(1.f, __fadd_rn(__fdiv_rn(1.f, near), tick));
 }
 
+// fine_depth_use_all (renderer.py:145-146): the fine pass renders sort(cat(coarse depths, resampled depths)).  Both inputs are
+// ascending per ray (coarse by construction, fine out of the resampler's rank sort): a rank merge, coarse first on ties.
+__global__ void k_merge_depths(const float* __restrict__ dc, const float* __restrict__ df, float* __restrict__ out, int nrays, int dn, int fdn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = dn + fdn;
+    if (i >= nrays * T) return;
+    const int ray = i / T, e = i - ray * T;
+    const float* c = dc + (size_t)ray * dn;
+    const float* f = df + (size_t)ray * fdn;
+    int rank;
+    float v;
+    if (e < dn) { v = c[e]; rank = e; for (int j = 0; j < fdn; ++j) rank += f[j] < v ? 1 : 0; }
+    else { v = f[e - dn]; rank = e - dn; for (int j = 0; j < dn; ++j) rank += c[j] <= v ? 1 : 0; }
+    out[(size_t)ray * T + rank] = v;
+}
+
 DEV void inv3x3(const float* K, float* o) {
     const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
     const float A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
@@ -992,15 +1008,16 @@ struct RayArgs {
 
 // LDS floats per ray after the attention scratch is dead (RENDER tail): per-ray reductions + resampling arrays
 namespace rt {
-constexpr int TF = 0;            // [64]  transmittance factors 1-alpha+1e-10
-constexpr int RED = 64;          // [6][64] hit*r, hit*g, hit*b, hit*z, (|grad|-1)^2, view-count flag
-constexpr int HP = 448;          // [64]  hit_prob + 1e-5
-constexpr int DN = 512;          // [64]  normalised inverse depth
-constexpr int PD = 576;          // [64]  pdf
-constexpr int CD = 640;          // [72]  cdf (dn+1)
-constexpr int CE = 712;          // [72]  bin centres (dn+1)
-constexpr int FD = 784;          // [64]  unsorted fine depth
-constexpr int END = 848;
+constexpr int W = MAX_DN_FWD;    // row width of the per-ray arrays
+constexpr int TF = 0;            // [W]  transmittance factors 1-alpha+1e-10
+constexpr int RED = W;           // [6][W] hit*r, hit*g, hit*b, hit*z, (|grad|-1)^2, view-count flag
+constexpr int HP = 7 * W;        // [W]  hit_prob + 1e-5
+constexpr int DN = 8 * W;        // [W]  normalised inverse depth
+constexpr int PD = 9 * W;        // [W]  pdf
+constexpr int CD = 10 * W;       // [W+8]  cdf (dn+1)
+constexpr int CE = 11 * W + 8;   // [W+8]  bin centres (dn+1)
+constexpr int FD = 12 * W + 16;  // [W]  unsorted fine depth
+constexpr int END = 13 * W + 16;
 }
 
 // logits of one query against key j for the 4 heads (natural domain; the backward twins' recomputation, gnr_bwd.inc); `ok`
@@ -1365,8 +1382,8 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         const float hp = __fadd_rn(hitp, 1e-5f);
         if (act) {
             const float cr = a.colors[pt * 3], cg = a.colors[pt * 3 + 1], cb = a.colors[pt * 3 + 2];
-            Red[i] = hitp * cr; Red[64 + i] = hitp * cg; Red[128 + i] = hitp * cb; Red[192 + i] = hitp * z;
-            Red[256 + i] = gn * gn; Red[320 + i] = (nvalid > (float)a.view_num) ? 1.f : 0.f;
+            Red[i] = hitp * cr; Red[rt::W + i] = hitp * cg; Red[2 * rt::W + i] = hitp * cb; Red[3 * rt::W + i] = hitp * z;
+            Red[4 * rt::W + i] = gn * gn; Red[5 * rt::W + i] = (nvalid > (float)a.view_num) ? 1.f : 0.f;
             Hp[i] = hp;
             if (a.sdf) a.sdf[pt] = sdf;
             if (a.alpha) a.alpha[pt] = alpha;
@@ -1377,7 +1394,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         if (rvalid) {
             for (int qn = slot; qn < 6; qn += S) {      // slot q sums quantity q (q, q+S, .. when a ray has < 6 slots)
                 float s = 0.f;
-                for (int j = 0; j < dn; ++j) s += Red[qn * 64 + j];
+                for (int j = 0; j < dn; ++j) s += Red[qn * rt::W + j];
                 if (qn < 3) { if (a.pix) a.pix[(size_t)ray * 3 + qn] = s; }
                 else if (qn == 3) { if (a.rdepth) a.rdepth[ray] = s; }
                 else if (qn == 4) { if (a.gerr_part) a.gerr_part[ray] = s; }

@@ -112,9 +112,9 @@ constexpr int R_OUT0W = R_LNB + 16, R_OUT0B = R_OUT0W + 256, R_OUT1W = R_OUT0B +
 constexpr int R_GEO2W = R_OUT1B + 4;        // [16][64]
 constexpr int R_GEO1E = R_GEO2W + 1024;     // geometry_fc.0 weight columns 65..85: [64][21 -> 24]
 constexpr int R_VARIANCE = R_GEO1E + 64 * 24;
-constexpr int R_PE = R_VARIANCE + 4;        // sinusoid table [64 positions][16]
+constexpr int R_PE = R_VARIANCE + 4;        // sinusoid table [128 positions][16]
 // transposed copies / products for the VJP so that every inner loop reads contiguous scalars
-constexpr int R_WQT = R_PE + 64 * 16, R_WKT = R_WQT + 256, R_WVT = R_WKT + 256, R_WFCT = R_WVT + 256;   // [in][out]
+constexpr int R_WQT = R_PE + 128 * 16, R_WKT = R_WQT + 256, R_WVT = R_WKT + 256, R_WFCT = R_WVT + 256;   // [in][out]
 constexpr int R_GEO2WT = R_WFCT + 256;      // geometry_fc.2 weight transposed: [64][16]
 constexpr int R_OUTVJP = R_GEO2WT + 1024;   // w = out_geometry_fc.0^T @ out_geometry_fc.1 [16]: both d sdf / d LayerNorm output
                                             // and the folded forward (two linears without activation, ibrnet.py:410-412)
@@ -154,7 +154,8 @@ constexpr int VIEWP_FLOATS = 24;
 // per-point record (k_chain -> k_ray)
 constexpr int REC_VOL = 20;     // g16[16], nvalid, pad
 constexpr int REC_RAY = 84;     // g16[16], u[64], nvalid, pad
-constexpr int MAX_DN = 64;      // samples per ray / column handled by one wavefront in k_ray
+constexpr int MAX_DN = 64;      // samples per ray / column in the backward twins and in the resampler (coarse pass)
+constexpr int MAX_DN_FWD = 128; // samples per ray of a forward render pass (fine_depth_use_all: dn + fdn, renderer.py:145-146)
 
 // Backward blob (gnr_pack_weights_bwd): transposed weights as chained-MFMA A fragments, true scale (gradients are
 // kept in the true domain; the forward's log2e-scaled activations are rescaled where they enter a product).

@@ -445,7 +445,7 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
         for (int e = 0; e < 21; ++e) p[pk::R_GEO1E + h * 24 + e] = c[can::GEO0_W + h * 86 + 65 + e];
     p[pk::R_VARIANCE] = c[can::VARIANCE];
     // positional table, float64 then cast (ref: ibrnet.py:437-445)
-    for (int pos = 0; pos < 64; ++pos)
+    for (int pos = 0; pos < 128; ++pos)
         for (int k = 0; k < 16; ++k) {
             const double ang = (double)pos / std::pow(10000.0, 2.0 * (k / 2) / 16.0);
             p[pk::R_PE + pos * 16 + k] = (float)((k % 2 == 0) ? std::sin(ang) : std::cos(ang));

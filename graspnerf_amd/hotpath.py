@@ -114,7 +114,7 @@ class HotPath:
         r = GnrRays(rn, dn, fdn, cfg.get('ray_mask_view_num', 2), cfg.get('ray_mask_point_num', 8),
                     t['coords'].data_ptr(), t['pose'].data_ptr(), t['K'].data_ptr(), t['depth_range'].data_ptr(),
                     imgs.data_ptr() if imgs is not None else None,
-                    fine_u.data_ptr() if fine_u is not None else None, chunk)
+                    fine_u.data_ptr() if fine_u is not None else None, chunk, 1 if cfg.get('fine_depth_use_all', False) else 0)
         return r, t
 
     def _alloc_out(self, B, rn, dn, with_gt, debug, chunk=0):
@@ -140,10 +140,12 @@ class HotPath:
         if self.wf is None:
             raise _lib.GnrError('render() needs the fine-level weights')
         B, rn = que['coords'].shape[:2]
-        scene, keep, ws = prepared or self.prepare(ref, 1, rn, max(dn, fdn))
+        # fine_depth_use_all (renderer.py:145-146): the fine pass renders the coarse and the resampled depths together
+        fine_dn = dn + fdn if cfg.get('fine_depth_use_all', False) else fdn
+        scene, keep, ws = prepared or self.prepare(ref, 1, rn, max(dn, fine_dn))
         rays, rkeep = self._rays(que, dn, fdn, cfg, scene.H, scene.W)
         co_s, co = self._alloc_out(B, rn, dn, 'imgs' in que, debug, rays.ray_batch_num)
-        fi_s, fi = self._alloc_out(B, rn, fdn, 'imgs' in que, debug, rays.ray_batch_num)
+        fi_s, fi = self._alloc_out(B, rn, fine_dn, 'imgs' in que, debug, rays.ray_batch_num)
         fd_in = _f32(fine_depth_in, self.device) if fine_depth_in is not None else None
         inds = torch.empty(B, rn, fdn, dtype=torch.int32, device=self.device) if debug else None
         _lib.check(self.L.gnr_render_rays_fwd(C.byref(scene), C.byref(rays), self.wc.data_ptr(), self.wf.data_ptr(),

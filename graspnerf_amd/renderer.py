@@ -268,13 +268,20 @@ class NeuralRayRenderer(nn.Module):
             ('agg_net_type', c['agg_net_type'] == 'neus'), ('init_net_type', c['init_net_type'] == 'cost_volume'),
             ('use_hierarchical_sampling', bool(c['use_hierarchical_sampling'])),
             ('dist_decoder_cfg.use_vis', not c['dist_decoder_cfg'].get('use_vis', True)),
-            ('fine_depth_use_all', not c['fine_depth_use_all']), ('disable_view_dir', not c['disable_view_dir']),
+            ('disable_view_dir', not c['disable_view_dir']),
             ('volume_type', list(c.get('volume_type', ['sdf'])) == ['sdf'])) if not ok]
         if unsupported:
             # Not configured by the reference's only yaml.  disable_view_dir cannot run in the reference either with
-            # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None); fine_depth_use_all renders dn + fdn = 80
-            # samples per ray (the kernels hold <= 64 per ray) and needs another sample_num; use_vis adds a fourth decoder branch.
+            # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None); use_vis adds a fourth decoder branch.
             raise NotImplementedError(f'config options outside configs/nrvgn_sdf.yaml are not built: {unsupported}')
+        if c['fine_depth_use_all']:
+            # renderer.py:145-146: the fine pass renders the coarse and the resampled depths together.  The reference adds its
+            # positional table [1, sample_num, 16] to [rn, dn + fdn, 16] (ibrnet.py:491): the lengths must agree there too.
+            n = c['depth_sample_num'] + c['fine_depth_sample_num']
+            if c['fine_agg_net_cfg'].get('sample_num', 64) != n:
+                raise ValueError(f"fine_depth_use_all needs fine_agg_net_cfg.sample_num = depth_sample_num + fine_depth_sample_num = {n}")
+            if n > 128:
+                raise NotImplementedError('fine_depth_use_all: at most 128 samples per ray in the fine pass')
         self.vis_encoder = DefaultVisEncoder(c['vis_encoder_cfg'])
         self.dist_decoder = _DistDecoderParams()
         self.image_encoder = ResUNetLight(3, [1, 2, 6, 4], 32, inplanes=16)
@@ -412,8 +419,7 @@ class NeuralRayRenderer(nn.Module):
         """Feature-map repack + view blocks once per forward; shared by volume / render / depth-mean."""
         c = self.cfg
         bref = self._batched_ref(ref_imgs_info)
-        return bref, self.hot().prepare(bref, c.get('volume_resolution', 40), rn,
-                                        max(c['depth_sample_num'], c['fine_depth_sample_num']))
+        return bref, self.hot().prepare(bref, c.get('volume_resolution', 40), rn, self._dn_max())
 
     @staticmethod
     def _batched_que(que):
@@ -426,11 +432,20 @@ class NeuralRayRenderer(nn.Module):
         c = self.cfg
         return {'depth_sample_num': c['depth_sample_num'], 'fine_depth_sample_num': c['fine_depth_sample_num'],
                 'ray_mask_view_num': c['ray_mask_view_num'], 'ray_mask_point_num': c['ray_mask_point_num'],
-                'ray_batch_num': c['ray_batch_num']}
+                'ray_batch_num': c['ray_batch_num'], 'fine_depth_use_all': bool(c['fine_depth_use_all'])}
+
+    def _dn_max(self):
+        """Most samples per ray of any render pass (workspace sizing)."""
+        c = self.cfg
+        fine = c['fine_depth_sample_num'] + (c['depth_sample_num'] if c['fine_depth_use_all'] else 0)
+        return max(c['depth_sample_num'], fine)
 
     def _use_autograd(self, is_train):
         """Training (autograd on, parameters trainable): the HIP twin pairs behind autograd.Functions."""
-        return bool(is_train) and torch.is_grad_enabled()
+        on = bool(is_train) and torch.is_grad_enabled()
+        if on and self.cfg['fine_depth_use_all']:
+            raise NotImplementedError('fine_depth_use_all is built for inference only (the backward twins hold <= 64 samples per ray)')
+        return on
 
     @staticmethod
     def _need_gpu(t):

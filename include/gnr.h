@@ -61,6 +61,10 @@ typedef struct GnrRays {
     int ray_batch_num;        /* cfg ray_batch_num (renderer.py:203-215): the reference renders rays in
                                  chunks and returns one sdf_gradient_error per chunk; >0 -> the output
                                  is [B, ceil(rn/ray_batch_num)] chunk means, 0 -> one mean per scene   */
+    int fine_depth_use_all;   /* cfg fine_depth_use_all (renderer.py:145-146): 1 -> the fine pass renders the dn coarse and
+                                 the fdn resampled depths of a ray, merged and sorted (dn + fdn <= 128 samples; the fine level's
+                                 positional table must have been built for that length, i.e. fine_agg_net_cfg.sample_num =
+                                 dn + fdn in the reference); 0 -> the fdn resampled depths only                              */
 } GnrRays;
 
 /* Outputs of one render pass (coarse or fine).  Keys follow renderer.py:90-138; any

@@ -447,7 +447,10 @@ def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None, fine_u=
     f1 = {} if debug is not None else None
     fd, inds = sample_fine_depth(depth, out['hit_prob_nr'][0], que['depth_range'],
                                  cfg['fine_depth_sample_num'], fine_u, details=f1)
-    fdepth = torch.sort(fd, -1)[0]                                         # renderer.py:148
+    if cfg.get('fine_depth_use_all', False):                               # renderer.py:145-146: coarse + resampled depths together
+        fdepth = torch.sort(torch.cat([depth, fd], -1), -1)[0]
+    else:
+        fdepth = torch.sort(fd, -1)[0]                                     # renderer.py:148
     if fine_depth_override is not None:
         fdepth = fine_depth_override
     fine = render_by_depth(sd, inp, que, fdepth, 'fine_dist_decoder.', 'fine_agg_net.', cfg, dbg_f)

@@ -177,3 +177,55 @@ def test_feature_magnitude_regimes(fscale, weights_np):
         assert np.isfinite(a).all() and np.isfinite(fi[k].cpu().numpy()).all(), (tag, k)
         close(a, ref_o[k].numpy(), f'{tag} coarse {k}', atol=m * ATOLS.get(k, ATOL_A))
         close(fi[k].cpu().numpy(), ref_o[k + '_fine'].numpy(), f'{tag} fine {k}', atol=m * ATOLS.get(k, ATOL_A))
+
+
+def test_fine_depth_use_all_matches_reference(weights_np, golden):
+    """cfg `fine_depth_use_all: true` (renderer.py:145-146): the fine pass renders sort(cat(coarse, resampled depths)), 16 + 16 = 32
+    samples at cfg1, against the reference's own outputs (golden_cfg1_use_all.npz, tools/make_goldens.py run_use_all).
+    Free-running: the merged depths contain the coarse ones bit for bit and are sorted; teacher-forced on the reference's
+    depths: every fine key within the tolerances of the other parity tests."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    G = golden('cfg1_use_all')
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    ref, que = make_scene(0, 'cfg1')
+    bref, bque = batch_scenes([(ref, que)])
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16, 'fine_depth_use_all': True}
+    co, fi = hp.render(bref, bque, cfg)
+    fd, cd = fi['depth'][0].cpu().numpy(), co['depth'][0].cpu().numpy()
+    assert fd.shape == (64, 32) and np.all(np.diff(fd, axis=1) >= 0)
+    assert all(np.isin(cd[r], fd[r]).all() for r in range(64))
+    assert np.mean(np.abs(fd - G['fine_depth_sorted']) > 1e-3) < 0.02           # resampling is ill-conditioned where the pdf is ~0
+    for k in VALUE_KEYS:
+        close(co[k].cpu().numpy(), G['render.' + k], f'use_all coarse {k}', atol=ATOLS.get(k, ATOL_A))
+    co2, fi2 = hp.render(bref, bque, cfg, fine_depth_in=G['fine_depth_sorted'][None])
+    for k in VALUE_KEYS + ['pixel_colors_nr', 'render_depth']:
+        close(fi2[k].cpu().numpy(), G['render.' + k + '_fine'], f'use_all fine {k}', atol=ATOLS.get(k, ATOL_A))
+    assert np.array_equal(fi2['ray_mask'].cpu().numpy(), G['render.ray_mask_fine'])
+
+
+def test_fine_depth_use_all_full_size(weights_np):
+    """40 + 40 = 80 samples per ray in the fine pass (beyond the 64 the resampler / backward twins hold; the forward render
+    pass takes up to 128) against the oracle, B = 2 scenes, plus the model mirror's config handling."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    from graspnerf_amd.renderer import NeuralRayRenderer
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    Wt = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    scenes = [make_scene(i, 'cfg2') for i in range(2)]
+    for s in scenes:
+        s[1]['coords'] = s[1]['coords'][:96]
+    bref, bque = batch_scenes(scenes)
+    cfg = {'depth_sample_num': 40, 'fine_depth_sample_num': 40, 'fine_depth_use_all': True}
+    co, fi = hp.render(bref, bque, cfg)
+    assert fi['sdf_values'].shape == (2, 96, 80)
+    for b, (ref, que) in enumerate(scenes):
+        o = O.render(Wt, O.to_torch(ref), O.to_torch(que), cfg, fine_depth_override=fi['depth'][b].cpu())
+        for k in VALUE_KEYS + ['pixel_colors_nr', 'render_depth']:
+            close(fi[k][b].cpu().numpy(), o[k + '_fine'].numpy()[0], f'use_all 80 scene {b} fine {k}', atol=ATOLS.get(k, ATOL_A))
+        assert np.array_equal(fi['ray_mask'][b].cpu().numpy(), o['ray_mask_fine'].numpy()[0])
+    base = {'network': 'grasp_nerf', 'init_net_type': 'cost_volume', 'agg_net_type': 'neus', 'use_hierarchical_sampling': True,
+            'fine_depth_use_all': True, 'depth_sample_num': 40, 'fine_depth_sample_num': 40, 'volume_type': ['sdf'],
+            'agg_net_cfg': {'sample_num': 40}, 'dist_decoder_cfg': {'use_vis': False}, 'fine_dist_decoder_cfg': {'use_vis': False}}
+    with pytest.raises(ValueError):
+        NeuralRayRenderer({**base, 'fine_agg_net_cfg': {'sample_num': 40}})
+    net = NeuralRayRenderer({**base, 'fine_agg_net_cfg': {'sample_num': 80}})
+    assert net._dn_max() == 80

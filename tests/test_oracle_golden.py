@@ -159,3 +159,29 @@ def test_f1_properties_random_inputs():
         assert bool(((lo <= u) & ((u < hi) | (inds == dn))).all())
         assert float(fd.min()) >= 0.2 - 1e-5 and float(fd.max()) <= 0.8 + 1e-5
         assert bool((fd[:, 1:] >= fd[:, :-1] - 1e-6).all())            # eval-mode u is increasing -> depths are
+
+
+def test_oracle_fine_depth_use_all(weights_np, golden):
+    """cfg `fine_depth_use_all: true` (renderer.py:145-146): the fine pass renders sort(cat(coarse depths, resampled depths)),
+    dn + fdn = 32 samples at cfg1, the fine aggregation net's positional table built for 32 positions.  Free-running merge
+    against the reference's own sorted depths, teacher-forced values against every output key."""
+    G = golden('cfg1_use_all')
+    ref, que = make_scene(0, 'cfg1')
+    W = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16, 'fine_depth_use_all': True}
+    dbg = {}
+    O.render(W, O.to_torch(ref), O.to_torch(que), cfg, debug=dbg)
+    fd = dbg['fine_depth'].numpy()
+    assert fd.shape == G['fine_depth_sorted'].shape == (64, 32) and np.all(np.diff(fd, axis=1) >= 0)
+    # the 16 coarse depths of every ray are among its 32 merged ones, bit for bit
+    co = dbg['coarse_depth'].numpy()
+    assert all(np.isin(co[r], fd[r]).all() for r in range(64))
+    assert np.mean(np.abs(fd - G['fine_depth_sorted']) > 1e-3) < 0.02           # resampling is ill-conditioned where the pdf is ~0
+    out = O.render(W, O.to_torch(ref), O.to_torch(que), cfg, fine_depth_override=torch.from_numpy(G['fine_depth_sorted']))
+    for k, v in out.items():
+        g, v = G['render.' + k], v.numpy()
+        assert v.shape == g.shape, k
+        if v.dtype == bool:
+            assert np.array_equal(v, g), k
+        else:
+            assert np.abs(v - g).max() < TOL, (k, np.abs(v - g).max())

@@ -193,6 +193,44 @@ def run_train_mode(renderer, weights):
         print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
 
 
+def run_use_all(renderer, weights):
+    """render() of the reference with `fine_depth_use_all: true` (renderer.py:145-146: the fine pass renders the coarse and the
+    resampled depths of a ray together, dn + fdn samples; the fine aggregation net's positional table is built for that
+    length: fine_agg_net_cfg.sample_num = dn + fdn) on cfg1 (16 + 16 = 32 samples) -> golden_cfg1_use_all.npz."""
+    import network.render_ops as rops   # noqa: F401
+    cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
+    cfg.update(volume_resolution=16, depth_sample_num=16, fine_depth_sample_num=16, fine_depth_use_all=True)
+    cfg['agg_net_cfg']['sample_num'] = 16
+    cfg['fine_agg_net_cfg']['sample_num'] = 32
+    torch.manual_seed(0)
+    net = renderer.NeuralRayRenderer(cfg)
+    net.eval()
+    load_weights(net, weights)
+    ref, que = make_scene(0, 'cfg1')
+    t = lambda a: torch.from_numpy(a.copy())
+    ref_info = {k: t(v) for k, v in ref.items()}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    cap = {}
+    orig_sort = torch.sort
+
+    def srt(x, *a, **kw):
+        r = orig_sort(x, *a, **kw)
+        cap['sorted'] = r[0].clone()
+        return r
+    torch.sort = srt
+    try:
+        with torch.no_grad():
+            rend = net.render(que_info, ref_info, False)
+    finally:
+        torch.sort = orig_sort
+    out = {'render.' + k: v.numpy() for k, v in rend.items()}
+    out['fine_depth_sorted'] = cap['sorted'].numpy()[0]                # [rn, 32]
+    np.savez_compressed(ROOT + '/tests/golden/golden_cfg1_use_all.npz', **out)
+    for k, v in out.items():
+        print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
+
+
 class _Stop(Exception):
     pass
 
@@ -437,6 +475,8 @@ def main():
         return run_full_forward(renderer)
     if '--ckpt-keys-only' in sys.argv:
         return run_ckpt_keys(renderer)
+    if '--use-all-only' in sys.argv:
+        return run_use_all(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     if '--f1-only' in sys.argv:
         return run_f1(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     if '--train-only' in sys.argv:
@@ -465,6 +505,7 @@ def main():
             print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
     run_train_mode(renderer, weights)
     run_f1(renderer, weights)
+    run_use_all(renderer, weights)
     run_ckpt_keys(renderer)
     run_full_forward(renderer)
     run_losses()
