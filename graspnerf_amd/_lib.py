@@ -15,7 +15,7 @@ c_float_p = C.POINTER(C.c_float)
 class GnrScene(C.Structure):
     _fields_ = [('B', C.c_int), ('V', C.c_int), ('H', C.c_int), ('W', C.c_int), ('fh', C.c_int), ('fw', C.c_int),
                 ('imgs', C.c_void_p), ('img_feats', C.c_void_p), ('ray_feats', C.c_void_p),
-                ('poses', C.c_void_p), ('Ks', C.c_void_p), ('depth_range', C.c_void_p)]
+                ('poses', C.c_void_p), ('Ks', C.c_void_p), ('depth_range', C.c_void_p), ('use_vis', C.c_int)]
 
 
 class GnrRays(C.Structure):
@@ -64,6 +64,8 @@ def lib():
     L.gnr_packed_weights_floats.restype = C.c_int
     L.gnr_pack_weights.argtypes = [c_float_p, c_float_p]
     L.gnr_pack_weights.restype = C.c_int
+    L.gnr_pack_vis_decoder.argtypes = [c_float_p, c_float_p]
+    L.gnr_pack_vis_decoder.restype = C.c_int
     L.gnr_layout_offset.argtypes = [C.c_char_p]
     L.gnr_layout_offset.restype = C.c_int
     L.gnr_workspace_bytes.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_int, C.c_int]
@@ -171,7 +173,7 @@ def lib():
     return L
 
 
-EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_layout_offset', 'gnr_workspace_bytes',
+EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_pack_vis_decoder', 'gnr_layout_offset', 'gnr_workspace_bytes',
             'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',

@@ -491,7 +491,9 @@ DEV void row_load(const float (&S)[V][SW], int v, float (&R)[SW]) {
 #endif
 #define GNR_CHAIN_MIN_BLOCKS (GNR_CHAIN_THREADS >= 1024 ? 1 : GNR_CHAIN_THREADS / 256)
 // SAVE: training forward (writes the states the backward twins need); compiled out of the inference kernels
-template <int V, bool RENDER, bool SAVE = false>
+// USEVIS: the optional fourth decoder branch (dist_decoder_cfg.use_vis; GnrScene.use_vis), its own instantiations: as a
+// run-time branch it cost the default kernels 5 - 18 % (3.65 -> 3.82 ms volume, 1.29 -> 1.52 ms render launch)
+template <int V, bool RENDER, bool SAVE = false, bool USEVIS = false>
 __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
@@ -646,8 +648,22 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 const float dinv = -rcp1(fmaxf(vg.z, 1e-5f));                 // dist_decoder.py:21-23
                 const float dhat = (dinv - vp[15]) * vp[17];
                 const float nearv = dhat - lo, farv = dhat + hi;
-                const float c00 = 0.5f + 0.5f * tanh1((nearv - mean0) * var0), c01 = 0.5f + 0.5f * tanh1((nearv - mean1) * var1);
-                const float c10 = 0.5f + 0.5f * tanh1((farv - mean0) * var0), c11 = 0.5f + 0.5f * tanh1((farv - mean1) * var1);
+                float c00 = 0.5f + 0.5f * tanh1((nearv - mean0) * var0), c01 = 0.5f + 0.5f * tanh1((nearv - mean1) * var1);
+                float c10 = 0.5f + 0.5f * tanh1((farv - mean0) * var0), c11 = 0.5f + 0.5f * tanh1((farv - mean1) * var1);
+                if constexpr (USEVIS) {   // dist_decoder_cfg.use_vis (dist_decoder.py:89-97,103-104,133-134); off in nrvgn_sdf.yaml
+                    f4 acc[2];
+                    float h1[8], h2[8];
+                    load_bias<2, LF>(lds + LO(pk::B_DECV1), g, acc);
+                    if constexpr (SP) mm16<1, 2, LF>(lds + LO(pk::DECV1), lane, &frp, acc);
+                    else mm<8, 2, 0, LF>(lds + LO(pk::DECV1), lane, FR, acc);
+                    elu_to<2, !SP>(acc, h1);
+                    load_bias<2, LF>(lds + LO(pk::B_DECV2), g, acc);
+                    if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF>(lds + LO(pk::DECV2), lane, &hp, acc); }
+                    else mm<8, 2, 0, LF>(lds + LO(pk::DECV2), lane, h1, acc);
+                    elu_to<2, !SP>(acc, h2);
+                    const float pv = sigmoid1(gsum(dot8(lds + LO(pk::T_DECV3), g, h2)) + lds[LO(pk::T_VIS)]);
+                    c00 *= pv; c01 *= pv; c10 *= pv; c11 *= pv;
+                }
                 vis = ((1.f - c00) * aw + (1.f - c01) * (1.f - aw)) * m;
                 hit = ((c10 - c00) * aw + (c11 - c01) * (1.f - aw)) * m;
             }

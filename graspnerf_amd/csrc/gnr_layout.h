@@ -75,7 +75,10 @@ constexpr int RGB2 = RGB1 + frag_floats(10, 1);           //  4   1
 constexpr int HOIST = RGB2 + frag_floats(4, 1);           // 36   4
 constexpr int GEO1 = HOIST + frag_floats(36, 4);          // 23   4
 constexpr int GEO2 = GEO1 + frag_floats(23, 4);           // 16   1
-constexpr int FRAG_END = GEO2 + frag_floats(16, 1);
+// optional fourth decoder branch (dist_decoder_cfg.use_vis, dist_decoder.py:89-97): zero unless gnr_pack_vis_decoder filled it
+constexpr int DECV1 = GEO2 + frag_floats(16, 1);          //  8   2   vis_decoder.0
+constexpr int DECV2 = DECV1 + frag_floats(8, 2);          //  8   2   vis_decoder.2
+constexpr int FRAG_END = DECV2 + frag_floats(8, 2);
 // bias tables: [NB][4 groups][4 regs] floats per layer (lane reads float4 at nb*4+g)
 constexpr int B_DEC1 = FRAG_END;            // 3 x 32
 constexpr int B_DEC2 = B_DEC1 + 96;         // 3 x 32
@@ -92,7 +95,9 @@ constexpr int B_RGB1 = B_VISB1 + 32;
 constexpr int B_RGB2 = B_RGB1 + 16;
 constexpr int B_GEO1 = B_RGB2 + 16;         // 64
 constexpr int B_GEO2 = B_GEO1 + 64;         // 16
-constexpr int BIAS_END = B_GEO2 + 16;
+constexpr int B_DECV1 = B_GEO2 + 16;        // 32
+constexpr int B_DECV2 = B_DECV1 + 32;       // 32
+constexpr int BIAS_END = B_DECV2 + 32;
 // VALU tables for the 1..2-row output layers: per lane-group weights [g][8] (or [g][4])
 constexpr int T_DEC3 = BIAS_END;            // 5 outputs x [4 g][8 j] = 160 ; order mean0 mean1 var0 var1 aw
 constexpr int T_DEC3_B = T_DEC3 + 160;      // 5 biases (+3 pad)
@@ -101,7 +106,9 @@ constexpr int T_VIS2R = T_NR2 + 16;         // row 32 of vis_fc.2: [4][8]
 constexpr int T_VISB2 = T_VIS2R + 32;       // vis_fc2.2: [4][8]
 constexpr int T_RGB3 = T_VISB2 + 32;        // rgb_fc.4: [4][4]
 constexpr int T_SCAL = T_RGB3 + 16;         // scalars: [0]=nr2 bias [1]=vis2 row32 bias [2]=visb2 bias [3]=rgb3 bias
-constexpr int CHAIN_END = T_SCAL + 8;
+constexpr int T_DECV3 = T_SCAL + 8;         // vis_decoder.4: [4][8]
+constexpr int T_VIS = T_DECV3 + 32;         // [0] = vis_decoder.4 bias, [1] = 1.0 when the branch is present (use_vis), else 0
+constexpr int CHAIN_END = T_VIS + 8;
 static_assert(CHAIN_END % 4 == 0, "CHAIN section must be float4 copyable");
 static_assert(CHAIN_END * 4 <= 160 * 1024, "CHAIN section must fit the 160 KiB LDS");
 

@@ -151,7 +151,22 @@ std::vector<C16Plan> c16_plan() {
     v.push_back({HOIST, 36, 4, {ksteps(0, 8), ksteps(8, 8), ksteps(16, 8), ksteps(24, 8), ksteps(32, 4)}, {}});      // 4-k-step tail zero-padded
     v.push_back({GEO1, 23, 4, {ksteps(0, 8), ksteps(8, 8), ksteps(16, 7)}, {}});                                     // 7-k-step tail zero-padded
     v.push_back({GEO2, 16, 1, {ksteps(0, 8), ksteps(8, 8)}, {}});
+    v.push_back({DECV1, 8, 2, {ksteps(0, 8)}, {}});
+    v.push_back({DECV2, 8, 2, {ksteps(0, 8)}, {}});
     return v;                                                // RDF1 (one k-step), RDF2 and RGB2 (4 k-steps) stay fp32
+}
+
+// C16 section of a packed blob from its CHAIN section: the same slots (two of them grown, gnr_layout.h c16_off) with the wide
+// layers' fragments as fp16 pairs: what k_chain stages into LDS
+int build_c16(float* p) {
+    using namespace gnr;
+    std::memset(p + pk::C16, 0, sizeof(float) * pk::C16_END);
+    const int cuts[4] = {0, pk::GEO1, pk::GEO2, pk::CHAIN_END};                   // the slot behind each grown layer starts a new run
+    for (int r = 0; r < 3; ++r)
+        std::memcpy(p + pk::C16 + pk::c16_off(cuts[r]), p + cuts[r], sizeof(float) * (cuts[r + 1] - cuts[r]));
+    for (const C16Plan& pl : c16_plan())
+        if (!to_pairs(p + pk::C16 + pk::c16_off(pl.off), p + pl.off, pl)) return GNR_ERR_ARG;      // a weight beyond the fp16 range (|w| >= 65520)
+    return GNR_OK;
 }
 
 // per-lane-group table of one output row over a natural-layout input of J slots: T[g][j]
@@ -168,11 +183,11 @@ extern "C" int gnr_layout_offset(const char* name) {
     static const E tab[] = {
         {"DEC1", DEC1}, {"DEC2", DEC2}, {"PE1", PE1}, {"RDF1", RDF1}, {"RDF2", RDF2}, {"NR1", NR1},
         {"BASE1", BASE1}, {"BASE2", BASE2}, {"VIS1", VIS1}, {"VIS2", VIS2}, {"VISB1", VISB1}, {"RGB1", RGB1},
-        {"RGB2", RGB2}, {"HOIST", HOIST}, {"GEO1", GEO1}, {"GEO2", GEO2}, {"FRAG_END", FRAG_END},
+        {"RGB2", RGB2}, {"HOIST", HOIST}, {"GEO1", GEO1}, {"GEO2", GEO2}, {"DECV1", DECV1}, {"DECV2", DECV2}, {"FRAG_END", FRAG_END},
         {"B_DEC1", B_DEC1}, {"B_DEC2", B_DEC2}, {"B_PE1", B_PE1}, {"B_RDF1", B_RDF1},
         {"B_RDF2", B_RDF2}, {"B_NR1", B_NR1}, {"B_HOIST", B_HOIST}, {"B_BASE2", B_BASE2}, {"B_VIS1", B_VIS1},
         {"B_VIS2", B_VIS2}, {"B_VISB1", B_VISB1}, {"B_RGB1", B_RGB1}, {"B_RGB2", B_RGB2}, {"B_GEO1", B_GEO1},
-        {"B_GEO2", B_GEO2}, {"T_DEC3", T_DEC3}, {"T_DEC3_B", T_DEC3_B}, {"T_NR2", T_NR2}, {"T_VIS2R", T_VIS2R},
+        {"B_GEO2", B_GEO2}, {"B_DECV1", B_DECV1}, {"B_DECV2", B_DECV2}, {"T_DECV3", T_DECV3}, {"T_VIS", T_VIS}, {"T_DEC3", T_DEC3}, {"T_DEC3_B", T_DEC3_B}, {"T_NR2", T_NR2}, {"T_VIS2R", T_VIS2R},
         {"T_VISB2", T_VISB2}, {"T_RGB3", T_RGB3}, {"T_SCAL", T_SCAL}, {"CHAIN_END", CHAIN_END},
         {"R_WQ", R_WQ}, {"R_WK", R_WK}, {"R_WV", R_WV}, {"R_WFC", R_WFC}, {"R_LNW", R_LNW}, {"R_LNB", R_LNB},
         {"R_OUT0W", R_OUT0W}, {"R_OUT0B", R_OUT0B}, {"R_OUT1W", R_OUT1W}, {"R_OUT1B", R_OUT1B},
@@ -469,15 +484,23 @@ extern "C" int gnr_pack_weights(const float* c, float* p) {
         for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT1_W + f] * (double)c[can::OUT0_B + f];
         p[pk::R_OUTB] = (float)acc;
     }
-    // --- C16 section: the CHAIN section's slots (three of them grown, gnr_layout.h c16_off) with the wide layers' fragments as
-    //     fp16 pairs: what k_chain stages into LDS
-    std::memset(p + pk::C16, 0, sizeof(float) * pk::C16_END);
-    {
-        const int cuts[4] = {0, pk::GEO1, pk::GEO2, pk::CHAIN_END};               // the slot behind each grown layer starts a new run
-        for (int r = 0; r < 3; ++r)
-            std::memcpy(p + pk::C16 + pk::c16_off(cuts[r]), p + cuts[r], sizeof(float) * (cuts[r + 1] - cuts[r]));
-    }
-    for (const C16Plan& pl : c16_plan())
-        if (!to_pairs(p + pk::C16 + pk::c16_off(pl.off), p + pl.off, pl)) return GNR_ERR_ARG;      // a weight beyond the fp16 range (|w| >= 65520)
-    return GNR_OK;
+    return build_c16(p);
+}
+
+// The optional fourth decoder branch of a level (dist_decoder_cfg.use_vis: true, dist_decoder.py:89-97,103-104,133-134) into an
+// already packed blob.  v = vis_decoder.{0.weight [32][32], 0.bias [32], 2.weight [32][32], 2.bias [32], 4.weight [1][32],
+// 4.bias [1]} in state-dict order (2 145 floats).  Sets the flag k_chain tests.
+extern "C" int gnr_pack_vis_decoder(const float* v, float* p) {
+    if (!v || !p) return GNR_ERR_ARG;
+    using namespace gnr;
+    const IdxFn natI = nat_in, natO = nat_out;
+    const IdxFn ray8 = [](int j, int g) { return 8 * g + j; };
+    pack_frag(p + pk::DECV1, v, 32, 8, 2, ray8, natO, LOG2E, kTrue);
+    pack_bias(p + pk::B_DECV1, v + 1024, 2, natO, LOG2E);
+    pack_frag(p + pk::DECV2, v + 1056, 32, 8, 2, natI, natO, LOG2E, kTilde);
+    pack_bias(p + pk::B_DECV2, v + 2080, 2, natO, LOG2E);
+    pack_row(p + pk::T_DECV3, v + 2112, 8, LOG2E);
+    p[pk::T_VIS] = v[2144];
+    p[pk::T_VIS + 1] = 1.f;
+    return build_c16(p);
 }

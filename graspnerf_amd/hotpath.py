@@ -33,6 +33,12 @@ class HotPath:
         self.device = torch.device(device)
         self.wc = torch.from_numpy(np.ascontiguousarray(packed_coarse, np.float32)).to(self.device)
         self.wf = None if packed_fine is None else torch.from_numpy(np.ascontiguousarray(packed_fine, np.float32)).to(self.device)
+        # cfg use_vis: the packed blobs say whether they carry the fourth decoder branch (gnr_pack_vis_decoder sets the flag)
+        flag = self.L.gnr_layout_offset(b'T_VIS') + 1
+        self.use_vis = bool(np.asarray(packed_coarse).reshape(-1)[flag] != 0)
+        if packed_fine is not None and bool(np.asarray(packed_fine).reshape(-1)[flag] != 0) != self.use_vis:
+            raise _lib.GnrError('use_vis must be the same for both levels (the reference evaluates the fine level with the coarse '
+                                "decoder's compute_prob, renderer.py:70-72)")
         self._ws = None
         self._keep = []
 
@@ -48,7 +54,7 @@ class HotPath:
         assert t['img_feats'].shape == (B, V, 32, fh, fw) and t['ray_feats'].shape == (B, V, 32, fh, fw)
         assert t['poses'].shape == (B, V, 3, 4) and t['Ks'].shape == (B, V, 3, 3) and t['depth_range'].shape == (B, V, 2)
         s = GnrScene(B, V, H, W, fh, fw, t['imgs'].data_ptr(), t['img_feats'].data_ptr(), t['ray_feats'].data_ptr(),
-                     t['poses'].data_ptr(), t['Ks'].data_ptr(), t['depth_range'].data_ptr())
+                     t['poses'].data_ptr(), t['Ks'].data_ptr(), t['depth_range'].data_ptr(), 1 if self.use_vis else 0)
         return s, t
 
     def _workspace(self, scene, res, rn, dn):

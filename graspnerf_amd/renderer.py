@@ -40,11 +40,13 @@ def _mlp(dims, skip_act_index=True):
 
 
 class _DistDecoderParams(nn.Module):
-    """ref: dist_decoder.py:53-88 (use_vis False)"""
+    """ref: dist_decoder.py:53-97 (parameter container; `use_vis` adds the fourth branch, :89-97)"""
 
-    def __init__(self):
+    def __init__(self, use_vis=False):
         super().__init__()
         self.mean_decoder, self.var_decoder, self.aw_decoder = _mlp([32, 32, 32, 2]), _mlp([32, 32, 32, 2]), _mlp([32, 32, 32, 1])
+        if use_vis:
+            self.vis_decoder = _mlp([32, 32, 32, 1])
 
 
 class _Attention(nn.Module):
@@ -267,12 +269,15 @@ class NeuralRayRenderer(nn.Module):
         unsupported = [k for k, ok in (
             ('agg_net_type', c['agg_net_type'] == 'neus'), ('init_net_type', c['init_net_type'] == 'cost_volume'),
             ('use_hierarchical_sampling', bool(c['use_hierarchical_sampling'])),
-            ('dist_decoder_cfg.use_vis', not c['dist_decoder_cfg'].get('use_vis', True)),
+            # the reference evaluates the fine level with the COARSE decoder's compute_prob (renderer.py:70-72): mixed settings
+            # either crash there (None * tensor) or silently ignore the fine branch
+            ('dist_decoder_cfg.use_vis != fine_dist_decoder_cfg.use_vis',
+             bool(c['dist_decoder_cfg'].get('use_vis', True)) == bool(c['fine_dist_decoder_cfg'].get('use_vis', True))),
             ('disable_view_dir', not c['disable_view_dir']),
             ('volume_type', list(c.get('volume_type', ['sdf'])) == ['sdf'])) if not ok]
         if unsupported:
             # Not configured by the reference's only yaml.  disable_view_dir cannot run in the reference either with
-            # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None); use_vis adds a fourth decoder branch.
+            # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None).
             raise NotImplementedError(f'config options outside configs/nrvgn_sdf.yaml are not built: {unsupported}')
         if c['fine_depth_use_all']:
             # renderer.py:145-146: the fine pass renders the coarse and the resampled depths together.  The reference adds its
@@ -283,11 +288,12 @@ class NeuralRayRenderer(nn.Module):
             if n > 128:
                 raise NotImplementedError('fine_depth_use_all: at most 128 samples per ray in the fine pass')
         self.vis_encoder = DefaultVisEncoder(c['vis_encoder_cfg'])
-        self.dist_decoder = _DistDecoderParams()
+        self.use_vis = bool(c['dist_decoder_cfg'].get('use_vis', True))      # dist_decoder.py:57: the reference's default is True
+        self.dist_decoder = _DistDecoderParams(self.use_vis)
         self.image_encoder = ResUNetLight(3, [1, 2, 6, 4], 32, inplanes=16)
         self.init_net = CostVolumeInitNet(c['init_net_cfg'])
         self.agg_net = _AggNetParams(c['agg_net_cfg'])
-        self.fine_dist_decoder = _DistDecoderParams()
+        self.fine_dist_decoder = _DistDecoderParams(self.use_vis)
         self.fine_agg_net = _AggNetParams(c['fine_agg_net_cfg'])
         self.use_sdf = True
         self._hot = None
@@ -308,6 +314,8 @@ class NeuralRayRenderer(nn.Module):
         if ps is None or self._hot is None:                  # (re)collected whenever the HotPath is rebuilt (_apply / load_state_dict)
             P = self._params()
             ps = self._hot_params = [P[k] for lvl in ('coarse', 'fine') for k, _ in _w.level_keys(lvl)]
+            if self.use_vis:
+                ps += [P[_w.LEVELS[lvl][0] + k] for lvl in ('coarse', 'fine') for k, _ in _w.VIS_KEYS]
         return tuple(p._version for p in ps)
 
     def hot(self):
@@ -321,8 +329,12 @@ class NeuralRayRenderer(nn.Module):
             self._hot_ver = ver
         elif getattr(self, '_hot_ver', None) != ver:
             sd = self._params()
-            self._hot.wc.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'coarse'))))
-            self._hot.wf.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'fine'))))
+            if self.use_vis:                                 # (per-key host copies: inference-only configuration, rarely re-packed)
+                self._hot.wc.copy_(torch.from_numpy(_w.pack_state_dict(sd, 'coarse')))
+                self._hot.wf.copy_(torch.from_numpy(_w.pack_state_dict(sd, 'fine')))
+            else:
+                self._hot.wc.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'coarse'))))
+                self._hot.wf.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'fine'))))
             self._hot_ver = ver
         return self._hot
 
@@ -445,6 +457,8 @@ class NeuralRayRenderer(nn.Module):
         on = bool(is_train) and torch.is_grad_enabled()
         if on and self.cfg['fine_depth_use_all']:
             raise NotImplementedError('fine_depth_use_all is built for inference only (the backward twins hold <= 64 samples per ray)')
+        if on and self.use_vis:
+            raise NotImplementedError('use_vis is built for inference only (the backward twins do not differentiate the vis_decoder branch)')
         return on
 
     @staticmethod

@@ -78,8 +78,30 @@ def pack(canonical):
     return out
 
 
+VIS_KEYS = [('vis_decoder.0.weight', (32, 32)), ('vis_decoder.0.bias', (32,)), ('vis_decoder.2.weight', (32, 32)),
+            ('vis_decoder.2.bias', (32,)), ('vis_decoder.4.weight', (1, 32)), ('vis_decoder.4.bias', (1,))]
+
+
+def has_vis_decoder(state_dict, level, prefix=''):
+    """cfg `use_vis: true` (dist_decoder.py:89-97): the level's decoder carries a fourth branch."""
+    return prefix + LEVELS[level][0] + VIS_KEYS[0][0] in state_dict
+
+
 def pack_state_dict(state_dict, level, prefix=''):
-    return pack(canonical_blob(state_dict, level, prefix))
+    """One level's packed blob from a state dict; a `vis_decoder` (use_vis) is packed behind it when the state dict has one."""
+    out = pack(canonical_blob(state_dict, level, prefix))
+    if has_vis_decoder(state_dict, level, prefix):
+        parts = []
+        for k, shape in VIS_KEYS:
+            v = state_dict[prefix + LEVELS[level][0] + k]
+            v = v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(f'{k}: expected shape {shape}, got {tuple(v.shape)}')
+            parts.append(np.asarray(v, np.float32).reshape(-1))
+        vis = np.ascontiguousarray(np.concatenate(parts))
+        L = _lib.lib()
+        _lib.check(L.gnr_pack_vis_decoder(vis.ctypes.data_as(_lib.c_float_p), out.ctypes.data_as(_lib.c_float_p)), 'gnr_pack_vis_decoder')
+    return out
 
 
 def pack_bwd(canonical):

@@ -40,6 +40,9 @@ typedef struct GnrScene {
     const float* poses;       /* [B,V,3,4] world->camera, OpenCV                            */
     const float* Ks;          /* [B,V,3,3]                                                  */
     const float* depth_range; /* [B,V,2] near, far                                          */
+    int use_vis;              /* cfg dist_decoder_cfg.use_vis (both levels, dist_decoder.py:89-97): 1 -> the packed level
+                                 blobs were completed with gnr_pack_vis_decoder and the chain runs the fourth decoder
+                                 branch (forward entry points only); 0 -> configs/nrvgn_sdf.yaml                       */
 } GnrScene;
 
 /* Query rays of B scenes.  Replaces the `que_imgs_info` dict (imgs_info.py:126-135). */
@@ -101,6 +104,11 @@ int gnr_packed_weights_floats(void);
  * stages into LDS, in which the wide layers' weights are stored as fp16 pairs w = h + m 2^-11 (1 fp32 ulp; csrc/gnr_layout.h
  * section C16).  GNR_ERR_ARG if a pointer is null or an effective weight is outside the fp16 range (|w| >= 65520). */
 int gnr_pack_weights(const float* canonical_host, float* packed_host);
+/* Optional: the fourth decoder branch of a level (cfg dist_decoder_cfg.use_vis: true; dist_decoder.py:89-97,103-104,133-134:
+ * its sigmoid output multiplies both cdfs) into a blob gnr_pack_weights has filled.  vis_decoder_host = vis_decoder.{0.weight
+ * [32][32], 0.bias [32], 2.weight [32][32], 2.bias [32], 4.weight [1][32], 4.bias [1]} in state-dict order (2145 floats).
+ * Forward entry points only: the backward twins do not differentiate this branch. */
+int gnr_pack_vis_decoder(const float* vis_decoder_host, float* packed_host);
 /* float offset of a named section of the packed blob (see csrc/gnr_layout.h), -1 if unknown */
 int gnr_layout_offset(const char* name);
 

@@ -150,7 +150,8 @@ def ref_view_inv_depth(z, depth_range):
 def decode_hit_vis(sd, dec, f_ray, z, mask, depth_range, lo, hi):
     """-> hit [V,N], vis [V,N] (already masked).  lo/hi: half-interval below/above the
     projected normalised inverse depth ([N] tensors or python floats).
-    ref: dist_decoder.py:99-107 (use_vis False), :109-142, renderer.py:62-78."""
+    ref: dist_decoder.py:99-107, :109-142, renderer.py:62-78.  `use_vis: true` = the state dict holds `vis_decoder`:
+    both cdfs are multiplied by its sigmoid output (dist_decoder.py:89-97,103-104,133-134)."""
     mean = _mlp3(f_ray, sd, dec + 'mean_decoder', F.softplus)              # [V,N,2]
     var = _mlp3(f_ray, sd, dec + 'var_decoder', F.softplus) + 0.05         # AddBias(0.05)
     aw = _mlp3(f_ray, sd, dec + 'aw_decoder', torch.sigmoid)               # [V,N,1]
@@ -160,6 +161,9 @@ def decode_hit_vis(sd, dec, f_ray, z, mask, depth_range, lo, hi):
     mix = torch.cat([aw, 1 - aw], -1)
     cdf0 = 0.5 + 0.5 * torch.tanh((near - mean) * var)
     cdf1 = 0.5 + 0.5 * torch.tanh((far - mean) * var)
+    if dec + 'vis_decoder.0.weight' in sd:
+        pv = _mlp3(f_ray, sd, dec + 'vis_decoder', torch.sigmoid)          # [V,N,1]
+        cdf0, cdf1 = cdf0 * pv, cdf1 * pv
     vis = torch.sum((1 - cdf0) * mix, -1)
     hit = torch.sum((cdf1 - cdf0) * mix, -1)
     m = mask.to(F32)

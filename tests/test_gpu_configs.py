@@ -229,3 +229,55 @@ def test_fine_depth_use_all_full_size(weights_np):
         NeuralRayRenderer({**base, 'fine_agg_net_cfg': {'sample_num': 40}})
     net = NeuralRayRenderer({**base, 'fine_agg_net_cfg': {'sample_num': 80}})
     assert net._dn_max() == 80
+
+
+def test_use_vis_matches_reference(weights_np, golden):
+    """cfg `use_vis: true` on both decoders (dist_decoder.py:89-97,103-104,133-134; the reference's own default, switched off by
+    nrvgn_sdf.yaml): a fourth decoder branch whose sigmoid output multiplies both cdfs.  Volume and render against the
+    reference's outputs (golden_cfg1_use_vis.npz carries the twelve vis_decoder tensors); the k_chain<.., USEVIS> kernels."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    G = golden('cfg1_use_vis')
+    wn = {**weights_np, **{k[len('weights.'):]: v for k, v in G.items() if k.startswith('weights.')}}
+    hp = HotPath(weights.pack_state_dict(wn, 'coarse'), weights.pack_state_dict(wn, 'fine'))
+    assert hp.use_vis
+    ref, que = make_scene(0, 'cfg1')
+    bref, bque = batch_scenes([(ref, que)])
+    vol = hp.sample_volume(bref, 16).cpu().numpy()
+    close(vol[0], G['volume'][0], 'use_vis volume vs reference golden')
+    plain = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    assert not plain.use_vis and np.abs(plain.sample_volume(bref, 16).cpu().numpy() - G['volume']).max() > 1e-3, 'the branch must matter'
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16}
+    co, fi = hp.render(bref, bque, cfg, fine_depth_in=G['fine_depth_sorted'][None])
+    for k in VALUE_KEYS:
+        close(co[k].cpu().numpy(), G['render.' + k], f'use_vis coarse {k}', atol=ATOLS.get(k, ATOL_A))
+        close(fi[k].cpu().numpy(), G['render.' + k + '_fine'], f'use_vis fine {k}', atol=ATOLS.get(k, ATOL_A))
+    assert np.array_equal(co['ray_mask'].cpu().numpy(), G['render.ray_mask'])
+    with pytest.raises(Exception):                                           # levels must agree
+        HotPath(weights.pack_state_dict(wn, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+
+
+def test_use_vis_model_mirror(weights_np, golden):
+    """NeuralRayRenderer with use_vis: the state dict gains the reference's twelve vis_decoder keys, sample_volume through the
+    mirror equals the reference's volume, training is refused (the backward twins do not carry the branch)."""
+    from graspnerf_amd.renderer import NeuralRayRenderer
+    G = golden('cfg1_use_vis')
+    base = {'network': 'grasp_nerf', 'init_net_type': 'cost_volume', 'agg_net_type': 'neus', 'use_hierarchical_sampling': True,
+            'volume_type': ['sdf'], 'volume_resolution': 16, 'depth_sample_num': 16, 'fine_depth_sample_num': 16,
+            'agg_net_cfg': {'sample_num': 16}, 'fine_agg_net_cfg': {'sample_num': 16}}
+    with pytest.raises(NotImplementedError):
+        NeuralRayRenderer({**base, 'dist_decoder_cfg': {'use_vis': True}, 'fine_dist_decoder_cfg': {'use_vis': False}})
+    net = NeuralRayRenderer({**base, 'dist_decoder_cfg': {'use_vis': True}, 'fine_dist_decoder_cfg': {'use_vis': True}})
+    keys = set(net.state_dict())
+    vis = {k[len('weights.'):] for k in G if k.startswith('weights.')}
+    assert len(vis) == 12 and vis <= keys
+    sd = {k: torch.from_numpy(v) for k, v in {**weights_np, **{k[len('weights.'):]: v for k, v in G.items() if k.startswith('weights.')}}.items()}
+    missing = net.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if 'decoder' in k or 'agg_net' in k] and not missing.unexpected_keys
+    net = net.cuda().eval()
+    ref, _ = make_scene(0, 'cfg1')
+    info = {k: torch.from_numpy(v).cuda() for k, v in ref.items()}
+    with torch.no_grad():
+        vol = net.sample_volume(info).cpu().numpy()
+    close(vol, G['volume'], 'use_vis volume through the model mirror')
+    with pytest.raises(NotImplementedError):
+        net._use_autograd(True)

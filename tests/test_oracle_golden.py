@@ -185,3 +185,29 @@ def test_oracle_fine_depth_use_all(weights_np, golden):
             assert np.array_equal(v, g), k
         else:
             assert np.abs(v - g).max() < TOL, (k, np.abs(v - g).max())
+
+
+def _with_vis_decoder(weights_np, G):
+    return {**weights_np, **{k[len('weights.'):]: v for k, v in G.items() if k.startswith('weights.')}}
+
+
+def test_oracle_use_vis(weights_np, golden):
+    """cfg `use_vis: true` on both decoders (dist_decoder.py:89-97,103-104,133-134): a fourth decoder branch whose sigmoid output
+    multiplies both cdfs; volume and every render key against the reference (golden_cfg1_use_vis.npz carries the twelve
+    vis_decoder tensors)."""
+    G = golden('cfg1_use_vis')
+    ref, que = make_scene(0, 'cfg1')
+    W = {k: torch.from_numpy(v) for k, v in _with_vis_decoder(weights_np, G).items()}
+    vol = O.sample_volume(W, O.to_torch(ref), 16).numpy()
+    assert np.abs(vol - G['volume']).max() < TOL
+    W0 = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    assert np.abs(O.sample_volume(W0, O.to_torch(ref), 16).numpy() - G['volume']).max() > 1e-3, 'the branch must matter'
+    cfg = {'depth_sample_num': 16, 'fine_depth_sample_num': 16}
+    out = O.render(W, O.to_torch(ref), O.to_torch(que), cfg, fine_depth_override=torch.from_numpy(G['fine_depth_sorted']))
+    for k, v in out.items():
+        g, v = G['render.' + k], v.numpy()
+        assert v.shape == g.shape, k
+        if v.dtype == bool:
+            assert np.array_equal(v, g), k
+        else:
+            assert np.abs(v - g).max() < TOL, (k, np.abs(v - g).max())

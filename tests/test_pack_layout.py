@@ -457,3 +457,46 @@ def test_base_fc0_split_in_pair_form(packed_and_sd):
     ref = LOG2E * (zt @ W.T.astype(np.float64) + b)
     mag = LOG2E * (np.abs(zt) @ np.abs(W.T.astype(np.float64)) + np.abs(b))
     assert np.max(np.abs(y - ref) / mag) < 5e-7
+
+
+def test_vis_decoder_branch(weights_np):
+    """gnr_pack_vis_decoder (cfg use_vis): the fourth decoder branch in both images -- fp32 fragments in the CHAIN section, fp16
+    pairs in the C16 image --, its .4 row as a VALU table, and the flag HotPath reads; absent -> all zero."""
+    rng = np.random.default_rng(21)
+    sd = dict(weights_np)
+    plain = weights.pack_state_dict(sd, 'coarse')
+    assert plain[off('T_VIS') + 1] == 0 and not plain[off('DECV1'): off('FRAG_END')].any()
+    for k, shape in weights.VIS_KEYS:
+        sd['dist_decoder.' + k] = (0.2 * rng.standard_normal(shape)).astype(np.float32)
+    packed = weights.pack_state_dict(sd, 'coarse')
+    assert weights.has_vis_decoder(sd, 'coarse') and not weights.has_vis_decoder(sd, 'fine')
+    assert packed[off('T_VIS') + 1] == 1 and packed[off('C16.T_VIS') + 1] == 1
+    assert np.array_equal(np.delete(packed, np.r_[off('DECV1'): off('FRAG_END'), off('B_DECV1'): off('B_DECV1') + 64,
+                                                  off('T_DECV3'): off('T_VIS') + 8,
+                                                  off('C16.DECV1'): off('C16.FRAG_END'), off('C16.B_DECV1'): off('C16.B_DECV1') + 64,
+                                                  off('C16.T_DECV3'): off('C16.T_VIS') + 8]),
+                          np.delete(plain, np.r_[off('DECV1'): off('FRAG_END'), off('B_DECV1'): off('B_DECV1') + 64,
+                                                 off('T_DECV3'): off('T_VIS') + 8,
+                                                 off('C16.DECV1'): off('C16.FRAG_END'), off('C16.B_DECV1'): off('C16.B_DECV1') + 64,
+                                                 off('C16.T_DECV3'): off('C16.T_VIS') + 8])), 'nothing else moves'
+    x = rng.standard_normal((16, 32)).astype(np.float32)
+    W0, b0 = sd['dist_decoder.vis_decoder.0.weight'], sd['dist_decoder.vis_decoder.0.bias']
+    W2, b2 = sd['dist_decoder.vis_decoder.2.weight'], sd['dist_decoder.vis_decoder.2.bias']
+    for base, boff, tag in ((off('DECV1'), off('B_DECV1'), 'fp32'), (None, None, 'pairs')):
+        if tag == 'fp32':
+            a1 = emulate(packed, off('DECV1'), 8, 2, to_B(x, 8, lambda j, g: 8 * g + j), bias_acc(packed, off('B_DECV1'), 2))
+            a2 = emulate(packed, off('DECV2'), 8, 2, to_B((x * LOG2E).astype(np.float32), 8, nat), bias_acc(packed, off('B_DECV2'), 2))
+        else:
+            a1 = emulate_pairs(packed, off('C16.DECV1'), 2, [to_B(x, 8, lambda j, g: 8 * g + j)], bias_acc(packed, off('C16.B_DECV1'), 2))
+            a2 = emulate_pairs(packed, off('C16.DECV2'), 2, [to_B((x * LOG2E).astype(np.float32), 8, nat)], bias_acc(packed, off('C16.B_DECV2'), 2))
+        np.testing.assert_allclose(from_D(a1, 2, lambda nb, i: 16 * nb + i, 32), LOG2E * (x.astype(np.float64) @ W0.T + b0), rtol=2e-5, atol=2e-5, err_msg=tag)
+        np.testing.assert_allclose(from_D(a2, 2, lambda nb, i: 16 * nb + i, 32), LOG2E * (x.astype(np.float64) @ W2.T + b2), rtol=2e-5, atol=2e-5, err_msg=tag)
+    # .4 row as a per-group table over a scaled-ELU input, bias next to the flag
+    h = (x * LOG2E).astype(np.float32)
+    out = np.zeros(16)
+    for r in range(16):
+        for g in range(4):
+            for j in range(8):
+                out[r] += packed[off('T_DECV3') + g * 8 + j] * h[r, nat(j, g)]
+    np.testing.assert_allclose(out + packed[off('T_VIS')], x.astype(np.float64) @ sd['dist_decoder.vis_decoder.4.weight'][0] + sd['dist_decoder.vis_decoder.4.bias'][0],
+                               rtol=2e-5, atol=2e-5)

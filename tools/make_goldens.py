@@ -231,6 +231,63 @@ def run_use_all(renderer, weights):
         print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
 
 
+def run_use_vis(renderer, weights):
+    """sample_volume + render of the reference with `use_vis: true` on both levels (dist_decoder.py:89-97,103-104,133-134: a
+    fourth decoder branch whose sigmoid output multiplies both cdfs) on cfg1 -> golden_cfg1_use_vis.npz, which also carries
+    the twelve vis_decoder tensors (the net of weights_seed0.npz has none): seeded init + the same bias perturbation."""
+    import network.render_ops as rops   # noqa: F401
+    import utils.field_utils as fu
+    cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
+    cfg.update(volume_resolution=16, depth_sample_num=16, fine_depth_sample_num=16)
+    cfg['agg_net_cfg']['sample_num'] = 16
+    cfg['fine_agg_net_cfg']['sample_num'] = 16
+    cfg['dist_decoder_cfg']['use_vis'] = True
+    cfg['fine_dist_decoder_cfg']['use_vis'] = True
+    torch.manual_seed(0)
+    net = renderer.NeuralRayRenderer(cfg)
+    net.eval()
+    load_weights(net, weights)
+    g = torch.Generator().manual_seed(4321)
+    extra = {}
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if 'vis_decoder' in k:
+                if k.endswith('.bias'):
+                    v.add_(0.1 * torch.randn(v.shape, generator=g))
+                extra[k] = v.detach().clone().numpy()
+    assert len(extra) == 12
+    fu.RESOLUTION = 16
+    fu.VOXEL_SIZE = fu.VOLUME_SIZE / 16
+    fu.HALF_VOXEL_SIZE = fu.VOXEL_SIZE / 2
+    renderer.TSDF_SAMPLE_POINTS = fu.generate_grid_points()
+    ref, que = make_scene(0, 'cfg1')
+    t = lambda a: torch.from_numpy(a.copy())
+    ref_info = {k: t(v) for k, v in ref.items()}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    cap = {}
+    orig_sort = torch.sort
+
+    def srt(x, *a, **kw):
+        r = orig_sort(x, *a, **kw)
+        cap['sorted'] = r[0].clone()
+        return r
+    torch.sort = srt
+    try:
+        with torch.no_grad():
+            vol = net.sample_volume(ref_info)
+            rend = net.render(que_info, ref_info, False)
+    finally:
+        torch.sort = orig_sort
+    out = {'render.' + k: v.numpy() for k, v in rend.items()}
+    out['volume'] = vol.numpy()
+    out['fine_depth_sorted'] = cap['sorted'].numpy()[0]
+    out.update({'weights.' + k: v for k, v in extra.items()})
+    np.savez_compressed(ROOT + '/tests/golden/golden_cfg1_use_vis.npz', **out)
+    for k, v in out.items():
+        print('   ', k, getattr(v, 'shape', None), getattr(v, 'dtype', None))
+
+
 class _Stop(Exception):
     pass
 
@@ -475,6 +532,8 @@ def main():
         return run_full_forward(renderer)
     if '--ckpt-keys-only' in sys.argv:
         return run_ckpt_keys(renderer)
+    if '--use-vis-only' in sys.argv:
+        return run_use_vis(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     if '--use-all-only' in sys.argv:
         return run_use_all(renderer, dict(np.load(ROOT + '/tests/golden/weights_seed0.npz')))
     if '--f1-only' in sys.argv:
@@ -506,6 +565,7 @@ def main():
     run_train_mode(renderer, weights)
     run_f1(renderer, weights)
     run_use_all(renderer, weights)
+    run_use_vis(renderer, weights)
     run_ckpt_keys(renderer)
     run_full_forward(renderer)
     run_losses()
