@@ -19,7 +19,7 @@ def train_losses(out, data, cfg=None):
     """Every loss / metric term of the configured losses for one scene's outputs (ref: loss.py, name2loss)."""
     ref = data['ref_imgs_info']
     terms = {}
-    terms.update(losses.render_loss(out))
+    terms.update(losses.render_loss(out, use_ray_mask='ray_mask' in out))   # renderer cfg use_ray_mask false drops the key (renderer.py:129-132)
     terms.update(losses.depth_loss(out, ref['true_depth'], ref['depth_range']))
     terms.update(losses.sdf_loss(out, ref['sdf_gt']))
     terms.update(losses.vgn_loss(out['vgn_pred'], data['grasp_info']))
@@ -32,7 +32,7 @@ def train_losses_stacked(st, datas):
     B = len(datas)
     refs = [d['ref_imgs_info'] for d in datas]
     terms = {}
-    terms.update(losses.render_loss(st))                                   # the reference's qn axis is the scene axis here
+    terms.update(losses.render_loss(st, use_ray_mask='ray_mask' in st))    # the reference's qn axis is the scene axis here
     terms.update(losses.depth_loss(st, torch.cat([r['true_depth'] for r in refs]), torch.cat([r['depth_range'] for r in refs]), scenes=B))
     terms.update(losses.sdf_loss(st, torch.stack([r['sdf_gt'] for r in refs]), scenes=B))
     terms.update(losses.vgn_loss(st['vgn_pred'], tuple(torch.stack(x) for x in zip(*[d['grasp_info'] for d in datas])), scenes=B))

@@ -74,3 +74,16 @@ def test_stacked_losses_equal_the_per_scene_ones():
     g2 = torch.autograd.grad(ref, leaves)
     for k, a, b in zip(list(leaf_keys) + ['q', 'r', 'w'], g1, g2):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-9, err_msg=k)
+
+
+def test_render_loss_without_ray_mask():
+    """Renderer cfg use_ray_mask false drops the key (renderer.py:129-132): the train step's render loss is then the plain mean
+    (loss.py:70-74, RenderLoss use_ray_mask false), per scene and stacked."""
+    from graspnerf_amd.trainer import train_losses, train_losses_stacked
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    pr, gt = synth_loss_case(seed=3)
+    p = {k: (tuple(t(x) for x in v) if isinstance(v, tuple) else t(v)) for k, v in pr.items() if k != 'ray_mask'}
+    d = {'ref_imgs_info': {k: t(gt[k]) for k in ('true_depth', 'depth_range', 'sdf_gt')}, 'grasp_info': tuple(t(x) for x in gt['grasp_info'])}
+    terms = train_losses(p, d)
+    want = 0.01 * ((p['pixel_colors_nr'] - p['pixel_colors_gt']) ** 2).sum(-1).mean(1)
+    assert torch.allclose(terms['loss_rgb_nr'], want)
