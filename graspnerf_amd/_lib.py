@@ -72,6 +72,10 @@ def lib():
     L.gnr_workspace_bytes.restype = C.c_size_t
     L.gnr_prepare.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_prepare.restype = C.c_int
+    L.gnr_range_status.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_size_t, C.POINTER(C.c_uint), C.c_void_p]
+    L.gnr_range_status.restype = C.c_int
+    L.gnr_force_fp32_chain.argtypes = [C.c_int]
+    L.gnr_force_fp32_chain.restype = C.c_int
     L.gnr_sample_volume_fwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_sample_volume_fwd.restype = C.c_int
@@ -174,7 +178,7 @@ def lib():
 
 
 EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_pack_vis_decoder', 'gnr_layout_offset', 'gnr_workspace_bytes',
-            'gnr_prepare', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
+            'gnr_prepare', 'gnr_range_status', 'gnr_force_fp32_chain', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
             'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_timing_begin', 'gnr_timing_begin_only', 'gnr_timing_end', 'gnr_grasp_select_workspace_bytes',

@@ -20,6 +20,13 @@
 
 #include "gnr_layout.h"
 
+// GNR_ABLATE: timing-only diagnostic builds of k_chain (tools/ab_chain.py; results are WRONG, never shipped): bit 0 no rotation of
+// the per-view state, bit 1 projection / tap arithmetic of view 0 reused for every view, bit 2 no residual half (m = 0),
+// bit 3 ELU -> identity, bit 5 no cross-term fold.  What a launch loses with a piece removed is that piece's cost.
+#ifndef GNR_ABLATE
+#define GNR_ABLATE 0
+#endif
+
 namespace gnr {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -38,16 +45,32 @@ DEV float elu1(float x) { return fmaxf(x, __builtin_amdgcn_fmed3f(__expf(x), 0.f
 // scaled form used inside the MFMA chain: input x' = log2e*x (the packer folds log2e into the producing
 // layer), output log2e*ELU(x) (divided out of the consumer's weights): 3 VALU ops per activation.
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+#if GNR_ABLATE & 8
+DEV float elu_s(float xs) { return xs; }
+#else
 DEV float elu_s(float xs) { return fmaxf(xs, fmaf(__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(xs), 0.f, 1.f), kLog2e, -kLog2e)); }
+#endif
 // the same activation as med3(x', log2e (2^x' - 1), 0): for inputs that come straight out of an MFMA (fmaxf would first
 // canonicalise them with an extra v_max x, x)
+#if GNR_ABLATE & 8
+DEV float elu_m(float xs) { return xs; }
+#else
 DEV float elu_m(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), kLog2e, -kLog2e), 0.f); }
+#endif
 DEV float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV float sigmoid1(float x) { return rcp1(1.f + __expf(-x)); }
 // softplus = max(x,0) + log(1 + e^-|x|)   (== torch's threshold-20 form to fp32 rounding)
 DEV float softplus1(float x) { return fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x))); }
 DEV float tanh1(float x) {            // 1 - 2/(e^{2x}+1); saturates cleanly to +-1
     return 1.f - 2.f * rcp1(__expf(2.f * x) + 1.f);
+}
+// sin / cos of x, 2x, 4x (the embedder's three octaves, ibrnet.py:118-131): one sincosf, the octaves by the double-angle
+// identities (each doubling adds <= 2 ulp of 1.0, 4e-7 absolute, on values the MLPs consume at 1e-3 relative); three precise
+// sincosf cost 377 VALU per tile of k_chain.  Every forward and backward kernel uses this one function (same bits everywhere).
+DEV void sincos_octaves(float x, float& s1, float& c1, float& s2, float& c2, float& s4, float& c4) {
+    sincosf(x, &s1, &c1);
+    s2 = 2.f * s1 * c1; c2 = fmaf(-2.f * s1, s1, 1.f);
+    s4 = 2.f * s2 * c2; c4 = fmaf(-2.f * s2, s2, 1.f);
 }
 // sum over the 4 lane groups (lanes l, l^16, l^32, l^48); identical bits on all four
 DEV float gsum(float x) {
@@ -168,7 +191,11 @@ DEV void split2(float x0, float x1, h2& h, h2& m) {
     h = __builtin_convertvector(x, h2);                                              // v_cvt_pk_f16_f32, round to nearest
     // (x - h) 2^11, exact: written as an fma on the scaled x so that it selects v_fma_mix_f32 (reads the fp16 half directly)
     const f2 r = {__builtin_fmaf((float)h.x, -kPairS, x0 * kPairS), __builtin_fmaf((float)h.y, -kPairS, x1 * kPairS)};
+#if GNR_ABLATE & 4
+    m = (h2){(_Float16)0.f, (_Float16)0.f};
+#else
     m = __builtin_convertvector(r, h2);
+#endif
 }
 template <int O, int N>
 DEV P8 split8(const float (&v)[N]) {
@@ -197,7 +224,43 @@ DEV P8 split8z(const float (&v)[N]) {
     p.m = (h8){m[0].x, m[0].y, m[1].x, m[1].y, m[2].x, m[2].y, m[3].x, m[3].y};
     return p;
 }
+// a pair block parked in eight 32-bit registers (the per-view state keeps e1 in this form: it is consumed twice as a B operand,
+// by neuray_fc.0 in the first view loop and by base_fc.0 in the second, and nowhere as fp32 values)
+DEV void p8_store(const P8& p, float* r) {
+    const f4 a = __builtin_bit_cast(f4, p.h), b = __builtin_bit_cast(f4, p.m);
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+}
+DEV P8 p8_load(const float* r) {
+    P8 p;
+    p.h = __builtin_bit_cast(h8, (f4){r[0], r[1], r[2], r[3]});
+    p.m = __builtin_bit_cast(h8, (f4){r[4], r[5], r[6], r[7]});
+    return p;
+}
 DEV f4 mfma32h(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// ---- range guard of the pair form.  The high half of a pair is an fp16: an operand of 65 520 or more becomes +-inf there and
+// the layer's outputs garbage (ELU then maps -inf and NaN to finite values, so nothing downstream would show it).  The fp32
+// reference has no such limit.  Every pair block whose operands are not bounded by construction is therefore watched:
+//  * a non-finite high half (+-inf, NaN) in column r of a B operand makes EVERY output of point r non-finite in that layer's
+//    accumulator (w inf = +-inf, 0 inf = NaN, inf - inf = NaN), so one accumulator register per lane and layer tells: chk =
+//    fma(acc, 0, chk) turns NaN at the first non-finite value and stays NaN -- one VALU instruction per watched LAYER
+//    (measured: 0.6 % of a launch; v_dot2c_f32_f16 over the halves, four operands per instruction, cost 2 %: it issues in ~10
+//    cycles; v_pk_max_i16 on the halves as signed integers, two per instruction, the same);
+//  * the gathered features are convex combinations of feature-map values, which k_repack_feats tests once per prepare.
+// A flagged launch sets a bit in GnrWorkspace's range word; the fp32-MFMA instantiation of the same kernel, launched right
+// behind every pair launch, returns at once unless a bit is set and otherwise recomputes the launch (gnr_capi.inc).
+#ifndef GNR_WATCH_LAST
+#define GNR_WATCH_LAST 0
+#endif
+#ifndef GNR_RANGE_GUARD
+#define GNR_RANGE_GUARD 1                     // 0: measurement builds without the watch and without the fp32 twin launches
+#endif
+constexpr float kFeatLimit = 60000.f;          // |feature| below this (k_repack_feats); leaves room for x = feature + ray_dir_fc
+// The running word is the tile's own valid-view count `msum` (live from the first view loop to the record, so the watch costs no
+// register): it turns NaN with the first non-finite accumulator and is tested once per tile.
+DEV void range_watch(float& word, const f4& a) {   // a: an output block of a pair-form layer (after the cross terms were folded in)
+    if constexpr (GNR_RANGE_GUARD) word = __builtin_fmaf(a.x, 0.f, word);
+}
 
 // acc[nb] += W x over KB K32 blocks (inputs x8[0..KB)), NB output blocks.  w: the layer's slot in the C16 image.  The
 // left-over fp32 k-steps of a layer are added by the caller with mm<>.
@@ -205,8 +268,9 @@ DEV f4 mfma32h(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16
 // outputs differed from launch to launch on the same inputs (tools/dbg/chain_det.py: 2 000 - 36 000 of 64 000 voxels by
 // 2e-7 ... 2e-5, at one and at two wavefronts per SIMD) -- a dependency the compiler's hazard tables (ROCm 7.2) do not
 // cover; tails are zero-padded into a K32 block instead.
-template <int KB, int NB, bool LF>
-DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, f4 (&acc)[NB]) {
+// WATCH: the B operands are not bounded by construction (range guard, RangeWatch)
+template <int KB, int NB, bool LF, bool WATCH = false>
+DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, f4 (&acc)[NB], float* rw = nullptr) {
     if constexpr (LF) asm volatile("" ::: "memory");
     const h8* w8 = reinterpret_cast<const h8*>(w) + lane;
 #pragma unroll
@@ -224,9 +288,14 @@ DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, 
             lo = mfma32h(wm, x8[kb].h, lo);
             acc[nb] = mfma32h(wh, x8[kb].h, acc[nb]);
         }
+#if GNR_ABLATE & 32
+        acc[nb] += lo;
+#else
         acc[nb].x = fmaf(lo.x, kPairSi, acc[nb].x); acc[nb].y = fmaf(lo.y, kPairSi, acc[nb].y);
         acc[nb].z = fmaf(lo.z, kPairSi, acc[nb].z); acc[nb].w = fmaf(lo.w, kPairSi, acc[nb].w);
+#endif
     }
+    if constexpr (WATCH) range_watch(*rw, acc[GNR_WATCH_LAST ? NB - 1 : 0]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -235,18 +304,22 @@ DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, 
 // [BV][32][npix] x2 (NCHW) -> [BV][npix][64]; block = 256 threads handles 64 pixels
 __global__ __launch_bounds__(256) void k_repack_feats(const float* __restrict__ ray_feats,
                                                       const float* __restrict__ img_feats,
-                                                      float* __restrict__ out, int npix) {
+                                                      float* __restrict__ out, int npix, unsigned* __restrict__ range_flag) {
     __shared__ float tile[64][65];
     const int bv = blockIdx.y, p0 = blockIdx.x * 64, t = threadIdx.x;
     const int tx = t & 63, ty = t >> 6;
     const size_t in_base = (size_t)bv * 32 * npix;
+    bool bad = false;
 #pragma unroll
     for (int c0 = 0; c0 < 64; c0 += 4) {
         const int c = c0 + ty, p = p0 + tx;
         float v = 0.f;
         if (p < npix) v = (c < 32) ? ray_feats[in_base + (size_t)c * npix + p] : img_feats[in_base + (size_t)(c - 32) * npix + p];
+        bad |= !(fabsf(v) < kFeatLimit);                   // also true for NaN / inf
         tile[c][tx] = v;
     }
+    // range guard of k_chain's pair form (RangeWatch): bit 0 = a feature beyond the fp16-pair range or not finite
+    if (range_flag && __ballot(bad) != 0 && (t & 63) == 0) atomicOr(range_flag, 1u);
     __syncthreads();
     float* o = out + ((size_t)bv * npix + p0) * 64;
 #pragma unroll
@@ -401,6 +474,10 @@ struct ChainArgs {
     float* save2;          // [tiles][V][9 | 11][64]   h~[8], v2 (, colour logit, raw rgb: RENDER)
     float* saveG;          // [tiles][17][64]     G[16] (log2e-scaled pre-activation incl. bias), 1/(sum m + 1e-8)
     float* saveZ;          // [tiles][18][64]     mean~[8], var~[8] (log2e / log2e^2 scaled), wbar, number of valid views
+    // range guard (RangeWatch): the pair kernels OR bit 1 into *range_flag when an operand leaves the fp16-pair range; a
+    // launch with only_if_flagged != 0 (the fp32-MFMA twin behind every pair launch) returns at once while the word is zero
+    unsigned* range_flag;
+    int only_if_flagged;
 };
 
 struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
@@ -449,38 +526,55 @@ DEV Taps make_taps(float u, float v, float sx, float sy, float off, int fh, int 
     return t;
 }
 
-constexpr int SW = 20;
-#ifndef GNR_VIEW_UNROLL
-#define GNR_VIEW_UNROLL 1
-#endif
-constexpr int view_unroll(int V) { return GNR_VIEW_UNROLL >= V ? V : ((GNR_VIEW_UNROLL >= 3 && V % 3 == 0) ? 3 : ((GNR_VIEW_UNROLL >= 2 && V % 2 == 0) ? 2 : 1)); }     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c rgb
-
-// GNR_ROW_SWITCH 1 (both view loops) / 2 (second view loop only): the per-view state S[V][SW] is addressed through wave-uniform branches on the view index (one
-// specialised copy of the 20-register row move per view) instead of being rotated by one row per view; needs
-// -mllvm -simplifycfg-sink-common=false, otherwise LLVM merges the arms into one access through a pointer phi and S
-// falls out of registers.
+constexpr int SW = 20;     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c . . . rgb
+// The per-view state S[V][SW] lives in registers, so its rows need static indices while the view loops stay rolled (code
+// size).  GNR_ROW_SWITCH 0 (default): S is a queue that advances one row per view -- 100 v_mov per view and loop, 1 440 per
+// tile, 8 % / 11 % of a volume / render launch (measured with the moves compiled out, GNR_ABLATE bit 0, tools/ab_chain.py).
+// GNR_ROW_SWITCH bit 0 / 1 (first / second view loop): a view's row is read / written through wave-uniform branches on the view
+// index instead (V arms of N moves, one of which executes: 20 out in the first loop, 19 in + 10 out in the second; GNR_ROW_ASM
+// 1 writes the moves as volatile inline asm, 0 as plain assignments, which needs -mllvm -simplifycfg-sink-common=false or LLVM
+// merges the arms into one access through a pointer phi and S drops to scratch).  Kept as a measured negative: every variant
+// spills (76 - 144 B of scratch against 12 - 60) and is slower: 3.76 / 4.31 ms (both loops, plain / asm), 3.63 / 3.64 (second
+// loop only), 3.91 / 4.18 (first loop only) against 3.56 ms per volume launch.  Also rejected: full unrolling
+// (code 83 KB > the 64 KB instruction cache, 900 B of scratch: 6.6 ms), two / three copies of the body per trip with the queue
+// advancing two / three rows (200 - 400 B of scratch: 4.85 ms), exchanging the halves of S with v_swap_b32 (6.4 cycles per
+// dword against 3.2 for v_mov_b32, tools/ubench/mov_rates.hip; v_mov_b64 / v_pk_mov_b32 move a dword in 2.8 / 3.1).
 #ifndef GNR_ROW_SWITCH
-#define GNR_ROW_SWITCH 0
+#define GNR_ROW_SWITCH 0          // bit 0: first view loop, bit 1: second view loop
 #endif
-template <int K, int V, int N>
-DEV void row_store(float (&S)[V][SW], int v, const float (&R)[N]) {
+#define GNR_RS1 ((GNR_ROW_SWITCH & 1) != 0)
+#define GNR_RS2 ((GNR_ROW_SWITCH & 2) != 0)
+#ifndef GNR_ROW_ASM
+#define GNR_ROW_ASM 1
+#endif
+// S[v][O .. O+N) = R   /   R = S[v][O .. O+N)   for a wave-uniform v
+template <int K, int O, int V, int N>
+DEV void row_put(float (&S)[V][SW], int v, const float (&R)[N]) {
     if constexpr (K < V) {
         if (v == K) {
 #pragma unroll
-            for (int q = 0; q < N; ++q) S[K][q] = R[q];
+#if GNR_ROW_ASM
+            for (int q = 0; q < N; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(S[K][O + q]) : "v"(R[q]));
+#else
+            for (int q = 0; q < N; ++q) S[K][O + q] = R[q];
+#endif
         } else {
-            row_store<K + 1, V, N>(S, v, R);
+            row_put<K + 1, O, V, N>(S, v, R);
         }
     }
 }
-template <int K, int V>
-DEV void row_load(const float (&S)[V][SW], int v, float (&R)[SW]) {
+template <int K, int O, int V, int N>
+DEV void row_get(float (&S)[V][SW], int v, float (&R)[N]) {
     if constexpr (K < V) {
         if (v == K) {
 #pragma unroll
-            for (int q = 0; q < SW; ++q) R[q] = S[K][q];
+#if GNR_ROW_ASM
+            for (int q = 0; q < N; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(R[q]) : "v"(S[K][O + q]));
+#else
+            for (int q = 0; q < N; ++q) R[q] = S[K][O + q];
+#endif
         } else {
-            row_load<K + 1, V>(S, v, R);
+            row_get<K + 1, O, V, N>(S, v, R);
         }
     }
 }
@@ -493,11 +587,15 @@ DEV void row_load(const float (&S)[V][SW], int v, float (&R)[SW]) {
 // SAVE: training forward (writes the states the backward twins need); compiled out of the inference kernels
 // USEVIS: the optional fourth decoder branch (dist_decoder_cfg.use_vis; GnrScene.use_vis), its own instantiations: as a
 // run-time branch it cost the default kernels 5 - 18 % (3.65 -> 3.82 ms volume, 1.29 -> 1.52 ms render launch)
-template <int V, bool RENDER, bool SAVE = false, bool USEVIS = false>
+// SP: the wide layers as fp16 pairs on the f16 matrix cores (the product's launches) / on the fp32-input MFMA (the range
+// guard's fallback, and every launch of the -DGNR_SPLIT16=0 companion build)
+template <int V, bool RENDER, bool SAVE = false, bool USEVIS = false, bool SP = (GNR_SPLIT16 != 0)>
 __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
-    constexpr bool SP = GNR_SPLIT16 != 0;
+    if (a.only_if_flagged && (a.range_flag == nullptr || __builtin_nontemporal_load(a.range_flag) == 0u)) return;   // wave-uniform
+    bool range_tripped = false;                           // wave-uniform
+    constexpr bool EP = SP && !SAVE;                       // e1 travels between the view loops as its fp16 pair (the training saves keep fp32)
 #define LO(o) (SP ? pk::c16_off(o) : (o))                  /* offset of a CHAIN-section name inside the staged image */                    // fp16-pair layers on the f16 matrix cores (C16 image) / fp32 MFMA (CHAIN image)
     // ---- stage the C16 (or CHAIN) section of the packed weights into LDS (once per workgroup)
     {
@@ -514,7 +612,6 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     const int tps = (a.P + 15) >> 4;                       // tiles per scene
     const int ntiles = a.B * tps;
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
-    constexpr int UNR = view_unroll(V);
     const float fsx = (float)a.fw / (float)(a.W - 1), fsy = (float)a.fh / (float)(a.H - 1);
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on
@@ -557,36 +654,44 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
         for (int k = 0; k < V; ++k)
 #pragma unroll
+#if GNR_ABLATE & 1
+            for (int q = 0; q < SW; ++q) S[k][q] = p[0] * (float)(k * SW + q + 1);      // opaque values: nothing downstream folds away
+#else
             for (int q = 0; q < SW; ++q) S[k][q] = 0.f;
+#endif
         float msum = 0.f;
         unsigned vbits = 0;
+#if GNR_ABLATE & 2
+        ViewGeom vg0;
+        project_view<true>(a.viewp + b * V * VIEWP_FLOATS, p, qd, a.H, a.W, vg0);
+        const Taps t0 = make_taps(vg0.u, vg0.v, fsx, fsy, -0.5f, a.fh, a.fw);
+        const Taps ti0 = make_taps(vg0.u, vg0.v, 1.f, 1.f, 0.f, a.H, a.W);
+#endif
 
         // ================= phase 1: per view, everything up to the first cross-view reduction
-        // The view loop stays rolled (code size) but runs UNR views per trip, back to back (the
-        // sched_barrier keeps the copies from being interleaved, which would spill), so the per-view
-        // register file S is rotated once per trip instead of once per view.
 #pragma unroll 1
-        for (int v0 = 0; v0 < V; v0 += UNR) {
-#if GNR_ROW_SWITCH != 1
+        for (int v = 0; v < V; ++v) {
+#if !GNR_RS1 && !(GNR_ABLATE & 1)
 #pragma unroll
-            for (int k = 0; k < V - UNR; ++k)
+            for (int k = 0; k < V - 1; ++k)
 #pragma unroll
-                for (int q = 0; q < SW; ++q) S[k][q] = S[k + UNR][q];
+                for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
 #endif
-#pragma unroll
-          for (int vu = 0; vu < UNR; ++vu) {
-            __builtin_amdgcn_sched_barrier(0);
+          {
             GNR_ITER_FENCE();
-            const int v = v0 + vu;
-#if GNR_ROW_SWITCH == 1
+#if GNR_RS1
             float Sv[SW];
 #else
-            float (&Sv)[SW] = S[V - UNR + vu];
+            float (&Sv)[SW] = S[V - 1];
 #endif
             const int bv = b * V + v;
             const float* vp = a.viewp + bv * VIEWP_FLOATS;
+#if GNR_ABLATE & 2
+            const ViewGeom vg = vg0;
+#else
             ViewGeom vg;
             project_view<true>(vp, p, qd, a.H, a.W, vg);
+#endif
             const float m = vg.m;
             msum += m;
             vbits |= (m != 0.f ? 1u : 0u) << v;
@@ -594,7 +699,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             // ---- gather: ray channels 8g..8g+7, image-feature channels 8g..8g+7, rgb channel g
             float FR[8], XI[9];
             {
+#if GNR_ABLATE & 2
+                const Taps t = t0;
+#else
                 const Taps t = make_taps(vg.u, vg.v, fsx, fsy, -0.5f, a.fh, a.fw);
+#endif
                 const float* fb = a.feat64 + (size_t)bv * a.fh * a.fw * 64 + 8 * g;
                 const f4* q00 = reinterpret_cast<const f4*>(fb + (size_t)t.o00 * 64);
                 const f4* q01 = reinterpret_cast<const f4*>(fb + (size_t)t.o01 * 64);
@@ -610,7 +719,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                     FR[4 * h] = fr.x; FR[4 * h + 1] = fr.y; FR[4 * h + 2] = fr.z; FR[4 * h + 3] = fr.w;
                     XI[4 * h] = fi.x; XI[4 * h + 1] = fi.y; XI[4 * h + 2] = fi.z; XI[4 * h + 3] = fi.w;
                 }
+#if GNR_ABLATE & 2
+                const Taps ti = ti0;
+#else
                 const Taps ti = make_taps(vg.u, vg.v, 1.f, 1.f, 0.f, a.H, a.W);
+#endif
                 const float* ib = a.imgs + ((size_t)bv * 3 + min(g, 2)) * a.H * a.W;
                 const float rgb = (ib[ti.o00] * ti.w00 + ib[ti.o01] * ti.w01 + ib[ti.o10] * ti.w10 + ib[ti.o11] * ti.w11) * m;
                 XI[8] = g < 3 ? rgb : 0.f;
@@ -630,7 +743,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 else mm<8, 2, 0, LF>(lds + LO(pk::DEC1) + br * frag_floats(8, 2), lane, FR, acc);
                 elu_to<2, !SP>(acc, h1);
                 load_bias<2, LF>(lds + LO(pk::B_DEC2) + br * 32, g, acc);
-                if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, &hp, acc); }
+                if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF, true>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, &hp, acc, &msum); }
                 else mm<8, 2, 0, LF>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, h1, acc);
                 elu_to<2, !SP>(acc, h2);
                 if (br < 2) {
@@ -658,7 +771,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                     else mm<8, 2, 0, LF>(lds + LO(pk::DECV1), lane, FR, acc);
                     elu_to<2, !SP>(acc, h1);
                     load_bias<2, LF>(lds + LO(pk::B_DECV2), g, acc);
-                    if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF>(lds + LO(pk::DECV2), lane, &hp, acc); }
+                    if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF, true>(lds + LO(pk::DECV2), lane, &hp, acc, &msum); }
                     else mm<8, 2, 0, LF>(lds + LO(pk::DECV2), lane, h1, acc);
                     elu_to<2, !SP>(acc, h2);
                     const float pv = sigmoid1(gsum(dot8(lds + LO(pk::T_DECV3), g, h2)) + lds[LO(pk::T_VIS)]);
@@ -681,9 +794,13 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                     e1[nb * 4 + 0] = fmaxf(acc[nb].x, 0.f); e1[nb * 4 + 1] = fmaxf(acc[nb].y, 0.f);
                     e1[nb * 4 + 2] = fmaxf(acc[nb].z, 0.f); e1[nb * 4 + 3] = fmaxf(acc[nb].w, 0.f);
                 }
-                // prob_embed.2 is folded into neuray_fc.0 / base_fc.0 on the host: the state kept per view is e1
+                // prob_embed.2 is folded into neuray_fc.0 / base_fc.0 on the host: the state kept per view is e1 -- as its fp16
+                // pair where nothing needs the fp32 values (inference, pair build), so that it is split once, not twice
+                if constexpr (EP) p8_store(split8<0>(e1), &Sv[9]);
+                else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) Sv[9 + j] = e1[j];
+                    for (int j = 0; j < 8; ++j) Sv[9 + j] = e1[j];
+                }
             }
             // ---- x = [rgb, img_feats] + ray_dir_fc(dir_diff)  (ibrnet.py:457-459)
             {
@@ -708,7 +825,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
                 for (int j = 0; j < 8; ++j) e[j] = Sv[9 + j];
                 load_bias<1, LF>(lds + LO(pk::B_NR1), g, acc1);
-                if constexpr (SP) { const P8 ep = split8<0>(e); mm16<1, 1, LF>(lds + LO(pk::NR1), lane, &ep, acc1); }
+                if constexpr (SP) { const P8 ep = EP ? p8_load(e) : split8<0>(e); mm16<1, 1, LF, true>(lds + LO(pk::NR1), lane, &ep, acc1, &msum); }
                 else mm<8, 1, 0, LF>(lds + LO(pk::NR1), lane, e, acc1);
                 elu_to<1, !SP>(acc1, n1);
                 Sv[17] = sigmoid1(gsum(dot4(lds + LO(pk::T_NR2), g, n1)) + lds[LO(pk::T_SCAL) + 0]);
@@ -719,11 +836,14 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
                 for (int q = 0; q < 19; ++q) sp[q * 64] = Sv[q];
             }
-#if GNR_ROW_SWITCH == 1
-            row_store<0, V, SW>(S, v, Sv);
+#if GNR_RS1 && !(GNR_ABLATE & 1)
+            row_put<0, 0, V, SW>(S, v, Sv);
+#elif GNR_RS1
+#pragma unroll
+            for (int q = 0; q < SW; ++q) S[V - 1][q] = Sv[q];
 #endif
             if (a.dbg && g == 0 && row_ok) { a.dbg[pt * 32 + v] = hit; a.dbg[pt * 32 + 8 + v] = vis; }
-        }
+          }
         }
 
         // ================= cross-view reduction 1 (ibrnet.py:466-472), in-lane
@@ -755,7 +875,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         load_bias<4, LF>(lds + LO(pk::B_HOIST), g, G);
         if constexpr (SP) {
             const P8 sp[5] = {split8<0>(SV), split8<8>(SV), split8<16>(SV), split8<24>(SV), split8z<32, 4>(SV)};
-            mm16<5, 4, LF>(lds + LO(pk::HOIST), lane, sp, G);
+            mm16<5, 4, LF, true>(lds + LO(pk::HOIST), lane, sp, G, &msum);
         } else mm<36, 4, 0, LF>(lds + LO(pk::HOIST), lane, SV, G);
         if (SAVE && a.saveG) {
             float* sp = a.saveG + ((size_t)b * tps + ts) * 17 * 64 + lane;
@@ -769,56 +889,33 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         // ================= phase 2: per view, base_fc / vis_fc / vis_fc2 (/ rgb_fc)
         float vsum = 0.f;
 #pragma unroll 1
-        for (int v0 = 0; v0 < V; v0 += UNR) {
-          // fully unrolled (UNR == V): every view works in place on its own row of S, nothing is copied or rotated
-          constexpr int CU = (UNR == V) ? 1 : UNR;
-          float X2[CU][9], E2[CU][8], m2[CU], rgb2[CU];
-#if GNR_ROW_SWITCH
-          static_assert(UNR == 1, "GNR_ROW_SWITCH needs the rolled view loop");
-          float Rv[SW];
-          row_load<0, V>(S, v0, Rv);
-#pragma unroll
-          for (int j = 0; j < 9; ++j) X2[0][j] = Rv[j];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) E2[0][j] = Rv[9 + j];
-          m2[0] = Rv[18]; rgb2[0] = Rv[19];
-          if constexpr (false) {
+        for (int v = 0; v < V; ++v) {
+          // GNR_RS2: the view's row is fetched, and its results put back, through branches on v.
+          // Queue form: the oldest row is copied out, the queue advances, the view's results become its last row.
+          constexpr int RN = (SAVE && RENDER) || !GNR_RS2 ? 20 : 19;     // the raw rgb (column 19) stays in its row
+          float Rv[RN];
+#if GNR_RS2 && !(GNR_ABLATE & 1)
+          row_get<0, 0, V, RN>(S, v, Rv);
 #else
-          if constexpr (UNR != V) {
+#pragma unroll
+          for (int j = 0; j < RN; ++j) Rv[j] = S[0][j];
+#if !GNR_RS2
+#if !(GNR_ABLATE & 1)
+#pragma unroll
+          for (int k = 0; k < V - 1; ++k)
+#pragma unroll
+              for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
 #endif
-#pragma unroll
-            for (int vu = 0; vu < UNR; ++vu) {
-#pragma unroll
-              for (int j = 0; j < 9; ++j) X2[vu][j] = S[vu][j];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) E2[vu][j] = S[vu][9 + j];
-              m2[vu] = S[vu][18]; rgb2[vu] = S[vu][19];
-            }
-#pragma unroll
-            for (int k = 0; k < V - UNR; ++k)
-#pragma unroll
-                for (int q = 0; q < SW; ++q) S[k][q] = S[k + UNR][q];
-          }
-#pragma unroll
-          for (int vu = 0; vu < UNR; ++vu) {
-            __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
+          {
             GNR_ITER_FENCE();
-            const int v = v0 + vu;
-#if GNR_ROW_SWITCH
-            float Sv[11];
-#else
-            float (&Sv)[SW] = S[V - UNR + vu];
-#endif
-            if constexpr (UNR == V && !GNR_ROW_SWITCH) {
+            float X[9], E[8];
 #pragma unroll
-              for (int j = 0; j < 9; ++j) X2[0][j] = Sv[j];
+            for (int j = 0; j < 9; ++j) X[j] = Rv[j];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) E2[0][j] = Sv[9 + j];
-              m2[0] = Sv[18]; rgb2[0] = Sv[19];
-            }
-            float (&X)[9] = X2[UNR == V ? 0 : vu];
-            float (&E)[8] = E2[UNR == V ? 0 : vu];
-            const float m = m2[UNR == V ? 0 : vu], rgbraw = rgb2[UNR == V ? 0 : vu];
+            for (int j = 0; j < 8; ++j) E[j] = Rv[9 + j];
+            const float m = Rv[18];
             const float w = m * inv_msum;
             float Hh[8];
             {
@@ -827,8 +924,8 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 if constexpr (SP) {
                     const float x8[1] = {X[8]};
                     mm<1, 4, 0, LF>(lds + LO(pk::BASE1) + 2 * pk::k32_floats(4), lane, x8, acc4);
-                    const P8 xe[2] = {split8<0>(X), split8<0>(E)};
-                    mm16<2, 4, LF>(lds + LO(pk::BASE1), lane, xe, acc4);
+                    const P8 xe[2] = {split8<0>(X), EP ? p8_load(E) : split8<0>(E)};
+                    mm16<2, 4, LF, true>(lds + LO(pk::BASE1), lane, xe, acc4, &msum);
                 } else {
                     mm<9, 4, 0, LF>(lds + LO(pk::BASE1), lane, X, acc4);
                     mm<8, 4, 9, LF>(lds + LO(pk::BASE1), lane, E, acc4);
@@ -836,7 +933,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 elu_to<4, !SP>(acc4, b1);
                 f4 acc[2];
                 load_bias<2, LF>(lds + LO(pk::B_BASE2), g, acc);
-                if constexpr (SP) { const P8 bp[2] = {split8<0>(b1), split8<8>(b1)}; mm16<2, 2, LF>(lds + LO(pk::BASE2), lane, bp, acc); }
+                if constexpr (SP) { const P8 bp[2] = {split8<0>(b1), split8<8>(b1)}; mm16<2, 2, LF, true>(lds + LO(pk::BASE2), lane, bp, acc, &msum); }
                 else mm<16, 2, 0, LF>(lds + LO(pk::BASE2), lane, b1, acc);
                 elu_to<2, !SP>(acc, Hh);
             }
@@ -847,11 +944,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * w;
                 load_bias<2, LF>(lds + LO(pk::B_VIS1), g, acc);
-                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF>(lds + LO(pk::VIS1), lane, &xp, acc); }
+                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF, true>(lds + LO(pk::VIS1), lane, &xp, acc, &msum); }
                 else mm<8, 2, 0, LF>(lds + LO(pk::VIS1), lane, xin, acc);
                 elu_to<2, !SP>(acc, v1);
                 load_bias<2, LF>(lds + LO(pk::B_VIS2), g, acc);
-                if constexpr (SP) { const P8 vp8 = split8<0>(v1); mm16<1, 2, LF>(lds + LO(pk::VIS2), lane, &vp8, acc); }
+                if constexpr (SP) { const P8 vp8 = split8<0>(v1); mm16<1, 2, LF, true>(lds + LO(pk::VIS2), lane, &vp8, acc, &msum); }
                 else mm<8, 2, 0, LF>(lds + LO(pk::VIS2), lane, v1, acc);
                 elu_to<2, !SP>(acc, res);
                 const float logit = elu1(gsum(dot8(lds + LO(pk::T_VIS2R), g, v1)) + lds[LO(pk::T_SCAL) + 1]);
@@ -866,7 +963,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * vis1;
                 load_bias<2, LF>(lds + LO(pk::B_VISB1), g, acc);
-                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF>(lds + LO(pk::VISB1), lane, &xp, acc); }
+                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF, true>(lds + LO(pk::VISB1), lane, &xp, acc, &msum); }
                 else mm<8, 2, 0, LF>(lds + LO(pk::VISB1), lane, xin, acc);
                 elu_to<2, !SP>(acc, t1);
                 v2 = sigmoid1(gsum(dot8(lds + LO(pk::T_VISB2), g, t1)) + lds[LO(pk::T_SCAL) + 2]) * m;   // :481
@@ -882,7 +979,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 load_bias<1, LF>(lds + LO(pk::B_RGB1), g, acc1);
                 const float ex[2] = {g == 0 ? v2 : (g == 1 ? vg.dd[0] : (g == 2 ? vg.dd[1] : vg.dd[2])), g == 0 ? vg.dd[3] : 0.f};
                 mm<2, 1, 8, LF>(lds + LO(pk::RGB1), lane, ex, acc1);
-                if constexpr (SP) { const P8 hp = split8<0>(Hh); mm16<1, 1, LF>(lds + LO(pk::RGB1), lane, &hp, acc1); }
+                if constexpr (SP) { const P8 hp = split8<0>(Hh); mm16<1, 1, LF, true>(lds + LO(pk::RGB1), lane, &hp, acc1, &msum); }
                 else mm<8, 1, 0, LF>(lds + LO(pk::RGB1), lane, Hh, acc1);
                 elu_to<1, !SP>(acc1, c1);
                 load_bias<1, LF>(lds + LO(pk::B_RGB2), g, acc1);
@@ -891,22 +988,29 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 clog = gsum(dot4(lds + LO(pk::T_RGB3), g, c2)) + lds[LO(pk::T_SCAL) + 3];
                 if (m == 0.f) clog = -1e9f;
             }
+            float Ov[10];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Sv[j] = Hh[j];
-            Sv[8] = v2;
-            Sv[9] = clog;
-            Sv[10] = rgbraw;
+            for (int j = 0; j < 8; ++j) Ov[j] = Hh[j];
+            Ov[8] = v2;
+            Ov[9] = clog;
             if (SAVE && a.save2) {
                 constexpr int S2W = RENDER ? 11 : 9;
                 float* sp = a.save2 + (((size_t)b * tps + ts) * V + v) * S2W * 64 + lane;
 #pragma unroll
-                for (int q = 0; q < S2W; ++q) sp[q * 64] = Sv[q];
+                for (int q = 0; q < (S2W < 10 ? S2W : 10); ++q) sp[q * 64] = Ov[q];
+                if constexpr (RENDER) sp[10 * 64] = Rv[RN - 1];
             }
-#if GNR_ROW_SWITCH
-            row_store<0, V, 11>(S, v, Sv);
+#if GNR_RS2 && !(GNR_ABLATE & 1)
+            row_put<0, 0, V, 10>(S, v, Ov);
+#else
+#pragma unroll
+            for (int j = 0; j < 10; ++j) S[V - 1][j] = Ov[j];
+#if !GNR_RS2
+            S[V - 1][19] = Rv[19];
+#endif
 #endif
             if (a.dbg && g == 0 && row_ok) a.dbg[pt * 32 + 16 + v] = v2;
-        }
+          }
         }
 
         // ================= cross-view reduction 2 (ibrnet.py:482-484,488) + colour blend (:510-511)
@@ -933,7 +1037,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             for (int v = 0; v < V; ++v) cmax = fmaxf(cmax, S[v][9]);
             float den = 0.f, num = 0.f;
 #pragma unroll
-            for (int v = 0; v < V; ++v) { const float e = __expf(S[v][9] - cmax); den += e; num += S[v][10] * e; }
+            for (int v = 0; v < V; ++v) { const float e = __expf(S[v][9] - cmax); den += e; num += S[v][19] * e; }
             if (g < 3 && row_ok) a.colors[pt * 3 + g] = num * rcp1(den);
         }
         if (SAVE && a.saveZ) {
@@ -946,9 +1050,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         {
             const float pc = g == 1 ? p[0] : (g == 2 ? p[1] : p[2]);
             float s1, c1, s2, c2, s4, c4;
-            sincosf(pc, &s1, &c1);
-            sincosf(2.f * pc, &s2, &c2);
-            sincosf(4.f * pc, &s4, &c4);
+            sincos_octaves(pc, s1, c1, s2, c2, s4, c4);
             const bool g0 = g == 0;
             Z[16] = g0 ? wbar : pc; Z[17] = g0 ? 0.f : s1; Z[18] = g0 ? 0.f : c1; Z[19] = g0 ? 0.f : s2;
             Z[20] = g0 ? 0.f : c2; Z[21] = g0 ? 0.f : s4; Z[22] = g0 ? 0.f : c4;
@@ -958,17 +1060,18 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         load_bias<4, LF>(lds + LO(pk::B_GEO1), g, U);
         if constexpr (SP) {
             const P8 zp[3] = {split8<0>(Z), split8<8>(Z), split8z<16, 7>(Z)};
-            mm16<3, 4, LF>(lds + LO(pk::GEO1), lane, zp, U);
+            mm16<3, 4, LF, true>(lds + LO(pk::GEO1), lane, zp, U, &msum);
         } else mm<23, 4, 0, LF>(lds + LO(pk::GEO1), lane, Z, U);
         elu_to<4, !SP>(U, u64);
         f4 g16[1];
         load_bias<1, LF>(lds + LO(pk::B_GEO2), g, g16);
-        if constexpr (SP) { const P8 up[2] = {split8<0>(u64), split8<8>(u64)}; mm16<2, 1, LF>(lds + LO(pk::GEO2), lane, up, g16); }
+        if constexpr (SP) { const P8 up[2] = {split8<0>(u64), split8<8>(u64)}; mm16<2, 1, LF, true>(lds + LO(pk::GEO2), lane, up, g16, &msum); }
         else mm<16, 1, 0, LF>(lds + LO(pk::GEO2), lane, u64, g16);
         float gg[4];
         elu_to<1, !SP>(g16, gg);
 
         // ================= record
+        if constexpr (SP && GNR_RANGE_GUARD != 0) range_tripped |= __ballot(msum != msum) != 0;
         if (row_ok) {
             float* rec = a.rec + pt * REC;
             const f4 gv = {gg[0] * kLn2, gg[1] * kLn2, gg[2] * kLn2, gg[3] * kLn2};    // back to true scale
@@ -989,6 +1092,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 d[24] = msum; d[25] = wbar; d[26] = Z[0] * kLn2; d[27] = Z[8] * kLn2 * kLn2; d[28] = SV[8]; d[29] = G[0].x * kLn2; d[30] = gg[0] * kLn2; d[31] = vsum;
             }
         }
+    }
+    if constexpr (SP) {      // range guard
+        if (a.range_flag && range_tripped && lane == 0) atomicOr(a.range_flag, 2u);
     }
 }
 
@@ -1368,7 +1474,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
         for (int c = 0; c < 3; ++c) {
             const float pc = pp[c];
             float s1, c1, s2, c2, s4, c4;
-            sincosf(pc, &s1, &c1); sincosf(2.f * pc, &s2, &c2); sincosf(4.f * pc, &s4, &c4);
+            sincos_octaves(pc, s1, c1, s2, c2, s4, c4);
             grad[c] = de[c] + c1 * de[3 + c] - s1 * de[6 + c] + 2.f * c2 * de[9 + c] - 2.f * s2 * de[12 + c]
                       + 4.f * c4 * de[15 + c] - 4.f * s4 * de[18 + c];
         }

@@ -81,6 +81,19 @@ class HotPath:
         self._prepared = (scene, keep, ws)
         return self._prepared
 
+    def range_status(self, prepared=None):
+        """Watch word of the range guard for the last prepare() (include/gnr.h gnr_range_status; synchronises the stream):
+        0 = every chain launch ran in the fp16-pair form; bit 0 / bit 1 = a feature / an activation left its range and the
+        launches were recomputed by the fp32-MFMA twin."""
+        scene, keep, ws = prepared or self._prepared
+        flags = C.c_uint(0)
+        _lib.check(self.L.gnr_range_status(C.byref(scene), ws.data_ptr(), ws.numel(), C.byref(flags), self._stream()), 'gnr_range_status')
+        return int(flags.value)
+
+    def force_fp32_chain(self, on):
+        """Process-wide test / measurement switch: every chain launch on the fp32-input MFMA (-> previous setting)."""
+        return bool(self.L.gnr_force_fp32_chain(1 if on else 0))
+
     # ---- sample_volume (ref: renderer.py:164-199) ------------------------------------------
     def sample_volume(self, ref, res=40, want_mask=False, prepared=None):
         scene, keep, ws = prepared or self.prepare(ref, res)

@@ -119,6 +119,18 @@ size_t gnr_workspace_bytes(const GnrScene* scene, int volume_res, int rn, int dn
  * Must precede the forward calls that use the same workspace (stream ordered). */
 int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Range guard.  The reference computes in fp32 everywhere (ibrnet.py:474-482; SURVEY.md 5 "mixed precision: none").  The chain
+ * kernel multiplies on the f16 matrix cores with every fp32 operand carried as an fp16 pair, whose high half cannot hold a
+ * magnitude of 65 520 or more.  Each forward (and training-forward) chain launch therefore watches its operands (feature maps in
+ * gnr_prepare, activations and cross-view statistics in the kernel) and is followed by its fp32-input-MFMA twin, which returns
+ * immediately unless the watch tripped and otherwise recomputes the launch: out-of-range scenes get the fp32 kernel's values,
+ * in-range scenes pay ~5 us per chain launch, and no call synchronises with the host.
+ * gnr_range_status reads the watch word of the last gnr_prepare on this workspace (synchronises `stream`):
+ *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range.
+ * gnr_force_fp32_chain(1) makes every chain launch run the fp32-MFMA kernel (tests, measurements); returns the old setting. */
+int gnr_range_status(const GnrScene* scene, const void* workspace, size_t workspace_bytes, unsigned* flags_out, void* stream);
+int gnr_force_fp32_chain(int on);
+
 /* sample_volume (renderer.py:164-199), volume_type [sdf]:
  *   sdf_out[b,x,y,z] for voxel centre bbox_min[b] + ((x,y,z)+.5)*(0.3/res).
  *   view_mask_out: optional [B, res^3] bytes in (x,y,z) order, bit v = in-image mask of view v. */

@@ -21,7 +21,26 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-F32 = torch.float32
+F32 = torch.float32          # the working dtype: torch.float32 like the reference; fp64_mode() switches it to float64
+
+
+class fp64_mode:
+    """`with fp64_mode():` runs the same restatement in float64 (inputs and weights are given as float64 tensors holding
+    the fp32 values exactly: to_torch64).  The ARBITER of the GPU parity tests (tests/test_gpu_precision.py): the distance
+    of the HIP path from these values is compared with the distance of the fp32 oracle (= the reference's arithmetic) from
+    them.  Index decisions (floor of a tap, in-image tests, searchsorted) are taken in float64 too, so single points that
+    sit within an fp32 rounding of such an edge can differ by a whole tap; the tests compare through quantiles."""
+
+    def __enter__(self):
+        global F32
+        self.prev = F32
+        F32 = torch.float64
+        return self
+
+    def __exit__(self, *exc):
+        global F32
+        F32 = self.prev
+        return False
 
 
 # ----------------------------------------------------------------------------------------
@@ -40,7 +59,7 @@ def grid_points(res, volume_size=0.3):
 def volume_query_points(res, bbox_min):
     """Points of sample_volume in column order: [res*res columns, res samples, 3], sample 0 =
     TOP voxel (z flipped).  ref: renderer.py:167-170."""
-    p = torch.from_numpy(grid_points(res)) + torch.as_tensor(bbox_min, dtype=F32)
+    p = (torch.from_numpy(grid_points(res)) + torch.as_tensor(bbox_min, dtype=torch.float32)).to(F32)   # the points are fp32 INPUTS of the path
     p = p.reshape(res * res, res, 3)
     return torch.flip(p, (1,))
 
@@ -200,7 +219,7 @@ def sinusoid_table(n, d=16):
     tab = ang.copy()
     tab[:, 0::2] = np.sin(ang[:, 0::2])
     tab[:, 1::2] = np.cos(ang[:, 1::2])
-    return torch.from_numpy(tab).float()
+    return torch.from_numpy(tab).float().to(F32)       # (the reference's table is fp32: rounded first)
 
 
 # ----------------------------------------------------------------------------------------
@@ -302,7 +321,7 @@ def sample_volume(sd, inp, res=40, dec='dist_decoder.', agg='agg_net.', debug=No
         uv, z, mask, dirv = project_points(pts, inp['poses'], inp['Ks'], h, w)
         f_ray, rgb, f_img = gather_views(inp, uv, mask)
         hit, vis = decode_hit_vis(sd, dec, f_ray, z, mask, inp['depth_range'], 0.005, 0.005)
-        qdir = torch.tensor([0., 0., 1.]).expand(pts.shape[0], 3)        # renderer.py:179
+        qdir = torch.tensor([0., 0., 1.], dtype=F32).expand(pts.shape[0], 3)        # renderer.py:179
     o = aggregate(sd, agg, f_ray, rgb, f_img, hit, vis, mask, dirv, qdir, pts, res * res, res,
                   want_grad=False, want_rgb=False, debug=debug)
     if debug is not None:
@@ -320,7 +339,7 @@ def sample_depth(depth_range, rn, dn):
     diff = 1 / far - 1 / near
     interval = diff / (dn - 1)
     val = torch.arange(1, dn - 1, dtype=F32)
-    ticks = torch.cat([torch.zeros(1), interval * val, diff.reshape(1)])
+    ticks = torch.cat([torch.zeros(1, dtype=F32), interval * val, diff.reshape(1)])
     return (1 / (1 / near + ticks))[None].expand(rn, dn).contiguous()
 
 
@@ -329,7 +348,7 @@ def ray_points(coords, pose, K, depth):
     ref: render_ops.py:4-39 (directions unnormalised, so `depth` is camera-z)."""
     rot = pose[:, :3].t()
     trans = -rot @ pose[:, 3:]                                            # [3,1]
-    hc = torch.cat([coords, torch.ones(coords.shape[0], 1)], 1)
+    hc = torch.cat([coords, torch.ones(coords.shape[0], 1, dtype=F32)], 1)
     cam = torch.inverse(K) @ hc.t()                                       # [3,rn]
     d = (rot @ cam + trans - trans).t()                                   # :22-23
     pts = trans.t()[:, None] + d[:, None] * depth[..., None]
@@ -475,3 +494,8 @@ def render(sd, inp, que, cfg=None, debug=None, fine_depth_override=None, fine_u=
 def to_torch(d):
     return {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
             for k, v in d.items()}
+
+
+def to_torch64(d):
+    """The same fp32 values as float64 tensors (for fp64_mode)."""
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in to_torch(d).items()}
