@@ -11,6 +11,10 @@ Scenes are independent, so N GPUs shard scenes with no data-path collective (wea
 Before any timing is accepted rank 0 runs a PARITY GATE: scene 0 of its batch is the scene tests/golden/golden_cfg2.npz pins
 (outputs of the imported reference), and the batched launch must reproduce it.
 
+`--dist-backend gloo --stub-step-ms T` runs the SAME control flow without a GPU (the step is a sleep): the N > 1 branches --
+RCCL rank count, barrier + MAX-over-ranks, per-rank gather, parity-gate failure propagation, the train leg's all-reduce
+record -- are executed under gloo by tests/test_bench_dist.py, so the first multi-GPU lease does not debug them.
+
 After the forward leg the same process measures, outside the headline's timed region and reported as sub-records of the ONE
 JSON line rank 0 prints:  `train_step` = BASELINE.json configs[4] (8 full-size scenes per GPU: backbones + volumetric path +
 grasp head + losses, backward, one flat gradient all-reduce over RCCL, Adam);  `with_backbones` = images -> volume + render +
@@ -58,39 +62,71 @@ def chain_flops(points, views, render):
     return 2.0 * points * (views * (MAC_VIEW_RAY if render else MAC_VIEW_VOL) + MAC_POINT_CHAIN)
 
 
-def recorded_bwd_traffic(scenes):
-    """HBM-side bytes per launch of k_view1_bwd (volume points, 8 scenes) from the same recorded PMC passes, or None."""
+def source_sha16(*names):
+    """sha256 of kernel source files (graspnerf_amd/csrc/<name>), first 16 hex digits: ties recorded counters to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(ROOT, 'graspnerf_amd', 'csrc', n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def newest_pmc(stamp_key, *sources):
+    """The newest committed profiles/r*_pmc_counters.json (tools/collect_profiles.sh), or None when its stamp `stamp_key`
+    (written by tools/pmc_summary.py) is not the sha256 of the CURRENT kernel sources: counters of another build are not
+    reported."""
+    import glob
     try:
-        import glob
         newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
-        k = json.load(open(newest))['kernels']['k_view1_bwd']
-        return (int(k['hbm_bytes_corrected']), os.path.relpath(newest, ROOT)) if scenes == 8 else (None, None)
-    except (OSError, KeyError, ValueError, IndexError):
+        d = json.load(open(newest))
+        if d.get(stamp_key) != source_sha16(*sources):
+            return None, None
+        return d, os.path.relpath(newest, ROOT)
+    except (OSError, ValueError, IndexError):
+        return None, None
+
+
+def recorded_bwd_traffic(scenes):
+    """HBM-side bytes per launch of k_view1_bwd (volume points, 8 scenes) from the recorded PMC passes, or None."""
+    d, src = newest_pmc('bwd_source_sha16', 'gnr_kernels.hip', 'gnr_bwd.inc')
+    try:
+        return (int(d['kernels']['k_view1_bwd']['hbm_bytes_corrected']), src) if (d and scenes == 8) else (None, None)
+    except KeyError:
         return None, None
 
 
 def recorded_pmc(batch):
     """Counters of the dominant kernel from the committed rocprofv3 PMC passes (newest profiles/r*_pmc_counters.json, made by
     tools/collect_profiles.sh: separate --pmc runs, gfx950 2x read correction applied to FETCH_SIZE).  PMC counters cannot be
-    read from inside this process: the figures are the recorded ones of that build, labelled with their source, and only
-    reported for the batch size they were measured at."""
+    read from inside this process: the figures are the recorded ones, reported only when the file is stamped with the sha256
+    of the kernel source this run was built from (`kernel_source_sha16`) and for the batch size they were measured at.
+    -> (traffic bytes per launch, counters dict, valu dict) or (None, None, None)."""
+    d, src = newest_pmc('kernel_source_sha16', 'gnr_kernels.hip')
     try:
-        import glob
-        newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
-        k = next(v for n, v in json.load(open(newest))['kernels'].items() if n.startswith('k_chain<6, false'))
-        if batch != 32:
-            return None, None
-        return int(k['hbm_bytes_corrected']), {
-            'source': os.path.relpath(newest, ROOT),
-            # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
-            'mfma_pipe_busy': round(k['SQ_VALU_MFMA_BUSY_CYCLES'] / (k['GRBM_GUI_ACTIVE'] / 8 * 1024), 3),
+        if d is None or batch != 32:
+            return None, None, None
+        k = next(v for n, v in d['kernels'].items() if n.startswith('k_chain<6, false, false, false'))
+        cycles = k['GRBM_GUI_ACTIVE'] / 8                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        simds = 1024
+        tiles = 32 * 64000 / 16
+        valu_insts = k['SQ_INSTS_VALU'] - k['SQ_INSTS_MFMA']          # SQ_INSTS_VALU counts the MFMAs too
+        counters = {
+            'source': src, 'kernel_source_sha16': d['kernel_source_sha16'],
+            'mfma_pipe_busy': round(k['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * simds), 3),   # summed over the 1024 SIMDs
             'l2_hit_rate': round(k['TCC_HIT_sum'] / (k['TCC_HIT_sum'] + k['TCC_MISS_sum']), 3),
-            # SQ_ACTIVE_INST_VALU counts quad-cycles over all wavefronts: x4 / (cycles x SIMDs) = share of the SIMDs' time a
-            # VALU (non-matrix) instruction is executing
-            'valu_busy': round(4 * k['SQ_ACTIVE_INST_VALU'] / (k['GRBM_GUI_ACTIVE'] / 8 * 1024), 3) if 'SQ_ACTIVE_INST_VALU' in k else None,
             'mfma_per_launch': k['SQ_INSTS_MFMA'], 'valu_incl_mfma_per_launch': k['SQ_INSTS_VALU']}
-    except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError, StopIteration):
-        return None, None
+        # the resource that binds k_chain (DESIGN.md 4.3): VALU issue.  SQ_ACTIVE_INST_VALU counts quad-cycles over all
+        # wavefronts; a SIMD executes one VALU instruction at a time (16 lanes: 4 cycles per wave64 instruction)
+        valu = {'instructions_per_tile': round(valu_insts / tiles, 1),
+                'cycles_per_instruction': round(4 * k['SQ_ACTIVE_INST_VALU'] / k['SQ_INSTS_VALU'], 3),
+                'issue_cycles_per_simd': round(4 * k['SQ_ACTIVE_INST_VALU'] / simds, 0),
+                'available_cycles_per_simd': round(cycles, 0),
+                'frac': round(4 * k['SQ_ACTIVE_INST_VALU'] / (cycles * simds), 3),
+                'note': 'share of the SIMDs\' cycles in which a vector instruction (incl. the MFMA issue slot) executes; what is left '
+                        'is the matrix pipe alone (mfma_pipe_busy overlaps partly) and stalls on LDS / memory counters'}
+        return int(k['hbm_bytes_corrected']), counters, valu
+    except (KeyError, ValueError, ZeroDivisionError, StopIteration):
+        return None, None, None
 
 
 # ---- parity gate -----------------------------------------------------------------------------------------------------
@@ -149,11 +185,12 @@ def parity_gate(hp, bref, bque, vol, co, fi_free, inds):
 # ---- CPU baseline (the oracle; reported at N = 1 only) ---------------------------------------------------------------
 def cpu_baseline(weights_np):
     """SURVEY.md §8d protocol: the oracle (torch-CPU fp32 port of the reference path; the only place bench.py touches
-    oracle/) on whole scenes of the same workload: 3 warm-ups, median of 10, plus a 1-thread figure."""
+    oracle/) on whole scenes of the same workload: 3 warm-ups + median of 10 at 16 threads (torch's intra-op pool stops
+    scaling well below the hardware threads of the GPU box on these op sizes: the figure reported as `value`), the same at
+    os.cpu_count() threads (SURVEY's protocol to the letter; median of 5), and one scene on one thread."""
     from oracle import graspnerf_oracle as O
-    # torch's intra-op pool stops scaling (and collapses from oversubscription) well below the hardware threads of the GPU box
-    # on these op sizes; 16 threads is what we actually use and report
-    cores = min(os.cpu_count() or 1, 16)
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 16)
     W = {k: torch.from_numpy(v) for k, v in weights_np.items()}
     ref, que = make_scene(0, 'cfg2')
     inp, q = O.to_torch(ref), O.to_torch(que)
@@ -168,14 +205,22 @@ def cpu_baseline(weights_np):
         one()
     ts = sorted(one() for _ in range(10))
     med = 0.5 * (ts[4] + ts[5])
+    all_cores = None
+    if ncpu > cores:
+        torch.set_num_threads(ncpu)
+        one()
+        ta = sorted(one() for _ in range(5))
+        all_cores = {'cores': ncpu, 'value': round(1.0 / ta[2], 4), 'median_s': round(ta[2], 3)}
     torch.set_num_threads(1)
     t1 = one()
     torch.set_num_threads(cores)
-    return {'value': round(1.0 / med, 4), 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
-            'value_1_thread': round(1.0 / t1, 4),
+    best = max(1.0 / med, all_cores['value'] if all_cores else 0.0)
+    return {'value': round(best, 4), 'unit': 'scenes/s', 'cores': cores if best == 1.0 / med or not all_cores else ncpu, 'kind': 'port',
+            'value_16_threads': round(1.0 / med, 4), 'all_cores': all_cores, 'value_1_thread': round(1.0 / t1, 4),
             'sample': f'whole scenes (6 views 288x512, 40^3 volume + 512 rays x (40+40) samples), oracle/graspnerf_oracle.py (torch '
                       f'{torch.__version__} CPU fp32): 3 warm-ups + median of 10 at {cores} threads ({med:.3f} s, min {ts[0]:.3f}, max '
-                      f'{ts[-1]:.3f}); 1 thread: one scene ({t1:.2f} s)'}
+                      f'{ts[-1]:.3f}); median of 5 at all {ncpu} hardware threads; 1 thread: one scene ({t1:.2f} s); value = the faster '
+                      f'of the two multi-thread figures'}
 
 
 # ---- BASELINE.json configs[4]: end-to-end train step -----------------------------------------------------------------
@@ -207,7 +252,8 @@ def f32_mfma_build_leg(value):
         return {'skipped': f'{type(e).__name__}: {e}'[:200]}
     return {'library': 'graspnerf_amd/csrc/libgnr_f32mfma.so (-DGNR_SPLIT16=0)', 'value': d['value'], 'unit': d['unit'], 'steps': d['steps'],
             'ms_per_step': d['ms_per_step'], 'parity_checked': d['parity_checked'],
-            'k_chain_volume_ms_per_launch': d['roofline']['ms_per_launch'], 'frac_of_fp32_mfma_peak': d['roofline']['frac'],
+            'k_chain_volume_ms_per_launch': d['roofline']['ms_per_launch'],
+            'frac_of_fp32_mfma_peak': round(d['roofline']['algorithmic_fp32_equiv']['tflops'] / PEAK_F32_MFMA_TFLOPS, 4),
             'product_speedup': round(value / d['value'], 3)}
 
 
@@ -236,8 +282,13 @@ def train_scenes(n, first, dev):
 
 
 def ev_ms(fn, iters=3):
-    """Average milliseconds of fn() on the current stream (torch events; one untimed call first)."""
+    """Average milliseconds of fn() on the current stream (torch events; one untimed call first); wall clock without a GPU."""
     fn()
+    if not torch.cuda.is_available():
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        return (time.perf_counter() - t0) / iters * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -335,13 +386,41 @@ def train_leg(args, world, rank, dev, dist, sync):
         rec['isolated_ms'] = {'backbones_fwd_bwd': round(ev_ms(backbones), 3), 'grasp_head_fwd_bwd': round(ev_ms(head), 3)}
         net.zero_grad(set_to_none=True)
     if dist is not None and world > 1:
-        # the step's only collective, alone: sum all-reduce of the flat fp32 gradient buffer (+1 scene counter)
-        flat = torch.zeros(sum(p.numel() for p in net.parameters()) + 1, device=dev)
-        ms = ev_ms(lambda: dist.all_reduce(flat), iters=10)
+        ar = allreduce_record(dist, world, sum(p.numel() for p in net.parameters()), dev)
         if rank == 0:
-            rec['allreduce'] = {'bytes': flat.numel() * 4, 'ms': round(ms, 4), 'GBps_bus': round(2 * (world - 1) / world * flat.numel() * 4 / (ms * 1e-3) / 1e9, 2)}
+            rec['allreduce'] = ar
     del tr, net
     torch.cuda.empty_cache()
+    return rec
+
+
+def allreduce_record(dist, world, n_params, dev):
+    """The train step's only collective, alone: sum all-reduce of the flat fp32 gradient buffer (+1 scene counter)."""
+    flat = torch.zeros(n_params + 1, device=dev)
+    ms = ev_ms(lambda: dist.all_reduce(flat), iters=10)
+    return {'bytes': flat.numel() * 4, 'ms': round(ms, 4), 'GBps_bus': round(2 * (world - 1) / world * flat.numel() * 4 / (ms * 1e-3) / 1e9, 2)}
+
+
+def train_leg_stub(args, world, rank, dev, dist, sync):
+    """--stub-step-ms: the control flow of train_leg without a GPU (a step = a sleep four times the forward stub): barrier +
+    MAX-over-ranks timing and the all-reduce record (the model has 4 659 307 parameters)."""
+    n, K = args.train_scenes, args.train_steps
+    for _ in range(min(args.train_warmup, 2)):
+        time.sleep(4e-3 * args.stub_step_ms)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        time.sleep(4e-3 * args.stub_step_ms)
+    sync()
+    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    rec = None
+    if rank == 0:
+        rec = {'metric': 'train scenes/sec (stub)', 'value': round(world * n * K / dt, 3), 'unit': 'scenes/s', 'ms_per_step': round(dt / K * 1e3, 3),
+               'steps': K, 'scenes_per_gpu': n, 'global_batch': world * n, 'n_gpus': world, 'data': 'stub (no GPU work)'}
+    if dist is not None and world > 1:
+        ar = allreduce_record(dist, world, 4659307, dev)
+        if rank == 0:
+            rec['allreduce'] = ar
     return rec
 
 
@@ -369,6 +448,21 @@ def backbone_leg(hp, bref, bque, dev, B, step_ms):
                     f'grasp head, run back to back; synthetic weights'}
 
 
+class StubPath:
+    """--stub-step-ms: stands in for HotPath + the library's timing hooks when there is no GPU (tests/test_bench_dist.py runs the
+    N > 1 control flow of this file under gloo).  A step is a sleep; the kernel tables are made up from it."""
+
+    def __init__(self, ms):
+        self.ms = ms
+        self.device = torch.device('cpu')
+
+    def step(self):
+        time.sleep(self.ms * 1e-3)
+
+    def table(self, steps):
+        return {'k_chain.volume': (steps, 0.5 * self.ms * steps), 'k_chain.render': (2 * steps, 0.3 * self.ms * steps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -382,45 +476,61 @@ def main():
     ap.add_argument('--train-scenes', type=int, default=8)
     ap.add_argument('--train-steps', type=int, default=8)
     ap.add_argument('--train-warmup', type=int, default=10, help='the caching allocators and MIOpen settle over ~10 steps')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (the product); gloo only with --stub-step-ms')
+    ap.add_argument('--stub-step-ms', type=float, default=0.0, help='> 0: no GPU, a step is a sleep of this length (control-flow test of the N > 1 branches)')
+    ap.add_argument('--stub-parity-fail', action='store_true', help='with --stub-step-ms: rank 0 fails its parity gate (every rank must exit 3)')
     args = ap.parse_args()
+    stub = args.stub_step_ms > 0
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})')
-    if not torch.cuda.is_available():
-        sys.exit('bench.py needs a ROCm GPU; the hot path has no CPU fallback')
-    torch.cuda.set_device(local)
+    if args.dist_backend == 'gloo' and not stub:
+        sys.exit('--dist-backend gloo is for --stub-step-ms runs: the product communicates over RCCL')
+    if not stub:
+        if not torch.cuda.is_available():
+            sys.exit('bench.py needs a ROCm GPU; the hot path has no CPU fallback')
+        torch.cuda.set_device(local)
     dist = None
     if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:      # under torch.distributed.run, also for one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if stub:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world, device_id=torch.device('cuda', local))
 
-    from graspnerf_amd.hotpath import HotPath, batch_scenes
-    wnp = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'weights_seed0.npz')))
-    hp = HotPath(weights.pack_state_dict(wnp, 'coarse'), weights.pack_state_dict(wnp, 'fine'), device=f'cuda:{local}')
     B = args.batch
     c = CONFIGS['cfg2']
     lo, hi = scene_shard(world * B, rank, world)          # contiguous block of the global scene list
-    scenes = [make_scene(i, 'cfg2') for i in range(lo, hi)]
-    bref, bque = batch_scenes(scenes)
-    dev = hp.device
-    bref = {k: torch.from_numpy(v).to(dev) for k, v in bref.items()}          # inputs resident in HBM
-    bque = {k: torch.from_numpy(v).to(dev) for k, v in bque.items()}
     res, rn, dn = c['res'], c['rn'], 40
+    wnp = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'weights_seed0.npz')))
+    if stub:
+        hp = StubPath(args.stub_step_ms)
+        dev = hp.device
+        step = hp.step
+    else:
+        from graspnerf_amd.hotpath import HotPath, batch_scenes
+        hp = HotPath(weights.pack_state_dict(wnp, 'coarse'), weights.pack_state_dict(wnp, 'fine'), device=f'cuda:{local}')
+        scenes = [make_scene(i, 'cfg2') for i in range(lo, hi)]
+        bref, bque = batch_scenes(scenes)
+        dev = hp.device
+        bref = {k: torch.from_numpy(v).to(dev) for k, v in bref.items()}          # inputs resident in HBM
+        bque = {k: torch.from_numpy(v).to(dev) for k, v in bque.items()}
 
-    def step():
-        prep = hp.prepare(bref, res, rn, dn)
-        vol = hp.sample_volume(bref, res, prepared=prep)
-        co, fi = hp.render(bref, bque, prepared=prep)
-        return vol, co, fi
+        def step():
+            prep = hp.prepare(bref, res, rn, dn)
+            vol = hp.sample_volume(bref, res, prepared=prep)
+            co, fi = hp.render(bref, bque, prepared=prep)
+            return vol, co, fi
 
     def sync():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     rccl_ranks = None
     if dist is not None:                                  # an actual collective over RCCL: every rank contributes 1
@@ -433,23 +543,30 @@ def main():
         step()
     # ---- parity gate in front of the timed region (rank 0 holds scene 0 = the scene the reference golden pins)
     parity = None
+    range_flags = None
     if rank == 0 and B >= 1:
-        prep = hp.prepare(bref, res, rn, dn)
-        vol = hp.sample_volume(bref, res, prepared=prep)
-        co, fi, inds = hp.render(bref, bque, prepared=prep, debug=True)
-        torch.cuda.synchronize()
         try:
-            parity = parity_gate(hp, bref, bque, vol, co, fi, inds)
+            if stub:
+                if args.stub_parity_fail:
+                    raise SystemExit('parity gate FAILED: (stub) forced failure')
+                parity = {'stub': 0.0}
+            else:
+                prep = hp.prepare(bref, res, rn, dn)
+                vol = hp.sample_volume(bref, res, prepared=prep)
+                co, fi, inds = hp.render(bref, bque, prepared=prep, debug=True)
+                torch.cuda.synchronize()
+                range_flags = hp.range_status(prep)          # 0: every chain launch of the step ran in the fp16-pair form
+                parity = parity_gate(hp, bref, bque, vol, co, fi, inds)
+                del vol, co, fi, inds
         except SystemExit as e:                            # no timing is accepted: tell the other ranks, then stop
             print(e, file=sys.stderr, flush=True)
-        del vol, co, fi, inds
     ok = max_over_ranks(0.0 if (rank != 0 or parity is not None) else 1.0, dev) == 0.0
     if not ok:
         if dist is not None:
             dist.destroy_process_group()
         sys.exit(3)
     sync()
-    if rank == 0:
+    if rank == 0 and not stub:
         _lib.timing_begin(only='k_chain.volume')      # HIP events around the dominant kernel's launches, on its launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -457,15 +574,20 @@ def main():
     sync()
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local, dev)
-    table = _lib.timing_end() if rank == 0 else {}
-    # per-kernel table: a few further steps with every launch bracketed (outside the timed region: 11 event pairs per step
-    # cost ~2 % of it)
+    table = {}
+    full = {}
     if rank == 0:
-        _lib.timing_begin()
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
-        full = _lib.timing_end()
+        if stub:
+            table, full = hp.table(args.steps), hp.table(5)
+        else:
+            table = _lib.timing_end()
+            # per-kernel table: a few further steps with every launch bracketed (outside the timed region: 14 event pairs per
+            # step cost ~2 % of it)
+            _lib.timing_begin()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            full = _lib.timing_end()
     per_rank = None
     if dist is not None:
         mine = torch.tensor([B * args.steps / dt_local], device=dev)
@@ -481,63 +603,67 @@ def main():
         n_ren, t_ren = full['k_chain.render']
         ms = t_vol / n_vol
         ms_ren = t_ren / n_ren
-        ms_alone = hp.time_chain_kernel(bref, res, iters=10)
-        fl = chain_flops(B * res ** 3, c['V'], render=False)
-        fl_ren = chain_flops(B * rn * dn, c['V'], render=True)
-        achieved = fl / (ms * 1e-3) / 1e12
-        traffic, counters = recorded_pmc(B)
-        K = args.steps
+        ms_alone = args.stub_step_ms * 0.5 if stub else hp.time_chain_kernel(bref, res, iters=10)
+        fl_alg = chain_flops(B * res ** 3, c['V'], render=False)
+        fl_exe = executed_mfma_flops(B * res ** 3, False)
+        fl_ren = executed_mfma_flops(B * rn * dn, True)
+        achieved = fl_exe / (ms * 1e-3) / 1e12
+        traffic, counters, valu = (None, None, None) if stub else recorded_pmc(B)
         out = {
             'metric': METRIC, 'value': round(world * B * args.steps / dt, 3), 'unit': 'scenes/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not stub else 'stub (no GPU work)',
             'dtype_note': 'fp32 values end to end (inputs, activations, accumulators, outputs); inside k_chain the products of the wide layers are '
                           'formed on the f16 matrix cores from fp32 operands carried as fp16 pairs (1 fp32 ulp; three exact partial products per MAC, '
-                          'DESIGN.md 4.1b); f32_mfma_build is the same step with those products on fp32 instructions',
-            'parity_checked': parity is not None, 'parity': parity,
+                          'DESIGN.md 4.1b; as close to a float64 evaluation as the fp32 CPU oracle, tests/test_range_guard.py); operands beyond the '
+                          'fp16 range make the launch fall back to the fp32-input MFMA (range_flags); f32_mfma_build is the same step with '
+                          'every product on fp32 instructions',
+            'parity_checked': parity is not None, 'parity': parity, 'range_flags': range_flags,
             'config': {'workload': f'{B} scenes/GPU/step, 6 views 288x512 (feature maps 72x128x32 x2), 40^3 TSDF volume + '
                                    f'512 rays x (40 coarse + 40 fine) samples incl. pixel_colors_gt, forward only, eval-mode resampling, '
                                    f'inputs resident in HBM (BASELINE.json configs[2]; configs[3] = the same on 8 GPUs)',
                        'global_batch': world * B, 'parallelism': f'scene-sharded x{world}, no data-path collective'},
-            'rccl_ranks': rccl_ranks, 'per_rank_scenes_per_s': per_rank,
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+            'rccl_ranks': rccl_ranks, 'per_rank_scenes_per_s': per_rank, 'dist_backend': args.dist_backend if dist is not None else None,
+            # The roof the kernel sits under: the wide layers run on the f16 matrix cores (three exact partial products per fp32
+            # MAC), the 1..4-k-step remainders on the fp32-input MFMA: achieved = the MFMA FLOPs the kernel EXECUTES per launch
+            # (MFMA_PER_TILE x tiles; PMC SQ_INSTS_MFMA agrees) / its HIP-event duration, peak = the dense f16 MFMA peak.
+            # What binds it is VALU issue (`valu`): 12 vector instructions per MFMA (activations, operand splitting, queue moves).
+            'roofline': {'bound': 'mfma', 'binding_resource': 'valu_issue', 'achieved': round(achieved, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic,
                          'kernel': 'k_chain<6,false> on the volume points', 'ms_per_launch': round(ms, 4),
                          'launches_timed': n_vol, 'ms_per_launch_standalone': round(ms_alone, 4),
-                         'flops_per_launch': fl,
-                         'note': 'achieved = algorithmic (un-hoisted) fp32 FLOPs, 2*(6*27736+6528) per point (SURVEY.md §8d), over the launch '
-                                 'time; peak = the fp32-instruction peak of the part (fp32-input MFMA = fp32 vector rate).  frac > 1 is not '
-                                 'an accounting error: the wide layers run on the f16 matrix cores with every fp32 operand carried as '
-                                 'an fp16 pair (h + m 2^-11, equal to the operand to 1 fp32 ulp) and three exact partial products per MAC '
-                                 '(DESIGN.md §4.1b; error against fp64 below that of the fp32 MFMA chain, profiles/r02_f_split_mfma_ubench.txt).  '
-                                 'What the kernel executes on the matrix pipe is in f16_mfma; what binds it now is VALU issue '
-                                 '(operand splitting, activations, projection / bilinear), see counters',
-                         'f16_mfma': {'executed_tflops': round(executed_mfma_flops(B * res ** 3, False) / (ms * 1e-3) / 1e12, 1),
-                                      'peak': PEAK_F16_MFMA_TFLOPS,
-                                      'frac': round(executed_mfma_flops(B * res ** 3, False) / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                                      'executed_flops_per_launch': executed_mfma_flops(B * res ** 3, False)},
+                         'flops_per_launch': fl_exe,
+                         'note': 'achieved = executed matrix-core FLOPs per launch (696 v_mfma_f32_16x16x32_f16 + 114 v_mfma_f32_16x16x4_f32 per '
+                                 '16-point tile; profiles/ PMC SQ_INSTS_MFMA per tile = 810) over the HIP-event launch time; peak = dense f16 MFMA.  '
+                                 'fp32 operands are carried as fp16 pairs and every fp32 MAC costs three f16 MACs, so the fp32-equivalent rate is '
+                                 'algorithmic_fp32_equiv (no fraction: it is not priced against a roof it does not run under).  The kernel is bound by '
+                                 'VALU issue, see valu',
+                         'valu': valu,
+                         'algorithmic_fp32_equiv': {'tflops': round(fl_alg / (ms * 1e-3) / 1e12, 2), 'flops_per_launch': fl_alg,
+                                                    'note': 'un-hoisted fp32 FLOPs 2*(6*27736+6528) per point (SURVEY.md 8d); the fp32-instruction peak of '
+                                                            'the part is 157.3 TFLOP/s (f32_mfma_build.frac_of_fp32_mfma_peak is measured against it)'},
                          'render_launch': {'kernel': 'k_chain<6,true> on the ray points (2 launches per step)', 'ms_per_launch': round(ms_ren, 4),
-                                           'achieved': round(fl_ren / (ms_ren * 1e-3) / 1e12, 3),
-                                           'frac': round(fl_ren / (ms_ren * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'flops_per_launch': fl_ren}},
+                                           'achieved': round(fl_ren / (ms_ren * 1e-3) / 1e12, 2),
+                                           'frac': round(fl_ren / (ms_ren * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'flops_per_launch': fl_ren}},
             'kernels_ms_per_step': {k: round(v[1] / 5, 4) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])},
         }
-        # SURVEY.md §8d extras: the whole step against both rooflines (38.7 GFLOP and 26.0 MB compulsory HBM bytes per scene,
-        # TSDF + render) and the recorded counters of the dominant kernel
+        # SURVEY.md §8d extras: the whole step against the HBM roof (26.0 MB compulsory bytes per scene, TSDF + render) and the
+        # recorded counters of the dominant kernel
         sps = B * args.steps / dt
-        out['roofline']['whole_step'] = {'fp32_fraction': round(38.7e9 * sps / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-                                         'hbm_fraction': round(26.0e6 * sps / (PEAK_HBM_TBPS * 1e12), 5),
+        out['roofline']['whole_step'] = {'hbm_fraction': round(26.0e6 * sps / (PEAK_HBM_TBPS * 1e12), 5),
+                                         'fp32_equiv_tflops': round(38.7e9 * sps / 1e12, 1),
                                          'traffic_GBps_dominant_kernel': None if traffic is None else round(traffic / (ms * 1e-3) / 1e9, 1)}
         out['roofline']['counters'] = counters
     step_ms = dt / args.steps * 1e3
     if not args.no_train:
-        rec = train_leg(args, world, rank, dev, dist, sync)
+        rec = train_leg_stub(args, world, rank, dev, dist, sync) if stub else train_leg(args, world, rank, dev, dist, sync)
         if rank == 0:
             out['train_step'] = rec
-    if rank == 0 and world == 1 and not args.no_backbones:
+    if rank == 0 and world == 1 and not args.no_backbones and not stub:
         out['with_backbones'] = backbone_leg(hp, bref, bque, dev, B, step_ms)
-    if rank == 0 and world == 1 and not args.no_f32_build:
+    if rank == 0 and world == 1 and not args.no_f32_build and not stub:
         out['f32_mfma_build'] = f32_mfma_build_leg(out['value'])
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:    # the CPU leg is reported at N=1 only (the other ranks would wait)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:    # the CPU leg is reported at N=1 only (the other ranks would wait)
         out['cpu_baseline'] = cpu_baseline(wnp)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -149,11 +149,15 @@ def test_flat_gradient_allreduce_gloo():
 def _step_worker(rank, world, port, q):
     import torch.distributed as dist
     from graspnerf_amd.trainer import Trainer
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world < 8 else 1)
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     net = build()
     tr = Trainer(net, {'lr_init': 1e-3})
-    shards = {2: [[0], [1, 2]], 3: [[0], [1, 2], []]}[world][rank]        # ragged / empty shards
+    if world == 8:                                                         # one node of 8 GPUs: contiguous shards of the global batch
+        from graspnerf_amd.sharding import scene_shard
+        shards = list(range(*scene_shard(8, rank, 8)))
+    else:
+        shards = {2: [[0], [1, 2]], 3: [[0], [1, 2], []]}[world][rank]    # ragged / empty shards
     torch.manual_seed(100 + rank)
     log = tr.step([scene_data(scene_id=i) for i in shards])
     sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items() if 'dist_decoder' in k or 'vgn_net.conv_qual' in k or 'agg_net.prob_embed' in k}
@@ -162,11 +166,12 @@ def _step_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_trainer_step_end_to_end_gloo(world):
     """Trainer.step over gloo with ragged shards (1 + 2 scenes; world 3 adds a rank with an EMPTY shard, as scene_shard
     produces when the global batch is smaller than the world): every rank takes part in the flat-gradient all-reduce and
-    ends the step with identical parameters, which moved; the empty rank returns a log without loss terms instead of failing."""
+    ends the step with identical parameters, which moved; the empty rank returns a log without loss terms instead of failing.
+    world 8 = the rank layout of one MI355X node (BASELINE.json configs[4] at 8 GPUs), one tiny scene per rank."""
     import socket
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')

@@ -26,7 +26,20 @@ res = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorte
 for k, cs in res.items():
     if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
         cs['hbm_bytes_corrected'] = (2 * cs['FETCH_SIZE'] + cs['WRITE_SIZE']) * 1024
+import hashlib
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'graspnerf_amd', 'csrc')
+
+
+def sha16(*names):
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(CSRC, n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 json.dump({
+    # bench.py reports these counters only while the stamps equal the sha256 of the kernel sources it runs (bench.py newest_pmc)
+    'kernel_source_sha16': sha16('gnr_kernels.hip'), 'bwd_source_sha16': sha16('gnr_kernels.hip', 'gnr_bwd.inc'),
     'command': 'rocprofv3 --pmc <set> --output-format csv -- python tools/run_hot.py --iters 1   (forward kernels: B=32 scenes, 6 views, '
                '40^3 + 512 rays) and -- python tools/time_volume_bwd.py --scenes 8 (k_*_bwd kernels of sample_volume: 8 scenes); '
                'one run per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU SQ_INSTS_MFMA | '
