@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <atomic>
 #include <vector>
 
 #include "../../include/gnr.h"
@@ -341,6 +342,15 @@ __global__ __launch_bounds__(256) void k_conv3d_staged(ConvArgs a) {
 using namespace gnrh;
 
 static thread_local char h_err[256] = "";
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) is per device: one bit per device id and kernel
+static bool head_attr_needed(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load() & bit) return false;
+    done.fetch_or(bit);
+    return true;
+}
 extern "C" const char* gnr_head_last_error(void) { return h_err; }
 
 extern "C" int gnr_head_canonical_floats(void) { return C_TOTAL; }
@@ -426,12 +436,11 @@ static int launch_staged(const ConvArgs& a, hipStream_t st) {
     const int nbx = (a.Dout + 7) / 8, nbz = (a.Dout + 3) / 4;
     const long blocks = (long)a.B * nbx * nbx * nbz;
     const size_t lds = ((size_t)CIN * halo_max(FOLD) + (size_t)TS * (CIN / 4) * NB * 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned long long> attr{0};
+    if (head_attr_needed(attr)) {
         hipError_t e = hipFuncSetAttribute((const void*)k_conv3d_staged<CIN, NB, KS, TS, EPI, FOLD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { snprintf(h_err, sizeof(h_err), "hipFuncSetAttribute: %s", hipGetErrorString(e)); return GNR_ERR_HIP; }
-        attr = true;
     }
     hipLaunchKernelGGL((k_conv3d_staged<CIN, NB, KS, TS, EPI, FOLD>), dim3((unsigned)blocks, a.nb_total / NB), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
@@ -712,13 +721,13 @@ extern "C" int gnr_conv3d_same(const float* x, const float* w, const float* bias
     HeadScope hs(mode ? "k_conv3d_s1.bwd_data@gnr_conv3d_same" : "k_conv3d_s1.fwd@gnr_conv3d_same", stream);
     if (K == 5) {
         const size_t lds = (16 * (12 * 12 * 8) + 5 * 256) * sizeof(float);
-        static bool attr = false;
-        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        static std::atomic<unsigned long long> attr{0};
+        if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
         hipLaunchKernelGGL(gnr_head::k_conv3d_s1<5>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
     } else {
         const size_t lds = (16 * (10 * 10 * 6) + 3 * 256) * sizeof(float);
-        static bool attr = false;
-        if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        static std::atomic<unsigned long long> attr{0};
+        if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
         hipLaunchKernelGGL(gnr_head::k_conv3d_s1<3>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
     }
     HCHK(hipGetLastError());
@@ -853,13 +862,13 @@ extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float
         HeadScope hs("k_conv3d_wgrad_s1@gnr_conv3d_same_bwd_weight", stream);
         if (K == 5) {
             const size_t lds = (16 * (12 * 12 * 8) + 16 * 256) * sizeof(float);
-            static bool attr = false;
-            if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+            static std::atomic<unsigned long long> attr{0};
+            if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
             hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi);
         } else {
             const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
-            static bool attr = false;
-            if (!attr) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+            static std::atomic<unsigned long long> attr{0};
+            if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
             hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<3>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi);
         }
         HCHK(hipGetLastError());

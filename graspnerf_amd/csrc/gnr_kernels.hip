@@ -594,6 +594,13 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
     if (a.only_if_flagged && (a.range_flag == nullptr || __builtin_nontemporal_load(a.range_flag) == 0u)) return;   // wave-uniform
+    if constexpr (SP && GNR_RANGE_GUARD != 0) {
+        // a weight without an fp16 pair (gnr_pack.cpp build_c16): bit 2, and the whole launch is the fp32 twin's
+        if (a.range_flag && a.wpk[pk::T_VIS + 2] != 0.f) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 4u);
+            return;
+        }
+    }
     bool range_tripped = false;                           // wave-uniform
     constexpr bool EP = SP && !SAVE;                       // e1 travels between the view loops as its fp16 pair (the training saves keep fp32)
 #define LO(o) (SP ? pk::c16_off(o) : (o))                  /* offset of a CHAIN-section name inside the staged image */                    // fp16-pair layers on the f16 matrix cores (C16 image) / fp32 MFMA (CHAIN image)

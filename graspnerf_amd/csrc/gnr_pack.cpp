@@ -164,8 +164,14 @@ int build_c16(float* p) {
     const int cuts[4] = {0, pk::GEO1, pk::GEO2, pk::CHAIN_END};                   // the slot behind each grown layer starts a new run
     for (int r = 0; r < 3; ++r)
         std::memcpy(p + pk::C16 + pk::c16_off(cuts[r]), p + cuts[r], sizeof(float) * (cuts[r + 1] - cuts[r]));
+    // A weight beyond the fp16 range (|w| >= 65 520) has no pair: the blob says so (T_VIS + 2, in both images) and k_chain's
+    // pair kernels hand every launch with this blob to their fp32-MFMA twins (range guard, gnr_kernels.hip).  The flag is
+    // sticky over gnr_pack_weights -> gnr_pack_vis_decoder (which re-runs this on the same blob).
+    bool ok = true;
     for (const C16Plan& pl : c16_plan())
-        if (!to_pairs(p + pk::C16 + pk::c16_off(pl.off), p + pl.off, pl)) return GNR_ERR_ARG;      // a weight beyond the fp16 range (|w| >= 65520)
+        if (!to_pairs(p + pk::C16 + pk::c16_off(pl.off), p + pl.off, pl)) ok = false;
+    if (!ok) p[pk::T_VIS + 2] = 1.f;
+    p[pk::C16 + pk::c16_off(pk::T_VIS) + 2] = p[pk::T_VIS + 2];
     return GNR_OK;
 }
 

@@ -123,12 +123,37 @@ def read_rgb_png(path):
         return np.asarray(im.convert('RGBA' if im.mode in ('RGBA', 'LA', 'P') else 'RGB'))[:, :, :3].copy()
 
 
+class _Rotation:
+    """The two accessors of scipy's Rotation the reference's callers use on a grasp pose (clutter_removal.py:198-199,
+    simulation.execute_grasp): as_quat() (x, y, z, w) and as_matrix()."""
+
+    def __init__(self, quat):
+        q = np.asarray(quat, np.float64)
+        self._q = q / max(np.linalg.norm(q), 1e-12)
+
+    def as_quat(self):
+        return self._q.copy()
+
+    def as_matrix(self):
+        x, y, z, w = self._q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+class _Pose:
+    def __init__(self, quat, translation):
+        self.rotation, self.translation = _Rotation(quat), np.asarray(translation, np.float64)
+
+
 class Grasp:
-    """(rotation quaternion x,y,z,w; translation; width) -- the fields of gd.grasp.Grasp(Transform(Rotation, t), width) the
-    callers of the planner read (main.py:79-84, 205)."""
+    """gd.grasp.Grasp(Transform(Rotation, t), width) as the planner's callers read it (main.py:79-84, 205;
+    clutter_removal.py:198-199): `.pose.rotation.as_quat()` / `.as_matrix()`, `.pose.translation`, `.width` -- plus the flat
+    `.quat` (x, y, z, w) and `.translation` this package uses itself."""
 
     def __init__(self, quat, translation, width):
         self.quat, self.translation, self.width = np.asarray(quat, np.float64), np.asarray(translation, np.float64), float(width)
+        self.pose = _Pose(self.quat, self.translation)
 
     def __repr__(self):
         return f'Grasp(t={self.translation.round(4).tolist()}, q={self.quat.round(4).tolist()}, w={self.width:.4f})'
@@ -154,22 +179,19 @@ class GraspNeRFPlanner:
         self.voxel_size, self.bbox3d = 0.3 / 40, [[-0.15, -0.15, -0.0503], [0.15, 0.15, 0.2497]]       # main.py:90-91
         self.tsdf_thres_high, self.tsdf_thres_low = 0.0, -0.85                                         # main.py:92-93
         self.renderer_root_dir, self.rgb_dir, self.seed = renderer_root_dir, rgb_dir, seed
-        self.net = load_model(cfg, checkpoint, device)                                                 # main.py:150-157
-        self.step = 0
-        if isinstance(checkpoint, (str, bytes)):
-            self.step = torch.load(checkpoint, map_location='cpu').get('step', 0)
+        ckpt = torch.load(checkpoint, map_location='cpu') if isinstance(checkpoint, (str, bytes)) else checkpoint   # read once
+        self.net = load_model(cfg, ckpt, device)                                                       # main.py:150-157
+        self.step = int(ckpt.get('step', 0)) if isinstance(ckpt, dict) else 0                          # main.py:155
         self.selector = GraspSelector(next(self.net.parameters()).device)
-        self._poses = None
 
     def get_image(self, img_id, round_idx=0):                                                          # main.py:167-172
         img = read_rgb_png(os.path.join(self.rgb_dir, '%04d.png' % img_id))
         return resize_bilinear_u8(img, self.img_wh).astype(np.float32)
 
     def get_pose(self, img_id):                                                                        # main.py:174-177
-        if self._poses is None:
-            ori = np.load(os.path.join(self.renderer_root_dir, 'camera_pose.npy'))
-            self._poses = [np.linalg.inv(p @ BLENDER2OPENCV)[:3, :] for p in ori]
-        return self._poses[img_id].astype(np.float32).copy()
+        # read on every call like the reference: the simulator rewrites camera_pose.npy between rounds
+        ori = np.load(os.path.join(self.renderer_root_dir, 'camera_pose.npy'))[img_id]
+        return np.linalg.inv(ori @ BLENDER2OPENCV)[:3, :].astype(np.float32)
 
     def get_K(self, img_id):
         return self.K.astype(np.float32).copy()

@@ -316,7 +316,15 @@ class NeuralRayRenderer(nn.Module):
             ps = self._hot_params = [P[k] for lvl in ('coarse', 'fine') for k, _ in _w.level_keys(lvl)]
             if self.use_vis:
                 ps += [P[_w.LEVELS[lvl][0] + k] for lvl in ('coarse', 'fine') for k, _ in _w.VIS_KEYS]
-        return tuple(p._version for p in ps)
+        # (version, storage address): optimizer.step / copy_ / load_state_dict bump the version, `p.data = tensor` moves the
+        # storage.  A write through `p.data.copy_()` / `p.data.mul_()` changes neither: call invalidate_packed() after such surgery.
+        return tuple((p._version, p.data_ptr()) for p in ps)
+
+    def invalidate_packed(self):
+        """Forget the packed HIP copies of the hot-path weights: the next forward re-packs from the current parameter values.
+        Needed only after in-place writes that bypass autograd's version counters (p.data.copy_, EMA swaps through .data)."""
+        self._hot_ver = None
+        self._repack_pending = None
 
     def hot(self):
         """The HIP path with weights packed from the CURRENT parameter values: re-packed whenever a parameter was updated in
@@ -567,7 +575,18 @@ class NeuralRayRenderer(nn.Module):
             return _SampleVolumeFn.apply(hot, bref, prep, self.cfg['volume_resolution'], ref_imgs_info['ray_feats'][None],
                                          ref_imgs_info['img_feats'][None], *[P[k] for k, _ in _w.level_keys('coarse')])
         bref, prep = _prep or self._prepare(ref_imgs_info)
-        return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
+        if not self.cfg.get('warn_low_valid_ratio', False):
+            return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
+        # renderer.py:174-176: the reference reads the share of (view, voxel) pairs that project into their image back to the
+        # host on every call and prints when it is below one half.  Opt-in here (cfg warn_low_valid_ratio): the read is a
+        # host synchronisation (and not capturable in a hipGraph); the in-image bits come out of the chain kernel anyway.
+        vol, vmask = self.hot().sample_volume(bref, self.cfg['volume_resolution'], want_mask=True, prepared=prep)
+        V = bref['imgs'].shape[1]
+        bits = sum(((vmask >> v) & 1).float() for v in range(V))
+        valid_ratio = bits.reshape(vmask.shape[0], -1).sum(1) / float(V * vmask[0].numel())
+        if float(valid_ratio.mean()) < 0.5:
+            print("!! too low ratio", valid_ratio)
+        return vol
 
     def _out_dict(self, o, suffix, level_net):
         keys = ['sdf_values', 'alpha_values', 'colors_nr', 'hit_prob_nr', 'pixel_colors_nr']
@@ -759,7 +778,7 @@ class GraspNeRF(nn.Module):
         the PyTorch module (same parameters) when autograd is needed."""
         if volume.is_cuda and not torch.is_grad_enabled():
             # the packed copy follows the parameters: optimizer.step() updates them in place (version counters move)
-            ver = tuple(p._version for p in self.vgn_net.parameters())
+            ver = tuple((p._version, p.data_ptr()) for p in self.vgn_net.parameters())
             if self._head is None or self._head_ver != ver:
                 self._head = GraspHead(self.vgn_net.state_dict(), device=volume.device)
                 self._head_ver = ver

@@ -102,7 +102,8 @@ int gnr_canonical_weights_floats(void);   /* 36958 */
 int gnr_packed_weights_floats(void);
 /* Host-side packer: MFMA fragments of every layer (fp32), the tables of the per-ray kernel, and the image the chain kernel
  * stages into LDS, in which the wide layers' weights are stored as fp16 pairs w = h + m 2^-11 (1 fp32 ulp; csrc/gnr_layout.h
- * section C16).  GNR_ERR_ARG if a pointer is null or an effective weight is outside the fp16 range (|w| >= 65520). */
+ * section C16).  GNR_ERR_ARG if a pointer is null.  An effective weight outside the fp16 range (|w| >= 65520) has no pair: the
+ * blob is marked and every chain launch with it runs on the fp32-input MFMA (gnr_range_status bit 2). */
 int gnr_pack_weights(const float* canonical_host, float* packed_host);
 /* Optional: the fourth decoder branch of a level (cfg dist_decoder_cfg.use_vis: true; dist_decoder.py:89-97,103-104,133-134:
  * its sigmoid output multiplies both cdfs) into a blob gnr_pack_weights has filled.  vis_decoder_host = vis_decoder.{0.weight
@@ -126,7 +127,8 @@ int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, 
  * immediately unless the watch tripped and otherwise recomputes the launch: out-of-range scenes get the fp32 kernel's values,
  * in-range scenes pay ~5 us per chain launch, and no call synchronises with the host.
  * gnr_range_status reads the watch word of the last gnr_prepare on this workspace (synchronises `stream`):
- *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range.
+ *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range;
+ *   bit 2: a weight beyond the fp16 range (gnr_pack_weights marks such a blob instead of refusing it).
  * gnr_force_fp32_chain(1) makes every chain launch run the fp32-MFMA kernel (tests, measurements); returns the old setting. */
 int gnr_range_status(const GnrScene* scene, const void* workspace, size_t workspace_bytes, unsigned* flags_out, void* stream);
 int gnr_force_fp32_chain(int on);

@@ -430,12 +430,19 @@ def test_c16_image_keeps_biases_and_tables(packed_and_sd):
     assert off('C16_END') * 4 <= 160 * 1024
 
 
-def test_packer_refuses_weights_beyond_fp16_range(weights_np):
+def test_packer_marks_weights_beyond_fp16_range(weights_np):
+    """A weight of 7e4 has no fp16 pair: the blob carries the mark (T_VIS + 2, both images) that makes k_chain's pair kernels hand
+    every launch to their fp32-MFMA twins (include/gnr.h gnr_range_status bit 2; GPU side: tests/test_range_guard.py); blobs of
+    in-range weights do not."""
+    ok = weights.pack(weights.canonical_blob(weights_np, 'coarse'))
+    assert ok[off('T_VIS') + 2] == 0.0 and ok[off('C16.T_VIS') + 2] == 0.0
     big = dict(weights_np)
     big['agg_net.agg_impl.base_fc.2.weight'] = big['agg_net.agg_impl.base_fc.2.weight'].copy()
     big['agg_net.agg_impl.base_fc.2.weight'][0, 0] = 7.0e4
-    with pytest.raises(Exception):
-        weights.pack(weights.canonical_blob(big, 'coarse'))
+    bad = weights.pack(weights.canonical_blob(big, 'coarse'))
+    assert bad[off('T_VIS') + 2] == 1.0 and bad[off('C16.T_VIS') + 2] == 1.0
+    # the fp32 sections (what the twin and the backward kernels read) hold the weight itself
+    assert np.isfinite(bad[:off('CHAIN_END')]).all() and np.abs(bad[:off('CHAIN_END')]).max() > 6.9e4
 
 
 def test_base_fc0_split_in_pair_form(packed_and_sd):

@@ -155,3 +155,17 @@ def test_planner_from_files_end_to_end(tmp_path):
         np.testing.assert_allclose(gr.translation, t, atol=1e-9)
         assert abs(gr.width - w) < 1e-5
     assert 0 < toc < 60
+
+
+def test_grasp_exposes_the_pose_interface_of_the_reference():
+    """gd.grasp.Grasp as its consumers read it (clutter_removal.py:198-199, simulation.execute_grasp): pose.rotation.as_quat()
+    / as_matrix(), pose.translation, width."""
+    from graspnerf_amd.planner import Grasp
+    q = np.array([0.1, -0.3, 0.2, 0.9])
+    q /= np.linalg.norm(q)
+    g = Grasp(q, [0.1, 0.2, 0.3], 0.05)
+    assert np.allclose(g.pose.rotation.as_quat(), q) and np.allclose(g.pose.translation, [0.1, 0.2, 0.3]) and g.width == 0.05
+    R = g.pose.rotation.as_matrix()
+    from scipy.spatial.transform import Rotation
+    assert np.allclose(R, Rotation.from_quat(q).as_matrix(), atol=1e-12)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12

@@ -125,6 +125,19 @@ def test_weights_that_drive_an_activation_past_the_fp16_range(weights_np):
     _check_fallback(hp, w, ref, que, 2, 'base_fc.0 x3e4')
 
 
+def test_a_weight_without_an_fp16_pair_runs_on_the_fp32_twin(weights_np):
+    """mean_decoder.0 (a layer whose operands are the bounded feature maps, i.e. not watched inside the kernel) with one weight of
+    1e5: the packer marks the blob (bit 2) and the launches are the fp32 twin's."""
+    w = dict(weights_np)
+    for lvl in ('dist_decoder.', 'fine_dist_decoder.'):
+        k = lvl + 'mean_decoder.0.weight'
+        w[k] = w[k].copy()
+        w[k][3, 5] = 1e5
+    hp = _hp(w)
+    ref, que = make_scene(0, 'cfg1')
+    _check_fallback(hp, w, ref, que, 4, 'mean_decoder.0 weight = 1e5')
+
+
 @pytest.mark.parametrize('regime', ['x1', 'features x30', 'features x1e-3', 'decoder+geometry weights x3'])
 def test_fp64_arbiter(regime, weights_np):
     """|HIP - fp64| against |fp32 oracle - fp64| on the volume (16^3) and the coarse sdf / alpha of 64 rays.  The HIP path uses

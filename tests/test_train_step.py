@@ -479,3 +479,87 @@ def test_full_size_train_step_matches_the_reference_statement():
             continue
         e = (got[True][k] - g).norm().item() / (g.norm().item() + 1e-9)
         assert e < 3e-3, (k, e)
+
+
+@pytest.mark.gpu
+def test_benched_shape_eight_scenes_stacked_equals_the_per_scene_loop():
+    """BASELINE.json configs[4] as bench.py's train_step runs it: EIGHT full-size scenes in one stacked forward / backward
+    (forward_scenes(stacked=True) + the stacked losses) against the per-scene loop over the same eight scenes with the same RNG
+    stream -- every loss term per scene and the gradient of every parameter of the volumetric path and the grasp head.  The two
+    differ only in the order in which the weight-gradient atomics of the backward kernels and MIOpen's reductions add up.
+    (Scene 0 of this batch against the pure-autograd statement: test_full_size_train_step_matches_the_reference_statement.)"""
+    from graspnerf_amd.renderer import GraspNeRF
+    from graspnerf_amd.trainer import train_losses, train_losses_stacked
+    from graspnerf_amd import losses
+    from reference_autograd import use_reference_statement
+    cfg = _full_size_cfg()
+    net = GraspNeRF(cfg)
+    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()}, strict=True)
+    net = net.cuda().train()
+    use_reference_statement(net, on=False)
+    datas = [_full_size_scene(i) for i in range(8)]
+    got, terms_got = {}, {}
+    for batched in (False, True):
+        for a in (net.nr_net.agg_net, net.nr_net.fine_agg_net):
+            a.step = 0
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(9)
+        if batched:
+            st = net.forward_scenes(datas, stacked=True)
+            assert st is not None
+            terms = train_losses_stacked(st, datas)
+            losses.total_loss(terms, scenes=8).backward()
+            terms_got[True] = {k: v.detach().reshape(8, -1).mean(1).cpu().numpy() for k, v in terms.items() if k.startswith('loss')}
+        else:
+            per = []
+            for d in datas:
+                terms = train_losses(net(d), d)
+                losses.total_loss(terms).backward()
+                per.append({k: float(v.detach().mean()) for k, v in terms.items() if k.startswith('loss')})
+            terms_got[False] = {k: np.array([p[k] for p in per]) for k in per[0]}
+        torch.cuda.synchronize()
+        got[batched] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if any(s in k for s in ('dist_decoder', 'agg_net', 'vgn_net'))}
+        torch.cuda.empty_cache()
+    for k, v in terms_got[False].items():
+        np.testing.assert_allclose(terms_got[True][k], v, rtol=2e-4, atol=1e-7, err_msg=k)
+    worst = (0.0, '')
+    for k, g in got[False].items():
+        if k.endswith('rgb_fc.4.bias'):
+            continue
+        worst = max(worst, ((got[True][k] - g).norm().item() / (g.norm().item() + 1e-9), k))
+    assert worst[0] < 3e-3, f'stacked batch of 8 vs per-scene loop: {worst}'
+
+
+@pytest.mark.gpu
+def test_packed_weights_follow_writes_that_bypass_the_version_counters(capsys):
+    """renderer.hot() keys its packed copies on (version counter, storage address) of the hot-path parameters.  `p.data = t`
+    moves the storage and is seen; `p.data.mul_()` changes neither and needs invalidate_packed().  Also the reference's
+    low-valid-ratio diagnostic (renderer.py:174-176), opt-in through cfg warn_low_valid_ratio."""
+    net = build('cuda').eval()
+    data = scene_data('cuda')
+    nr = net.nr_net
+    with torch.no_grad():
+        ref = nr.image_encoder(data['ref_imgs_info']['imgs'])
+        info = dict(data['ref_imgs_info'])
+        info['img_feats'] = ref
+        info['ray_feats'] = nr.vis_encoder(nr.init_net({'imgs': info['imgs']}, None, False), ref)
+        v0 = nr.sample_volume(info).clone()
+        p = dict(nr.named_parameters())['agg_net.agg_impl.geometry_fc.2.weight']
+        p.data = p.data * 1.5                                     # new storage: picked up by the key
+        v1 = nr.sample_volume(info).clone()
+        assert (v1 - v0).abs().max() > 1e-4
+        p.data.mul_(1.0 / 1.5)                                    # in place through .data: invisible to the key ...
+        v2 = nr.sample_volume(info).clone()
+        assert torch.equal(v2, v1)
+        nr.invalidate_packed()                                    # ... until told
+        v3 = nr.sample_volume(info).clone()
+        assert (v3 - v0).abs().max() < 1e-5
+        # diagnostic: cameras that see (almost) none of the workspace
+        nr.cfg['warn_low_valid_ratio'] = True
+        capsys.readouterr()
+        assert torch.equal(nr.sample_volume(info), v3) and 'too low ratio' not in capsys.readouterr().out
+        far = dict(info, bbox3d=info['bbox3d'] + 5.0)
+        nr.sample_volume(far)
+        assert '!! too low ratio' in capsys.readouterr().out
+        nr.cfg['warn_low_valid_ratio'] = False
