@@ -238,6 +238,43 @@ DEV P8 p8_load(const float* r) {
 }
 DEV f4 mfma32h(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// ---- GNR_UNSCALED_ACT: the cheaper pair of an ACTIVATION (inner layers only: operands that are ELU outputs, O(1) vectors).
+//   x = h + m   with  h = fp16(x),  m = fp16(x - h)  -- the residual UNSCALED, so that both products with the weight's high half
+//   accumulate in the layer's own accumulator:  W x = wh h + wh m + wm (h 2^-11)  (wm = the weight's residual, scaled by 2^11 as
+//   before; its B operand is the high half times 2^-11, exact unless subnormal).  No second accumulator, no fold: a split costs 5
+//   VALU per two operands instead of 6 and an output nothing instead of one fma.  Price: the residual of |x| < 2^-3 falls into the
+//   fp16 subnormal range (quantum 2^-24), so such an operand carries an ABSOLUTE error of up to 2^-25 instead of a relative one of
+//   2^-24: a pre-activation is off by at most 2^-25 sum|w| (1e-7 for these layers) on top of the fp32-like rounding.  Against the
+//   float64 arbiter the path is as close as with scaled residuals (tests/test_range_guard.py::test_fp64_arbiter).  Layers fed by
+//   feature maps or cross-view statistics (any magnitude) keep the scaled form.
+#ifndef GNR_UNSCALED_ACT
+#define GNR_UNSCALED_ACT 1
+#endif
+struct P8U { h8 h, m, s; };
+DEV void split2u(float x0, float x1, h2& h, h2& m, h2& s) {
+    const f2 x = {x0, x1};
+    h = __builtin_convertvector(x, h2);
+    // x - h, exact, as ONE instruction reading the fp16 half in place (the compiler turns fma(h, -1, x) back into a subtraction
+    // and lowers that to v_cvt_f32_f16 + v_sub_f32)
+    f2 r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(h), "v"(x1));
+    m = __builtin_convertvector(r, h2);
+    s = h * (h2){(_Float16)kPairSi, (_Float16)kPairSi};                 // v_pk_mul_f16
+}
+template <int O, int N>
+DEV P8U split8u(const float (&v)[N]) {
+    static_assert(O + 8 <= N, "split8u reads 8 slots");
+    h2 h[4], m[4], s[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split2u(v[O + 2 * q], v[O + 2 * q + 1], h[q], m[q], s[q]);
+    P8U p;
+    p.h = (h8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+    p.m = (h8){m[0].x, m[0].y, m[1].x, m[1].y, m[2].x, m[2].y, m[3].x, m[3].y};
+    p.s = (h8){s[0].x, s[0].y, s[1].x, s[1].y, s[2].x, s[2].y, s[3].x, s[3].y};
+    return p;
+}
+
 // ---- range guard of the pair form.  The high half of a pair is an fp16: an operand of 65 520 or more becomes +-inf there and
 // the layer's outputs garbage (ELU then maps -inf and NaN to finite values, so nothing downstream would show it).  The fp32
 // reference has no such limit.  Every pair block whose operands are not bounded by construction is therefore watched:
@@ -296,6 +333,26 @@ DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, 
 #endif
     }
     if constexpr (WATCH) range_watch(*rw, acc[GNR_WATCH_LAST ? NB - 1 : 0]);
+}
+// the same layer on unscaled activation pairs: three products into ONE accumulator (the k-blocks outermost, so that
+// consecutive MFMAs go to different output blocks)
+template <int KB, int NB, bool LF, bool WATCH = false>
+DEV void mm16u(const float* __restrict__ w, int lane, const P8U* __restrict__ x8, f4 (&acc)[NB], float* rw = nullptr) {
+    if constexpr (LF) asm volatile("" ::: "memory");
+    const h8* w8 = reinterpret_cast<const h8*>(w) + lane;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        h8 wh[NB], wm[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { wh[nb] = w8[((kb * NB + nb) * 2) * 64]; wm[nb] = w8[((kb * NB + nb) * 2 + 1) * 64]; }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32h(wh[nb], x8[kb].h, acc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32h(wh[nb], x8[kb].m, acc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32h(wm[nb], x8[kb].s, acc[nb]);
+    }
+    if constexpr (WATCH) range_watch(*rw, acc[0]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -602,6 +659,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         }
     }
     bool range_tripped = false;                           // wave-uniform
+    constexpr bool UA = SP && GNR_UNSCALED_ACT != 0;       // inner layers on unscaled activation pairs (split8u / mm16u)
     constexpr bool EP = SP && !SAVE;                       // e1 travels between the view loops as its fp16 pair (the training saves keep fp32)
 #define LO(o) (SP ? pk::c16_off(o) : (o))                  /* offset of a CHAIN-section name inside the staged image */                    // fp16-pair layers on the f16 matrix cores (C16 image) / fp32 MFMA (CHAIN image)
     // ---- stage the C16 (or CHAIN) section of the packed weights into LDS (once per workgroup)
@@ -750,9 +808,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 else mm<8, 2, 0, LF>(lds + LO(pk::DEC1) + br * frag_floats(8, 2), lane, FR, acc);
                 elu_to<2, !SP>(acc, h1);
                 load_bias<2, LF>(lds + LO(pk::B_DEC2) + br * 32, g, acc);
-                if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF, true>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, &hp, acc, &msum); }
+                if constexpr (SP) {
+                    if constexpr (UA) { const P8U hp = split8u<0>(h1); mm16u<1, 2, LF, true>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, &hp, acc, &msum); }
+                    else { const P8 hp = split8<0>(h1); mm16<1, 2, LF, true>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, &hp, acc, &msum); }
+                }
                 else mm<8, 2, 0, LF>(lds + LO(pk::DEC2) + br * frag_floats(8, 2), lane, h1, acc);
-                elu_to<2, !SP>(acc, h2);
+                elu_to<2, !SP || UA>(acc, h2);
                 if (br < 2) {
                     o5[2 * br] = gsum(dot8(lds + LO(pk::T_DEC3) + (2 * br) * 32, g, h2)) + lds[LO(pk::T_DEC3_B) + 2 * br];
                     o5[2 * br + 1] = gsum(dot8(lds + LO(pk::T_DEC3) + (2 * br + 1) * 32, g, h2)) + lds[LO(pk::T_DEC3_B) + 2 * br + 1];
@@ -778,9 +839,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                     else mm<8, 2, 0, LF>(lds + LO(pk::DECV1), lane, FR, acc);
                     elu_to<2, !SP>(acc, h1);
                     load_bias<2, LF>(lds + LO(pk::B_DECV2), g, acc);
-                    if constexpr (SP) { const P8 hp = split8<0>(h1); mm16<1, 2, LF, true>(lds + LO(pk::DECV2), lane, &hp, acc, &msum); }
+                    if constexpr (SP) {
+                        if constexpr (UA) { const P8U hp = split8u<0>(h1); mm16u<1, 2, LF, true>(lds + LO(pk::DECV2), lane, &hp, acc, &msum); }
+                        else { const P8 hp = split8<0>(h1); mm16<1, 2, LF, true>(lds + LO(pk::DECV2), lane, &hp, acc, &msum); }
+                    }
                     else mm<8, 2, 0, LF>(lds + LO(pk::DECV2), lane, h1, acc);
-                    elu_to<2, !SP>(acc, h2);
+                    elu_to<2, !SP || UA>(acc, h2);
                     const float pv = sigmoid1(gsum(dot8(lds + LO(pk::T_DECV3), g, h2)) + lds[LO(pk::T_VIS)]);
                     c00 *= pv; c01 *= pv; c10 *= pv; c11 *= pv;
                 }
@@ -940,9 +1004,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 elu_to<4, !SP>(acc4, b1);
                 f4 acc[2];
                 load_bias<2, LF>(lds + LO(pk::B_BASE2), g, acc);
-                if constexpr (SP) { const P8 bp[2] = {split8<0>(b1), split8<8>(b1)}; mm16<2, 2, LF, true>(lds + LO(pk::BASE2), lane, bp, acc, &msum); }
+                if constexpr (SP) {
+                    if constexpr (UA) { const P8U bp[2] = {split8u<0>(b1), split8u<8>(b1)}; mm16u<2, 2, LF, true>(lds + LO(pk::BASE2), lane, bp, acc, &msum); }
+                    else { const P8 bp[2] = {split8<0>(b1), split8<8>(b1)}; mm16<2, 2, LF, true>(lds + LO(pk::BASE2), lane, bp, acc, &msum); }
+                }
                 else mm<16, 2, 0, LF>(lds + LO(pk::BASE2), lane, b1, acc);
-                elu_to<2, !SP>(acc, Hh);
+                elu_to<2, !SP || UA>(acc, Hh);
             }
             float vis1;
             {
@@ -951,13 +1018,19 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * w;
                 load_bias<2, LF>(lds + LO(pk::B_VIS1), g, acc);
-                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF, true>(lds + LO(pk::VIS1), lane, &xp, acc, &msum); }
+                if constexpr (SP) {
+                    if constexpr (UA) { const P8U xp = split8u<0>(xin); mm16u<1, 2, LF, true>(lds + LO(pk::VIS1), lane, &xp, acc, &msum); }
+                    else { const P8 xp = split8<0>(xin); mm16<1, 2, LF, true>(lds + LO(pk::VIS1), lane, &xp, acc, &msum); }
+                }
                 else mm<8, 2, 0, LF>(lds + LO(pk::VIS1), lane, xin, acc);
-                elu_to<2, !SP>(acc, v1);
+                elu_to<2, !SP || UA>(acc, v1);
                 load_bias<2, LF>(lds + LO(pk::B_VIS2), g, acc);
-                if constexpr (SP) { const P8 vp8 = split8<0>(v1); mm16<1, 2, LF, true>(lds + LO(pk::VIS2), lane, &vp8, acc, &msum); }
+                if constexpr (SP) {
+                    if constexpr (UA) { const P8U vp8 = split8u<0>(v1); mm16u<1, 2, LF, true>(lds + LO(pk::VIS2), lane, &vp8, acc, &msum); }
+                    else { const P8 vp8 = split8<0>(v1); mm16<1, 2, LF, true>(lds + LO(pk::VIS2), lane, &vp8, acc, &msum); }
+                }
                 else mm<8, 2, 0, LF>(lds + LO(pk::VIS2), lane, v1, acc);
-                elu_to<2, !SP>(acc, res);
+                elu_to<2, !SP || UA>(acc, res);
                 const float logit = elu1(gsum(dot8(lds + LO(pk::T_VIS2R), g, v1)) + lds[LO(pk::T_SCAL) + 1]);
                 vis1 = sigmoid1(logit) * m;                                    // ibrnet.py:479
 #pragma unroll
@@ -970,9 +1043,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[j] = Hh[j] * vis1;
                 load_bias<2, LF>(lds + LO(pk::B_VISB1), g, acc);
-                if constexpr (SP) { const P8 xp = split8<0>(xin); mm16<1, 2, LF, true>(lds + LO(pk::VISB1), lane, &xp, acc, &msum); }
+                if constexpr (SP) {
+                    if constexpr (UA) { const P8U xp = split8u<0>(xin); mm16u<1, 2, LF, true>(lds + LO(pk::VISB1), lane, &xp, acc, &msum); }
+                    else { const P8 xp = split8<0>(xin); mm16<1, 2, LF, true>(lds + LO(pk::VISB1), lane, &xp, acc, &msum); }
+                }
                 else mm<8, 2, 0, LF>(lds + LO(pk::VISB1), lane, xin, acc);
-                elu_to<2, !SP>(acc, t1);
+                elu_to<2, !SP || UA>(acc, t1);
                 v2 = sigmoid1(gsum(dot8(lds + LO(pk::T_VISB2), g, t1)) + lds[LO(pk::T_SCAL) + 2]) * m;   // :481
             }
             vsum += v2;
