@@ -105,7 +105,7 @@ def recorded_pmc(batch):
     try:
         if d is None or batch != 32:
             return None, None, None
-        k = next(v for n, v in d['kernels'].items() if n.startswith('k_chain<6, false, false, false'))
+        k = d['kernels']['k_chain<6, false, false, false, true>']          # V = 6, volume points, inference, no vis branch, pair form
         cycles = k['GRBM_GUI_ACTIVE'] / 8                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         simds = 1024
         tiles = 32 * 64000 / 16

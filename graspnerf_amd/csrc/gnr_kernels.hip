@@ -583,58 +583,84 @@ DEV Taps make_taps(float u, float v, float sx, float sy, float off, int fh, int 
     return t;
 }
 
+// ---- cooperative projection (k_chain's first view loop).  The four lanes of a point (one per lane group) would each compute the
+// same projection, two IEEE divisions and both sets of bilinear taps.  Instead lane group g does ONE axis of ONE map -- axis
+// g & 1 (u / v), map g >> 1 (feature map / full-resolution image): its row of K[R|t], its division, its 1-D tap (two indices
+// and a weight) and its in-image test -- and the groups exchange the results through ds_bpermute_b32 (12 per view; the LDS
+// crossbar, no VALU slot).  Every lane then assembles the 2 x 4 offsets and weights with the operations make_taps() uses,
+// so offsets, weights and the in-image mask are bit for bit the ones of project_view() + make_taps() (the parity suites pass
+// unchanged, all outputs bitwise equal).  The per-group constants (tap scale / offset, last index, image bound, row stride) sit
+// in a 32-float table behind the weight image in LDS.
+// MEASURED NEGATIVE, kept as a switch (default off): 41 vector instructions per view fewer (907 -> 866 in the first view loop,
+// -246 per tile) and the same time -- 3.36 - 3.40 ms per volume launch and 2.45 - 2.46 ms per pair of render launches either
+// way: the exchange puts an LDS round trip at the head of each view's dependency chain.
+#ifndef GNR_COOP_PROJ
+#define GNR_COOP_PROJ 0
+#endif
+constexpr int COOP_TAB_FLOATS = 32;
+struct CoopOut { Taps f, i; float m, z; };
+DEV void project_coop(const float* __restrict__ vp, const float* __restrict__ tab, int row_bytes, int bp, const float (&p)[3], CoopOut& o) {
+    const f4 row = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(vp) + row_bytes);
+    const float pc = __fmaf_rn(row.z, p[2], __fmaf_rn(row.y, p[1], __fmul_rn(row.x, p[0]))) + row.w;
+    float z = __fmaf_rn(vp[10], p[2], __fmaf_rn(vp[9], p[1], __fmul_rn(vp[8], p[0]))) + vp[11];
+    const bool inval = fabsf(z) < 1e-4f;
+    if (inval) z = 1e-3f;
+    o.z = z;
+    const float q = __fdiv_rn(pc, z);
+    const f4 c = reinterpret_cast<const f4*>(tab)[0];                  // tap scale, tap offset, last index, image bound
+    const f4 ci = reinterpret_cast<const f4*>(tab)[1];                 // (as ints) row stride, last index
+    const int stride = __float_as_int(ci.x), n1 = __float_as_int(ci.y);
+    const bool outside = (q < -0.5f) | (q >= c.w);
+    float px = fmaf(q, c.x, c.y);
+    px = fminf(fmaxf(px, 0.f), c.z);
+    const float x0 = floorf(px);
+    const float w1 = px - x0;                                          // in [0, 1): the sign bit carries "not visible along this axis"
+    const int i0 = (int)x0, i1 = min(i0 + 1, n1);
+    const int o0 = __mul24(i0, stride), o1 = __mul24(i1, stride);
+    const int w1b = __float_as_int(w1) | ((outside | inval) ? (int)0x80000000 : 0);
+    int O0[4], O1[4], W1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        O0[k] = __builtin_amdgcn_ds_bpermute(bp + 64 * k, o0);
+        O1[k] = __builtin_amdgcn_ds_bpermute(bp + 64 * k, o1);
+        W1[k] = __builtin_amdgcn_ds_bpermute(bp + 64 * k, w1b);
+    }
+    o.m = ((W1[0] | W1[1]) >= 0) ? 1.f : 0.f;
+    auto assemble = [&](int kx, int ky, Taps& t) {
+        t.o00 = O0[ky] + O0[kx]; t.o01 = O0[ky] + O1[kx]; t.o10 = O1[ky] + O0[kx]; t.o11 = O1[ky] + O1[kx];
+        const float wx1 = fabsf(__int_as_float(W1[kx])), wy1 = fabsf(__int_as_float(W1[ky])), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+    };
+    assemble(0, 1, o.f);
+    assemble(2, 3, o.i);
+}
+// point-to-camera direction against the query direction (the FULL part of project_view)
+DEV void view_dir(const float* __restrict__ vp, const float (&p)[3], const float (&qd)[3], float (&dd)[4]) {
+    float d[3] = {p[0] - vp[12], p[1] - vp[13], p[2] - vp[14]};
+    const float inr = -__builtin_amdgcn_rsqf(fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f));
+    d[0] *= inr; d[1] *= inr; d[2] *= inr;
+    dd[0] = d[0] - qd[0]; dd[1] = d[1] - qd[1]; dd[2] = d[2] - qd[2];
+    dd[3] = d[0] * qd[0] + d[1] * qd[1] + d[2] * qd[2];
+}
+
 constexpr int SW = 20;     // per-view state width: X[9] E[8] gate m rgb  /  H2[8] v2 c . . . rgb
-// The per-view state S[V][SW] lives in registers, so its rows need static indices while the view loops stay rolled (code
-// size).  GNR_ROW_SWITCH 0 (default): S is a queue that advances one row per view -- 100 v_mov per view and loop, 1 440 per
-// tile, 8 % / 11 % of a volume / render launch (measured with the moves compiled out, GNR_ABLATE bit 0, tools/ab_chain.py).
-// GNR_ROW_SWITCH bit 0 / 1 (first / second view loop): a view's row is read / written through wave-uniform branches on the view
-// index instead (V arms of N moves, one of which executes: 20 out in the first loop, 19 in + 10 out in the second; GNR_ROW_ASM
-// 1 writes the moves as volatile inline asm, 0 as plain assignments, which needs -mllvm -simplifycfg-sink-common=false or LLVM
-// merges the arms into one access through a pointer phi and S drops to scratch).  Kept as a measured negative: every variant
-// spills (76 - 144 B of scratch against 12 - 60) and is slower: 3.76 / 4.31 ms (both loops, plain / asm), 3.63 / 3.64 (second
-// loop only), 3.91 / 4.18 (first loop only) against 3.56 ms per volume launch.  Also rejected: full unrolling
-// (code 83 KB > the 64 KB instruction cache, 900 B of scratch: 6.6 ms), two / three copies of the body per trip with the queue
-// advancing two / three rows (200 - 400 B of scratch: 4.85 ms), exchanging the halves of S with v_swap_b32 (6.4 cycles per
-// dword against 3.2 for v_mov_b32, tools/ubench/mov_rates.hip; v_mov_b64 / v_pk_mov_b32 move a dword in 2.8 / 3.1).
-#ifndef GNR_ROW_SWITCH
-#define GNR_ROW_SWITCH 0          // bit 0: first view loop, bit 1: second view loop
+// The per-view state lives in registers, so its rows need static indices while the view loops stay rolled (code size): the
+// state is a QUEUE that advances one row per view: (V-1) x 20 v_mov_b32 per view and loop, 1 320 per tile at V = 6 (14 % of the
+// kernel's vector instructions).  They cost next to nothing: GNR_TWO_QUEUES 1 splits the views into two halves with a queue
+// each and writes every view loop out twice (one rolled loop per queue: (V/2 - 1) x 20 moves per view, 600 per tile, 7 KB more
+// code) and changes a volume launch from 3.35 to 3.32 ms and a render launch from 2.43 to 2.51 (more scratch: 88 B) -- the
+// moves issue while the SIMD's other wavefront owns the matrix pipe.  (An earlier "no moves" ablation that showed 8 - 11 % had
+// let the compiler hoist the second loop's now view-invariant operand splits out of the loop.)  Kept as a switch, default off.
+// Other measured negatives: addressing the row through wave-uniform branches on the view index (V arms of 20
+// moves; every variant spills, 3.63 - 4.31 ms against 3.56); full unrolling (code 83 KB, 900 B of scratch: 6.6 ms); two / three
+// bodies per trip with the queue advancing two / three rows (200 - 400 B of scratch: 4.85 ms); v_swap_b32 (6.4 cycles per dword),
+// v_mov_b64 / v_pk_mov_b32 (2.8 / 3.1 cycles per dword against 3.2 for v_mov_b32, tools/ubench/mov_rates.hip).
+#ifndef GNR_TWO_QUEUES
+#define GNR_TWO_QUEUES 0
 #endif
-#define GNR_RS1 ((GNR_ROW_SWITCH & 1) != 0)
-#define GNR_RS2 ((GNR_ROW_SWITCH & 2) != 0)
-#ifndef GNR_ROW_ASM
-#define GNR_ROW_ASM 1
-#endif
-// S[v][O .. O+N) = R   /   R = S[v][O .. O+N)   for a wave-uniform v
-template <int K, int O, int V, int N>
-DEV void row_put(float (&S)[V][SW], int v, const float (&R)[N]) {
-    if constexpr (K < V) {
-        if (v == K) {
-#pragma unroll
-#if GNR_ROW_ASM
-            for (int q = 0; q < N; ++q) asm volatile("v_mov_b32 %0, %1" : "+v"(S[K][O + q]) : "v"(R[q]));
-#else
-            for (int q = 0; q < N; ++q) S[K][O + q] = R[q];
-#endif
-        } else {
-            row_put<K + 1, O, V, N>(S, v, R);
-        }
-    }
-}
-template <int K, int O, int V, int N>
-DEV void row_get(float (&S)[V][SW], int v, float (&R)[N]) {
-    if constexpr (K < V) {
-        if (v == K) {
-#pragma unroll
-#if GNR_ROW_ASM
-            for (int q = 0; q < N; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(R[q]) : "v"(S[K][O + q]));
-#else
-            for (int q = 0; q < N; ++q) R[q] = S[K][O + q];
-#endif
-        } else {
-            row_get<K + 1, O, V, N>(S, v, R);
-        }
-    }
-}
+// rows of the two queues
+constexpr int rows_a(int V) { return GNR_TWO_QUEUES ? (V + 1) / 2 : V; }
+constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
 
 #ifndef GNR_CHAIN_THREADS
 #define GNR_CHAIN_THREADS 512     // 8 wavefronts = 2 per SIMD at 250 registers; 256 (1 per SIMD, 512 registers) was measured too;
@@ -667,6 +693,19 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         const f4* src = reinterpret_cast<const f4*>(a.wpk + (SP ? pk::C16 : 0));
         f4* dst = reinterpret_cast<f4*>(lds);
         for (int i = threadIdx.x; i < (SP ? pk::C16_END : pk::CHAIN_END) / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    constexpr int COOP_TAB = SP ? pk::C16_END : pk::CHAIN_END;            // per-lane-group constants of project_coop
+    if (threadIdx.x < 4) {
+        const int gg = threadIdx.x, axis = gg & 1, img = gg >> 1;
+        const int n = img ? (axis ? a.H : a.W) : (axis ? a.fh : a.fw);
+        float* tb = lds + COOP_TAB + gg * 8;
+        tb[0] = img ? 1.f : (axis ? (float)a.fh / (float)(a.H - 1) : (float)a.fw / (float)(a.W - 1));
+        tb[1] = img ? 0.f : -0.5f;
+        tb[2] = (float)(n - 1);
+        tb[3] = (float)(axis ? a.H : a.W) - 0.5f;
+        tb[4] = __int_as_float(axis ? (img ? a.W : a.fw) : 1);
+        tb[5] = __int_as_float(n - 1);
+        tb[6] = 0.f; tb[7] = 0.f;
     }
     __syncthreads();
 
@@ -715,14 +754,17 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             const f4 d0 = reinterpret_cast<const f4*>(a.desc)[pt * 2], d1 = reinterpret_cast<const f4*>(a.desc)[pt * 2 + 1];
             p[0] = d0.x; p[1] = d0.y; p[2] = d0.z; qd[0] = d0.w; qd[1] = d1.x; qd[2] = d1.y; lo = d1.z; hi = d1.w;
         }
-        float S[V][SW];
+        constexpr int VA = rows_a(V), VB = rows_b(V);
+        float SA[VA][SW], SB[VB > 0 ? VB : 1][SW];
+        // row of view v (v a compile-time constant after unrolling: the branch folds)
+        auto S = [&](int v, int q) -> float& { return (VB == 0 || v < VA) ? SA[v < VA ? v : 0][q] : SB[v >= VA ? v - VA : 0][q]; };
 #pragma unroll
         for (int k = 0; k < V; ++k)
 #pragma unroll
 #if GNR_ABLATE & 1
-            for (int q = 0; q < SW; ++q) S[k][q] = p[0] * (float)(k * SW + q + 1);      // opaque values: nothing downstream folds away
+            for (int q = 0; q < SW; ++q) S(k, q) = p[0] * (float)(k * SW + q + 1);      // opaque values: nothing downstream folds away
 #else
-            for (int q = 0; q < SW; ++q) S[k][q] = 0.f;
+            for (int q = 0; q < SW; ++q) S(k, q) = 0.f;
 #endif
         float msum = 0.f;
         unsigned vbits = 0;
@@ -734,28 +776,36 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #endif
 
         // ================= phase 1: per view, everything up to the first cross-view reduction
+        // Q: one of the two queues; the views v0 .. v0 + rows - 1 enter it in order (the loop is instantiated once per queue)
+        auto phase1 = [&](auto& Q, const int v0) __attribute__((always_inline)) {
+          constexpr int NQ = (int)(sizeof(Q) / sizeof(Q[0]));
 #pragma unroll 1
-        for (int v = 0; v < V; ++v) {
-#if !GNR_RS1 && !(GNR_ABLATE & 1)
+          for (int v = v0; v < v0 + NQ; ++v) {
+#if !(GNR_ABLATE & 1)
 #pragma unroll
-            for (int k = 0; k < V - 1; ++k)
+            for (int k = 0; k < NQ - 1; ++k)
 #pragma unroll
-                for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
+                for (int q = 0; q < SW; ++q) Q[k][q] = Q[k + 1][q];
 #endif
-          {
             GNR_ITER_FENCE();
-#if GNR_RS1
-            float Sv[SW];
-#else
-            float (&Sv)[SW] = S[V - 1];
-#endif
+            float (&Sv)[SW] = Q[NQ - 1];
             const int bv = b * V + v;
             const float* vp = a.viewp + bv * VIEWP_FLOATS;
-#if GNR_ABLATE & 2
-            const ViewGeom vg = vg0;
-#else
             ViewGeom vg;
+            Taps t, ti;
+#if GNR_ABLATE & 2
+            vg = vg0; t = t0; ti = ti0;
+#elif GNR_COOP_PROJ
+            {
+                CoopOut co;
+                project_coop(vp, lds + COOP_TAB + g * 8, (g & 1) * 16, (lane & 15) << 2, p, co);
+                view_dir(vp, p, qd, vg.dd);
+                vg.z = co.z; vg.m = co.m; t = co.f; ti = co.i;
+            }
+#else
             project_view<true>(vp, p, qd, a.H, a.W, vg);
+            t = make_taps(vg.u, vg.v, fsx, fsy, -0.5f, a.fh, a.fw);
+            ti = make_taps(vg.u, vg.v, 1.f, 1.f, 0.f, a.H, a.W);
 #endif
             const float m = vg.m;
             msum += m;
@@ -764,11 +814,6 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             // ---- gather: ray channels 8g..8g+7, image-feature channels 8g..8g+7, rgb channel g
             float FR[8], XI[9];
             {
-#if GNR_ABLATE & 2
-                const Taps t = t0;
-#else
-                const Taps t = make_taps(vg.u, vg.v, fsx, fsy, -0.5f, a.fh, a.fw);
-#endif
                 const float* fb = a.feat64 + (size_t)bv * a.fh * a.fw * 64 + 8 * g;
                 const f4* q00 = reinterpret_cast<const f4*>(fb + (size_t)t.o00 * 64);
                 const f4* q01 = reinterpret_cast<const f4*>(fb + (size_t)t.o01 * 64);
@@ -784,11 +829,6 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                     FR[4 * h] = fr.x; FR[4 * h + 1] = fr.y; FR[4 * h + 2] = fr.z; FR[4 * h + 3] = fr.w;
                     XI[4 * h] = fi.x; XI[4 * h + 1] = fi.y; XI[4 * h + 2] = fi.z; XI[4 * h + 3] = fi.w;
                 }
-#if GNR_ABLATE & 2
-                const Taps ti = ti0;
-#else
-                const Taps ti = make_taps(vg.u, vg.v, 1.f, 1.f, 0.f, a.H, a.W);
-#endif
                 const float* ib = a.imgs + ((size_t)bv * 3 + min(g, 2)) * a.H * a.W;
                 const float rgb = (ib[ti.o00] * ti.w00 + ib[ti.o01] * ti.w01 + ib[ti.o10] * ti.w10 + ib[ti.o11] * ti.w11) * m;
                 XI[8] = g < 3 ? rgb : 0.f;
@@ -907,15 +947,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #pragma unroll
                 for (int q = 0; q < 19; ++q) sp[q * 64] = Sv[q];
             }
-#if GNR_RS1 && !(GNR_ABLATE & 1)
-            row_put<0, 0, V, SW>(S, v, Sv);
-#elif GNR_RS1
-#pragma unroll
-            for (int q = 0; q < SW; ++q) S[V - 1][q] = Sv[q];
-#endif
             if (a.dbg && g == 0 && row_ok) { a.dbg[pt * 32 + v] = hit; a.dbg[pt * 32 + 8 + v] = vis; }
           }
-        }
+        };
+        phase1(SA, 0);
+        if constexpr (VB > 0) phase1(SB, VA);
 
         // ================= cross-view reduction 1 (ibrnet.py:466-472), in-lane
         float SV[36];
@@ -926,16 +962,16 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 float mu0 = 0.f, mu1 = 0.f;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    const float w = S[v][18] * inv_msum;
-                    mu0 += S[v][j] * (S[v][17] * w);
-                    mu1 += S[v][j] * w;
+                    const float w = S(v, 18) * inv_msum;
+                    mu0 += S(v, j) * (S(v, 17) * w);
+                    mu1 += S(v, j) * w;
                 }
                 float va0 = 0.f, va1 = 0.f;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    const float w = S[v][18] * inv_msum;
-                    const float d0 = S[v][j] - mu0, d1 = S[v][j] - mu1;
-                    va0 += (S[v][17] * w) * d0 * d0;
+                    const float w = S(v, 18) * inv_msum;
+                    const float d0 = S(v, j) - mu0, d1 = S(v, j) - mu1;
+                    va0 += (S(v, 17) * w) * d0 * d0;
                     va1 += w * d1 * d1;
                 }
                 SV[j] = mu0; SV[9 + j] = va0; SV[18 + j] = mu1; SV[27 + j] = va1;
@@ -959,27 +995,21 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 
         // ================= phase 2: per view, base_fc / vis_fc / vis_fc2 (/ rgb_fc)
         float vsum = 0.f;
+        // the oldest row of the queue is copied out, the queue advances, the view's results become its last row
+        auto phase2 = [&](auto& Q, const int v0) __attribute__((always_inline)) {
+          constexpr int NQ = (int)(sizeof(Q) / sizeof(Q[0]));
 #pragma unroll 1
-        for (int v = 0; v < V; ++v) {
-          // GNR_RS2: the view's row is fetched, and its results put back, through branches on v.
-          // Queue form: the oldest row is copied out, the queue advances, the view's results become its last row.
-          constexpr int RN = (SAVE && RENDER) || !GNR_RS2 ? 20 : 19;     // the raw rgb (column 19) stays in its row
-          float Rv[RN];
-#if GNR_RS2 && !(GNR_ABLATE & 1)
-          row_get<0, 0, V, RN>(S, v, Rv);
-#else
+          for (int v = v0; v < v0 + NQ; ++v) {
+            constexpr int RN = 20;
+            float Rv[RN];
 #pragma unroll
-          for (int j = 0; j < RN; ++j) Rv[j] = S[0][j];
-#if !GNR_RS2
+            for (int j = 0; j < RN; ++j) Rv[j] = Q[0][j];
 #if !(GNR_ABLATE & 1)
 #pragma unroll
-          for (int k = 0; k < V - 1; ++k)
+            for (int k = 0; k < NQ - 1; ++k)
 #pragma unroll
-              for (int q = 0; q < SW; ++q) S[k][q] = S[k + 1][q];
+                for (int q = 0; q < SW; ++q) Q[k][q] = Q[k + 1][q];
 #endif
-#endif
-#endif
-          {
             GNR_ITER_FENCE();
             float X[9], E[8];
 #pragma unroll
@@ -1083,18 +1113,14 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 for (int q = 0; q < (S2W < 10 ? S2W : 10); ++q) sp[q * 64] = Ov[q];
                 if constexpr (RENDER) sp[10 * 64] = Rv[RN - 1];
             }
-#if GNR_RS2 && !(GNR_ABLATE & 1)
-            row_put<0, 0, V, 10>(S, v, Ov);
-#else
 #pragma unroll
-            for (int j = 0; j < 10; ++j) S[V - 1][j] = Ov[j];
-#if !GNR_RS2
-            S[V - 1][19] = Rv[19];
-#endif
-#endif
+            for (int j = 0; j < 10; ++j) Q[NQ - 1][j] = Ov[j];
+            Q[NQ - 1][19] = Rv[19];
             if (a.dbg && g == 0 && row_ok) a.dbg[pt * 32 + 16 + v] = v2;
           }
-        }
+        };
+        phase2(SA, 0);
+        if constexpr (VB > 0) phase2(SB, VA);
 
         // ================= cross-view reduction 2 (ibrnet.py:482-484,488) + colour blend (:510-511)
         float Z[23];
@@ -1102,25 +1128,25 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         {
             const float inv_vsum = rcp1(vsum + 1e-8f);
 #pragma unroll
-            for (int v = 0; v < V; ++v) wbar += S[v][8] * inv_vsum;
+            for (int v = 0; v < V; ++v) wbar += S(v, 8) * inv_vsum;
             wbar *= (1.f / (float)V);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float mu = 0.f, va = 0.f;
 #pragma unroll
-                for (int v = 0; v < V; ++v) mu += S[v][j] * (S[v][8] * inv_vsum);
+                for (int v = 0; v < V; ++v) mu += S(v, j) * (S(v, 8) * inv_vsum);
 #pragma unroll
-                for (int v = 0; v < V; ++v) { const float d = S[v][j] - mu; va += (S[v][8] * inv_vsum) * d * d; }
+                for (int v = 0; v < V; ++v) { const float d = S(v, j) - mu; va += (S(v, 8) * inv_vsum) * d * d; }
                 Z[j] = mu; Z[8 + j] = va;
             }
         }
         if constexpr (RENDER) {
             float cmax = -3.0e38f;
 #pragma unroll
-            for (int v = 0; v < V; ++v) cmax = fmaxf(cmax, S[v][9]);
+            for (int v = 0; v < V; ++v) cmax = fmaxf(cmax, S(v, 9));
             float den = 0.f, num = 0.f;
 #pragma unroll
-            for (int v = 0; v < V; ++v) { const float e = __expf(S[v][9] - cmax); den += e; num += S[v][19] * e; }
+            for (int v = 0; v < V; ++v) { const float e = __expf(S(v, 9) - cmax); den += e; num += S(v, 19) * e; }
             if (g < 3 && row_ok) a.colors[pt * 3 + g] = num * rcp1(den);
         }
         if (SAVE && a.saveZ) {

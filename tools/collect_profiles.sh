@@ -6,7 +6,7 @@
 # 3. rocprofv3 --kernel-trace --stats of steady-state train steps      -> <tag>_train_step_kernel_stats.txt
 # 4. the default bench.py line (forward + train_step + with_backbones + cpu_baseline) -> <tag>_bench.json
 # Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 R=$PWD
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
@@ -30,6 +30,8 @@ python tools/pmc_summary.py gpurun_out/$TAG/pmc gpurun_out/$TAG/pmc_counters.jso
 cp gpurun_out/$TAG/pmc_counters.json profiles/${TAG}_pmc_counters.json
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 [ -x tools/ubench/split_mfma ] && timeout 60 tools/ubench/split_mfma > gpurun_out/$TAG/split_mfma_ubench.txt 2>&1
+[ -x tools/ubench/mov_rates ] && timeout 60 tools/ubench/mov_rates > gpurun_out/$TAG/mov_rates_ubench.txt 2>&1
+python tools/isa_stats.py --no-compile --dir gpurun_out/$TAG/isa > /dev/null 2>&1 || true
 head -14 gpurun_out/$TAG/bench_kernel_stats.txt
 head -30 gpurun_out/$TAG/train_step_kernel_stats.txt | cut -c1-130
 tail -1 gpurun_out/$TAG/bench.json | cut -c1-300

@@ -19,7 +19,7 @@ for f in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive
             k = m.group(1)
             # the backward passes (pmc/bwd_*: tools/time_volume_bwd.py, 8 scenes) also launch inference kernels at another batch
             # size: keep only the training kernels from them
-            if os.sep + 'bwd_' in ff and not ('_bwd' in k or k.endswith(', true>') and k.startswith('k_chain')):
+            if os.sep + 'bwd_' in ff and not ('_bwd' in k or re.match(r'k_chain<\d+, (true|false), true,', k)):      # k_chain<V, RENDER, SAVE, ..>
                 continue
             acc[k][cname].append(v)
 res = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
