@@ -1277,8 +1277,16 @@ DEV void head_logits_s(const float (&qs)[16], const float* __restrict__ Kj, floa
 #ifndef GNR_RAY_UNROLL
 #define GNR_RAY_UNROLL 1
 #endif
+// LDS per ray: K [dn][16], V [dn][16], squared key norms [dn][4]; the render kernel's column pass re-uses the same floats for
+// Q [dn][16], dO [dn][16] and the row statistics [dn][12] once every lane is past the row pass (RAY_PER floats per sample: 7.2 KB
+// per 40-sample ray, 43 KB per workgroup of six rays), which lets THREE workgroups share a CU (launch bounds 3: <= 168
+// registers) where the separate Q / dO / statistics arrays (76 floats per sample) allowed two.
+#ifndef GNR_RAY_BLOCKS
+#define GNR_RAY_BLOCKS 3
+#endif
+constexpr int ray_per(bool render) { return render ? (GNR_RAY_BLOCKS >= 3 ? 44 : 80) : 36; }
 template <bool RENDER>
-__global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
+__global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int dn = a.dn, S = a.slots, rpb = a.rays_per_block;
     // thread -> (ray in block, slot).  Threads beyond the last ray of the block / launch shadow the last valid
@@ -1292,17 +1300,16 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
     const int ray = min(ray_u, a.nrays - 1);
     const bool act = rvalid && slot < dn;
     const int i = min(slot, dn - 1);
-    constexpr int PER = RENDER ? 76 : 36;            // floats of attention scratch per sample
+    constexpr bool OVL = RENDER && GNR_RAY_BLOCKS >= 3;   // Q / dO / statistics overlay K / V / key norms
     float* sc = sm + (size_t)rl * a.ray_stride;
     float* Kb = sc;                                   // [dn][16]
     float* Vb = sc + dn * 16;                         // [dn][16]
-    float* Qb = sc + dn * 32;                         // [dn][16]   (RENDER)
-    float* Ob = sc + dn * 48;                         // [dn][16]   dO  (RENDER)
-    float* St = sc + dn * 64;                         // [dn][12]   shift[4] (log2 domain), 1/sum[4], rs[4] (RENDER)
-    // squared key norms per head: in the dO slots until the VJP needs them (RENDER), else 4 extra floats per sample
-    float* KN = RENDER ? Ob : sc + dn * 32;
-    constexpr int KNS = RENDER ? 16 : 4;
-    (void)PER; (void)Qb; (void)St;
+    float* KN = sc + dn * 32;                         // [dn][4]    squared key norms per head
+    constexpr int KNS = 4;
+    float* Qb = OVL ? sc : sc + dn * 36;              // [dn][16]   (RENDER, column pass)
+    float* Ob = OVL ? sc + dn * 16 : sc + dn * 52;    // [dn][16]   dO
+    float* St = OVL ? sc + dn * 32 : sc + dn * 68;    // [dn][12]   shift[4] (log2 domain), 1/sum[4], rs[4]
+    (void)Qb; (void)St; (void)Ob;
     const size_t pt = (size_t)ray * dn + i;
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
     const float* rec = a.rec + pt * REC;
@@ -1349,7 +1356,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             reinterpret_cast<f4*>(Kb + i * 16)[c] = k4;
             reinterpret_cast<f4*>(Vb + i * 16)[c] = v4;
             KN[i * KNS + c] = k4.x * k4.x + k4.y * k4.y + k4.z * k4.z + k4.w * k4.w;
-            if constexpr (RENDER) {
+            if constexpr (RENDER && !OVL) {
                 const f4 q4 = {qs[4 * c], qs[4 * c + 1], qs[4 * c + 2], qs[4 * c + 3]};
                 reinterpret_cast<f4*>(Qb + i * 16)[c] = q4;
             }
@@ -1499,12 +1506,24 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
                 dQ[4 * h] = d4.x; dQ[4 * h + 1] = d4.y; dQ[4 * h + 2] = d4.z; dQ[4 * h + 3] = d4.w;
             }
         }
-        __syncthreads();                                  // every lane is past the key-norm sweep: the dO slots are free
+        if constexpr (OVL) {                              // the lane's own key / value row, before the arrays are re-used
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f4 k4 = reinterpret_cast<const f4*>(Kb + i * 16)[c], v4 = reinterpret_cast<const f4*>(Vb + i * 16)[c];
+                kk[4 * c] = k4.x; kk[4 * c + 1] = k4.y; kk[4 * c + 2] = k4.z; kk[4 * c + 3] = k4.w;
+                vv[4 * c] = v4.x; vv[4 * c + 1] = v4.y; vv[4 * c + 2] = v4.z; vv[4 * c + 3] = v4.w;
+            }
+        }
+        __syncthreads();                                  // every lane is past the row pass (and the key-norm sweep): K / V / KN are free
         if (act) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const f4 d4 = {dO[4 * c], dO[4 * c + 1], dO[4 * c + 2], dO[4 * c + 3]};
                 reinterpret_cast<f4*>(Ob + i * 16)[c] = d4;
+                if constexpr (OVL) {
+                    const f4 q4 = {qs[4 * c], qs[4 * c + 1], qs[4 * c + 2], qs[4 * c + 3]};
+                    reinterpret_cast<f4*>(Qb + i * 16)[c] = q4;
+                }
             }
             const f4 m4 = {amax[0], amax[1], amax[2], amax[3]}, i4 = {ainv[0], ainv[1], ainv[2], ainv[3]};
             const f4 r4 = {rsv[0], rsv[1], rsv[2], rsv[3]};
@@ -1544,6 +1563,15 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
             }
         }
         // dT = dy (residual) + Wq^T dQ + Wk^T dK + Wv^T dV ; dc = dT * ELU'(c) with ELU' = g>0 ? 1 : g+1
+        float g16b[16];                                   // geometry_fc's output again (re-read: 16 registers less across the sweeps)
+        {
+            const f4* r4 = reinterpret_cast<const f4*>(rec);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f4 x = __builtin_nontemporal_load(r4 + q4);
+                g16b[4 * q4] = x.x; g16b[4 * q4 + 1] = x.y; g16b[4 * q4 + 2] = x.z; g16b[4 * q4 + 3] = x.w;
+            }
+        }
         float dc[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -1554,7 +1582,7 @@ __global__ __launch_bounds__(256, 2) void k_ray(RayArgs a) {
                 s = fmaf(W[pk::R_WKT + c * 16 + f], dK[f], s);
                 s = fmaf(W[pk::R_WVT + c * 16 + f], dV[f], s);
             }
-            dc[c] = s * (g16[c] > 0.f ? 1.f : g16[c] + 1.f);
+            dc[c] = s * (g16b[c] > 0.f ? 1.f : g16b[c] + 1.f);
         }
         // geometry_fc backward, streamed over the 64 hidden units; only the 21 embed columns matter
         float de[21];
