@@ -147,7 +147,9 @@ def lib():
     L.gnr_host_randperm_prefix.restype = C.c_int
     L.gnr_geo_dual_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
     L.gnr_geo_dual_fwd.restype = C.c_int
-    L.gnr_geo_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
+    L.gnr_geo_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_geo_dual_bwd_workspace_bytes.argtypes = [C.c_int]
+    L.gnr_geo_dual_bwd_workspace_bytes.restype = C.c_size_t
     L.gnr_geo_dual_bwd.restype = C.c_int
     L.gnr_composite_bwd.restype = C.c_int
     L.gnr_render_tail_fwd_train.restype = C.c_int
@@ -186,7 +188,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
             'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
-            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_composite_bwd', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_host_randperm_prefix']
+            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_composite_bwd', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix']
 
 
 def check(rc, what):

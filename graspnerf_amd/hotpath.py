@@ -353,8 +353,12 @@ class HotPath:
         P = stats.shape[0]
         dstats = torch.empty(P, 66, dtype=torch.float32, device=self.device)
         dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
+        need = self.L.gnr_geo_dual_bwd_workspace_bytes(P)
+        if getattr(self, '_gd_scratch', None) is None or self._gd_scratch.numel() < need:
+            self._gd_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         _lib.check(self.L.gnr_geo_dual_bwd(canon.data_ptr(), stats.data_ptr(), pts.data_ptr(), gamma.data_ptr(), gbar.data_ptr(),
-                                           gdbar.data_ptr(), dstats.data_ptr(), dcan.data_ptr(), P, self._stream()), 'gnr_geo_dual_bwd')
+                                           gdbar.data_ptr(), dstats.data_ptr(), dcan.data_ptr(), P, self._gd_scratch.data_ptr(),
+                                           self._gd_scratch.numel(), self._stream()), 'gnr_geo_dual_bwd')
         return dstats, dcan
 
     def composite_bwd(self, level, sdf, grad, col, depth, qdir, dpix, ddepth=None, wgerr=None, dalpha=None, dhit=None):

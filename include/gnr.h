@@ -275,8 +275,11 @@ int gnr_ray_tail_grad_floats(void);
  * (overwritten) and the gradients of geometry_fc.{0,2}.{weight,bias} ACCUMULATED into d_canonical (state-dict order).   */
 int gnr_geo_dual_fwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, float* g, float* gd,
                      int P, void* stream);
+/* bwd runs as two kernels (one lane per point; then the weight-gradient outer products over the points on the matrix cores) with the
+ * per-point adjoints between them in caller-owned scratch of gnr_geo_dual_bwd_workspace_bytes(P) bytes (288 floats per point). */
+size_t gnr_geo_dual_bwd_workspace_bytes(int P);
 int gnr_geo_dual_bwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, const float* gbar,
-                     const float* gdbar, float* dstats, float* d_canonical, int P, void* stream);
+                     const float* gdbar, float* dstats, float* d_canonical, int P, void* scratch, size_t scratch_bytes, void* stream);
 /* Backward of NeuS alpha + compositing (aggregate_net.py:105-121, render_ops.py:72-80, renderer.py:110-123) for a flat list
  * of rays, forward values taken from the tensors the forward wrote: sdf [nrays*dn], grad, col [nrays*dn,3], depth
  * [nrays*dn], qdir [nrays,3].  Upstream: dpix [nrays,3]; ddepth [nrays], wgerr [nrays] (d L / d sum_k (|grad_k|-1)^2 of the

@@ -334,7 +334,9 @@ def test_training_tail_entry_points_validate_arguments():
     assert L.gnr_composite_bwd(p, p, p, p, p, p, p, None, None, None, None, p, p, p, p, 4, 70, None) == -2
     assert L.gnr_geo_dual_fwd(p, p, p, None, p, p, 10, None) == -1
     assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 0, None) == -2
-    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, None, 10, None) == -1
+    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, None, 10, p, 1 << 20, None) == -1
+    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, p, 10, p, 16, None) == -4             # scratch too small
+    assert L.gnr_geo_dual_bwd_workspace_bytes(10) >= 10 * 288 * 4
     assert b'geo_dual_bwd' in L.gnr_last_error()
 
 
