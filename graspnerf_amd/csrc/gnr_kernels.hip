@@ -366,34 +366,38 @@ __global__ __launch_bounds__(256) void k_repack_feats(const float* __restrict__ 
     const int bv = blockIdx.y, p0 = blockIdx.x * 64, t = threadIdx.x;
     const int tx = t & 63, ty = t >> 6;
     const size_t in_base = (size_t)bv * 32 * npix;
-    bool bad = false;
 #pragma unroll
     for (int c0 = 0; c0 < 64; c0 += 4) {
         const int c = c0 + ty, p = p0 + tx;
         float v = 0.f;
         if (p < npix) v = (c < 32) ? ray_feats[in_base + (size_t)c * npix + p] : img_feats[in_base + (size_t)(c - 32) * npix + p];
-        bad |= !(fabsf(v) < kFeatLimit);                   // also true for NaN / inf
         tile[c][tx] = v;
     }
-    // range guard of k_chain's pair form (RangeWatch): bit 0 = a feature beyond the fp16-pair range or not finite
-    if (range_flag && __ballot(bad) != 0 && (t & 63) == 0) atomicOr(range_flag, 1u);
     __syncthreads();
     float* o = out + ((size_t)bv * npix + p0) * 64;
+    // range guard of k_chain's pair form (4.1d): bit 0 = a feature beyond the fp16-pair range or not finite.  Tested on the way
+    // out, four values per test: the largest magnitude of a float4 against the limit, and its sum for NaN (max drops NaN, + keeps it)
+    float amax = 0.f, nansum = 0.f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = it * 256 + t;           // float4 index within the 64x64 tile
         const int p = idx >> 4, c4 = (idx & 15) * 4;
         if (p0 + p < npix) {
             f4 v = {tile[c4][p], tile[c4 + 1][p], tile[c4 + 2][p], tile[c4 + 3][p]};
+            amax = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), amax);
+            nansum += (v.x + v.y) + (v.z + v.w);
             reinterpret_cast<f4*>(o)[idx] = v;
         }
     }
+    const bool bad = !(amax < kFeatLimit) || nansum != nansum;
+    if (range_flag && __ballot(bad) != 0 && (t & 63) == 0) atomicOr(range_flag, 1u);
 }
 
 // ref: render_ops.py:94 (K @ Rt), :112 (camera centre), dist_decoder.py:17-20
 __global__ void k_view_setup(const float* __restrict__ poses, const float* __restrict__ Ks,
-                             const float* __restrict__ dr, float* __restrict__ viewp, int nviews) {
+                             const float* __restrict__ dr, float* __restrict__ viewp, int nviews, unsigned* __restrict__ range_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && range_flag) *range_flag = 0u;            // gnr_prepare launches this kernel first: a new watch word per prepare
     if (i >= nviews) return;
     const float* P = poses + i * 12;
     const float* K = Ks + i * 9;
