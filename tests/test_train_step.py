@@ -32,23 +32,27 @@ render_depth: true
 """)
 
 
-def build(device='cpu', reference_statement=None):
+FIXTURES = {'a': ('golden_train_step.npz', dict(scene_id=0, weight_seed=7, torch_seed=321, loss_seed=5)),
+            'b': ('golden_train_step_b.npz', dict(scene_id=3, weight_seed=11, torch_seed=77, loss_seed=9))}   # tools/make_goldens.py run_train_step
+
+
+def build(device='cpu', reference_statement=None, weight_seed=7):
     """The model mirror with synthetic parameters.  On the CPU (or with reference_statement=True) its training forward
     runs the differentiable PyTorch statement of the path (tests/reference_autograd.py: test infrastructure -- the product
     trains through its HIP twin pairs only and raises without a GPU)."""
     from graspnerf_amd.renderer import GraspNeRF
     from reference_autograd import use_reference_statement
     net = GraspNeRF(CFG)
-    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=weight_seed)
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()}, strict=True)
     if reference_statement if reference_statement is not None else (str(device) == 'cpu'):
         use_reference_statement(net)
     return net.to(device)
 
 
-def scene_data(device='cpu', scene_id=0):
+def scene_data(device='cpu', scene_id=0, loss_seed=5):
     ref, que = make_scene(scene_id, 'cfg1')
-    _, gt = synth_loss_case()
+    _, gt = synth_loss_case(seed=loss_seed)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     ref_info = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
     ref_info.update(true_depth=t(gt['true_depth']), sdf_gt=t(gt['sdf_gt']))
@@ -81,14 +85,17 @@ def check_against_golden(net, terms, G, rtol_loss, rtol_grad, rtol_backbone=None
     assert worst[0] < (rtol_backbone or rtol_grad), f'gradient-norm mismatch {worst}'
 
 
-def test_train_step_gradients_match_reference():
-    """CPU, bitwise-same RNG draws as the reference (seed 321): random fine samples, depth-loss pixels."""
+@pytest.mark.parametrize('fx', ['a', 'b'])
+def test_train_step_gradients_match_reference(fx):
+    """CPU, bitwise-same RNG draws as the reference: random fine samples, depth-loss pixels.  Two fixtures made by the imported
+    reference: two scenes, two parameter draws, two RNG streams."""
     from graspnerf_amd.trainer import train_losses
     from graspnerf_amd import losses
-    G = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_step.npz')))
-    net = build().train()
-    data = scene_data()
-    torch.manual_seed(321)
+    name, su = FIXTURES[fx]
+    G = dict(np.load(os.path.join(ROOT, 'tests', 'golden', name)))
+    net = build(weight_seed=su['weight_seed']).train()
+    data = scene_data(scene_id=su['scene_id'], loss_seed=su['loss_seed'])
+    torch.manual_seed(su['torch_seed'])
     out = net(data)
     assert out['s'].shape == (1, 2) and out['sdf_gradient_error_fine'].shape == (1, 2)      # 64 rays, chunks of 40
     terms = train_losses(out, data)
@@ -236,15 +243,17 @@ def test_product_refuses_to_train_without_a_gpu():
 
 
 @pytest.mark.gpu
-def test_train_step_on_gpu_matches_reference_gradients():
+@pytest.mark.parametrize('fx', ['a', 'b'])
+def test_train_step_on_gpu_matches_reference_gradients(fx):
     """Same check with the model on the MI355X: the volumetric path in HIP in both directions (renderer.py autograd.Functions over
     csrc/gnr_bwd.inc), backbones / grasp head / losses under PyTorch autograd."""
     from graspnerf_amd.trainer import train_losses
     from graspnerf_amd import losses
-    G = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_step.npz')))
-    net = build('cuda').train()
-    data = scene_data('cuda')
-    torch.manual_seed(321)
+    name, su = FIXTURES[fx]
+    G = dict(np.load(os.path.join(ROOT, 'tests', 'golden', name)))
+    net = build('cuda', weight_seed=su['weight_seed']).train()
+    data = scene_data('cuda', scene_id=su['scene_id'], loss_seed=su['loss_seed'])
+    torch.manual_seed(su['torch_seed'])
     terms = train_losses(net(data), data)
     losses.total_loss(terms).backward()
     torch.cuda.synchronize()

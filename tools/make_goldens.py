@@ -401,11 +401,12 @@ def run_full_forward(renderer):
     print('full forward golden:', {k: v.shape for k, v in g.items()})
 
 
-def run_train_step(renderer):
-    """One training step of the reference (trainer.py:142-158): GraspNeRF.forward in train mode on the cfg1 scene with
+def run_train_step(renderer, scene_id=0, weight_seed=7, torch_seed=321, loss_seed=5, out_name='golden_train_step.npz'):
+    """One training step of the reference (trainer.py:142-158): GraspNeRF.forward in train mode on a cfg1 scene with
     synthetic supervision (synth_loss_case targets), the configured losses (loss: [render, depth, sdf, vgn]), backward.
-    -> tests/golden/golden_train_step.npz: every loss term, the gradient of every hot-path parameter (full arrays) and the
-    L2 norm of every parameter's gradient."""
+    -> tests/golden/<out_name>: every loss term, the gradient of every hot-path parameter (full arrays) and the
+    L2 norm of every parameter's gradient.  Two fixtures are kept: the defaults (golden_train_step.npz) and a
+    second scene / parameter draw / RNG stream (golden_train_step_b.npz: scene 3, weight seed 11, torch seed 77, loss case 9)."""
     _stub_optional_modules()
     import network.loss as L
     cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
@@ -418,10 +419,10 @@ def run_train_step(renderer):
     renderer.TSDF_SAMPLE_POINTS = fu.generate_grid_points()
     net = renderer.GraspNeRF(cfg)
     net.train()
-    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=weight_seed)
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
-    ref, que = make_scene(0, 'cfg1')
-    _, gt = synth_loss_case()
+    ref, que = make_scene(scene_id, 'cfg1')
+    _, gt = synth_loss_case(seed=loss_seed)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     ref_info = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
     ref_info.update(true_depth=t(gt['true_depth']), sdf_gt=t(gt['sdf_gt']))
@@ -429,7 +430,7 @@ def run_train_step(renderer):
                 'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
     data = {'step': 0, 'ref_imgs_info': ref_info, 'que_imgs_info': que_info, 'src_imgs_info': dict(ref_info),
             'grasp_info': tuple(t(x) for x in gt['grasp_info']), 'scene_name': 'vgn_syn/train/pile/x'}
-    torch.manual_seed(321)
+    torch.manual_seed(torch_seed)
     out = net(data)
     terms = {}
     for loss in (L.RenderLoss({'use_nr_fine_loss': True}), L.DepthLoss({}), L.SDFLoss({}), L.VGNLoss({})):
@@ -447,7 +448,8 @@ def run_train_step(renderer):
     g['param_names'] = np.array(names)
     g['grad_norms'] = np.asarray(norms)
     g['no_grad'] = np.array([k for k, p in net.named_parameters() if p.grad is None])
-    np.savez_compressed(ROOT + '/tests/golden/golden_train_step.npz', **g)
+    g['setup'] = np.array([scene_id, weight_seed, torch_seed, loss_seed])
+    np.savez_compressed(ROOT + '/tests/golden/' + out_name, **g)
     print('train step golden: total', total.item(), {k: float(v.mean()) for k, v in terms.items() if k.startswith('loss')})
     print('  params', len(names), 'without grad', len(g['no_grad']), 'hot-path grads stored', sum(k.startswith('grad.') for k in g))
 
@@ -525,7 +527,8 @@ def main():
     if '--post-only' in sys.argv:
         return run_post()
     if '--train-step-only' in sys.argv:
-        return run_train_step(renderer)
+        run_train_step(renderer)
+        return run_train_step(renderer, 3, 11, 77, 9, 'golden_train_step_b.npz')
     if '--losses-only' in sys.argv:
         return run_losses()
     if '--full-only' in sys.argv:
@@ -571,6 +574,7 @@ def main():
     run_losses()
     run_post()
     run_train_step(renderer)
+    run_train_step(renderer, 3, 11, 77, 9, 'golden_train_step_b.npz')
 
 
 if __name__ == '__main__':
