@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', os.environ.get('GNR_LIB', 'libgnr.so'))   # GNR_LIB: A/B builds
 
-GNR_OK = 0
+GNR_OK, GNR_ERR_ARG, GNR_ERR_SHAPE, GNR_ERR_HIP, GNR_ERR_WORKSPACE = 0, -1, -2, -3, -4
 ERRORS = {-1: 'GNR_ERR_ARG', -2: 'GNR_ERR_SHAPE', -3: 'GNR_ERR_HIP', -4: 'GNR_ERR_WORKSPACE'}
 
 c_float_p = C.POINTER(C.c_float)
@@ -173,6 +173,16 @@ def lib():
     L.gnr_timing_end.restype = C.c_int
     L.gnr_chain_timing_end.argtypes = [c_float_p, C.POINTER(C.c_int)]
     L.gnr_chain_timing_end.restype = C.c_int
+    L.gnr_img_last_error.restype = C.c_char_p
+    L.gnr_instnorm_act.argtypes = [C.c_void_p] * 7 + [C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    L.gnr_instnorm_act.restype = C.c_int
+    L.gnr_instnorm_act_bwd.argtypes = [C.c_void_p] * 12 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.gnr_instnorm_act_bwd.restype = C.c_int
+    for fn in (L.gnr_reflect_pad2d, L.gnr_reflect_pad2d_bwd):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        fn.restype = C.c_int
+    L.gnr_upsample2x_bilinear.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+    L.gnr_upsample2x_bilinear.restype = C.c_int
     L.gnr_last_error.restype = C.c_char_p
     L.gnr_dominant_kernel_name.restype = C.c_char_p
     _lib = L
@@ -188,7 +198,8 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
             'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
-            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_composite_bwd', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix']
+            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_composite_bwd', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
+            'gnr_img_last_error', 'gnr_instnorm_act', 'gnr_instnorm_act_bwd', 'gnr_reflect_pad2d', 'gnr_reflect_pad2d_bwd', 'gnr_upsample2x_bilinear']
 
 
 def check(rc, what):

@@ -41,20 +41,143 @@ class _InstanceNormFn(torch.autograd.Function):
         return dx, sxh.sum(0).reshape(c), s1.sum(0).reshape(c), None
 
 
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2          # include/gnr.h GNR_ACT_*
+
+
+def _img_lib():
+    from . import _lib
+    return _lib, _lib.lib()
+
+
+def _img_check(rc, what):
+    if rc:
+        _lib, L = _img_lib()
+        raise _lib.GnrError(f'{what} failed: {_lib.ERRORS.get(rc, rc)} ({L.gnr_img_last_error().decode(errors="replace")})')
+
+
+def _stream(t):
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _InstNormActFn(torch.autograd.Function):
+    """act(InstanceNorm2d(x) + res) in one pass per direction on the device (csrc/gnr_img.hip: the plane stays in registers
+    between the statistics and the apply pass).  The op-by-op statement of the same arithmetic is `_InstanceNormFn` above plus
+    the residual add and F.relu / F.elu; tests/test_backbone_ops.py holds the two against each other."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, act, res):
+        _, L = _img_lib()
+        x = x.contiguous()
+        res = res.contiguous() if res is not None else None
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(n * c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        weight, bias = weight.contiguous(), bias.contiguous()
+        _img_check(L.gnr_instnorm_act(x.data_ptr(), res.data_ptr() if res is not None else None, weight.data_ptr(), bias.data_ptr(),
+                                      y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n * c, c, h * w, eps, act, _stream(x)), 'gnr_instnorm_act')
+        ctx.save_for_backward(x, y, mean, rstd, weight)
+        ctx.act, ctx.has_res = act, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _, L = _img_lib()
+        x, y, mean, rstd, weight = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[5]) else None
+        scratch = torch.empty(2 * n * c + 2 * c, dtype=torch.float32, device=x.device)   # per-plane sums, then d weight, d bias
+        s1, s2, dw, db = scratch[:n * c], scratch[n * c:2 * n * c], scratch[2 * n * c:2 * n * c + c], scratch[2 * n * c + c:]
+        _img_check(L.gnr_instnorm_act_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(),
+                                          dx.data_ptr(), dres.data_ptr() if dres is not None else None, s1.data_ptr(), s2.data_ptr(),
+                                          dw.data_ptr(), db.data_ptr(), n * c, c, h * w, ctx.act, _stream(x)), 'gnr_instnorm_act_bwd')
+        return dx, dw, db, None, None, dres
+
+
+class _ReflectPadFn(torch.autograd.Function):
+    """F.pad(x, (p, p, p, p), mode='reflect'); the backward gathers (<= 9 taps per pixel) instead of scattering atomics."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        _, L = _img_lib()
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        y = torch.empty(n, c, h + 2 * p, w + 2 * p, dtype=torch.float32, device=x.device)
+        _img_check(L.gnr_reflect_pad2d(x.data_ptr(), y.data_ptr(), n * c, h, w, p, _stream(x)), 'gnr_reflect_pad2d')
+        ctx.p, ctx.shape = p, (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _, L = _img_lib()
+        n, c, h, w = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=dy.device)
+        _img_check(L.gnr_reflect_pad2d_bwd(dy.data_ptr(), dx.data_ptr(), n * c, h, w, ctx.p, _stream(dy)), 'gnr_reflect_pad2d_bwd')
+        return dx, None
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True): ATen's forward kernel runs at ~0.15 TB/s on these
+    shapes (1.0 - 2.1 ms per call, 6.3 ms of a training step); its backward is fine and stays."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _, L = _img_lib()
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        y = torch.empty(n, c, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+        _img_check(L.gnr_upsample2x_bilinear(x.data_ptr(), y.data_ptr(), n * c, h, w, _stream(x)), 'gnr_upsample2x_bilinear')
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        return torch.ops.aten.upsample_bilinear2d_backward(dy.contiguous(), [2 * h, 2 * w], [n, c, h, w], True, None, None)
+
+
+HIP_GLUE = {'norm': True, 'pad': True, 'upsample': True}      # switches for A/B runs and tests; all on in the product
+
+
+def _on_device(x, what=None):
+    return x.is_cuda and x.dtype == torch.float32 and (what is None or HIP_GLUE[what])
+
+
+def upsample2x(x):
+    if _on_device(x, 'upsample'):
+        return _Upsample2xFn.apply(x)
+    return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+
+
 class _InstanceNorm(nn.InstanceNorm2d):
-    """nn.InstanceNorm2d(affine=True, track_running_stats=False) with the same parameters/keys.  On ROCm
-    `torch.instance_norm` goes through a batch-norm path that blocks the host for ~0.23 ms per call (62 calls =
-    14 ms of a 34 ms single-scene forward, tools/time_full_forward.py --profile); on the GPU the statistics are
-    computed with plain reductions instead (same formula: biased variance, eps inside the rsqrt)."""
+    """nn.InstanceNorm2d(affine=True, track_running_stats=False) with the same parameters/keys, optionally fused with the
+    residual add and the activation that follow it: forward(x, act, res) = act(norm(x) + res).  On the GPU one HIP kernel per
+    direction (`_InstNormActFn`; `torch.instance_norm` on ROCm goes through a batch-norm path that blocks the host for
+    ~0.23 ms per call, and the op-by-op graph reads the activation 5 times forward and 11 times backward); on the CPU the
+    stock module followed by the stock ops."""
+
+    def forward(self, x, act=ACT_NONE, res=None):
+        if _on_device(x, 'norm'):
+            return _InstNormActFn.apply(x, self.weight, self.bias, self.eps, act, res)
+        y = super().forward(x)
+        if res is not None:
+            y = y + res
+        return F.relu(y) if act == ACT_RELU else (F.elu(y) if act == ACT_ELU else y)
+
+
+class _ReflectConv2d(nn.Conv2d):
+    """nn.Conv2d(padding_mode='reflect') with the padding as one HIP gather in each direction on the GPU (ATen's reflection
+    pad backward scatters atomics: 5.1 ms of a training step) and no padding pass at all for the 1x1 convolutions."""
 
     def forward(self, x):
-        if not x.is_cuda:
-            return super().forward(x)
-        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            return _InstanceNormFn.apply(x, self.weight, self.bias, self.eps)          # training: hand-written backward
-        var, mean = torch.var_mean(x, dim=(2, 3), unbiased=False, keepdim=True)
-        scale = torch.rsqrt(var + self.eps) * self.weight[None, :, None, None]
-        return torch.addcmul(self.bias[None, :, None, None] - mean * scale, x, scale)
+        p = self.padding[0]
+        if _on_device(x, 'pad') and self.padding_mode == 'reflect' and self.padding[1] == p:
+            return F.conv2d(_ReflectPadFn.apply(x, p) if p else x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+        return super().forward(x)
 
 
 def _inorm(ch):
@@ -62,11 +185,11 @@ def _inorm(ch):
 
 
 def _c3(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, 3, stride, 1, bias=False, padding_mode='reflect')
+    return _ReflectConv2d(cin, cout, 3, stride, 1, bias=False, padding_mode='reflect')
 
 
 def _c1(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, 1, stride, bias=False, padding_mode='reflect')
+    return _ReflectConv2d(cin, cout, 1, stride, bias=False, padding_mode='reflect')
 
 
 class BasicBlock(nn.Module):
@@ -81,18 +204,18 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(_c1(cin, cout, stride), _inorm(cout))
 
     def forward(self, x):
-        y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
-        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+        identity = x if self.downsample is None else self.downsample(x)
+        return self.bn2(self.conv2(self.bn1(self.conv1(x), ACT_RELU)), ACT_RELU, identity)
 
 
 class conv(nn.Module):       # lower-case name kept: it is part of the checkpoint key path
     def __init__(self, cin, cout, k, stride):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, padding_mode='reflect')
+        self.conv = _ReflectConv2d(cin, cout, k, stride, (k - 1) // 2, padding_mode='reflect')
         self.bn = _inorm(cout)
 
     def forward(self, x):
-        return F.elu(self.bn(self.conv(x)))
+        return self.bn(self.conv(x), ACT_ELU)
 
 
 class upconv(nn.Module):
@@ -102,6 +225,8 @@ class upconv(nn.Module):
         self.conv = conv(cin, cout, k, 1)
 
     def forward(self, x):
+        if self.scale == 2:
+            return self.conv(upsample2x(x))
         return self.conv(F.interpolate(x, scale_factor=self.scale, mode='bilinear', align_corners=True))
 
 
@@ -111,7 +236,7 @@ class ResUNetLight(nn.Module):
 
     def __init__(self, in_dim=3, layers=(2, 3, 6, 3), out_dim=32, inplanes=32):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_dim, inplanes, 7, 2, 3, bias=False, padding_mode='reflect')
+        self.conv1 = _ReflectConv2d(in_dim, inplanes, 7, 2, 3, bias=False, padding_mode='reflect')
         self.bn1 = _inorm(inplanes)
         chans, c = (32, 64, 128), inplanes
         stages = []
@@ -133,7 +258,7 @@ class ResUNetLight(nn.Module):
         return torch.cat([up, skip], 1)
 
     def forward(self, x):
-        x = F.relu(self.bn1(self.conv1(x)))
+        x = self.bn1(self.conv1(x), ACT_RELU)
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
@@ -151,7 +276,9 @@ class ResidualBlock(nn.Module):
         self.short_cut = nn.Conv2d(cin, cout, 1, 1) if cin != cout else None
 
     def forward(self, x):
-        return self.conv(x) + (x if self.short_cut is None else self.short_cut(x))
+        c = self.conv                                 # Sequential kept for the checkpoint keys (conv.0 / .2 / .3 / .5)
+        y = c[5](c[3](c[2](c[0](x, ACT_RELU)), ACT_RELU))
+        return y + (x if self.short_cut is None else self.short_cut(x))
 
 
 class CostVolumeInitNet(nn.Module):

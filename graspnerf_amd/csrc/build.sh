@@ -4,7 +4,7 @@
 # two scalar ops it replaces when it sits between MFMAs (MI355X_MICROARCH.md); measured -1 % on k_chain, -1.2 % per step.
 set -e
 cd "$(dirname "$0")"
-SRC="gnr_kernels.hip gnr_head.hip gnr_post.hip gnr_pack.cpp gnr_host_rng.cpp"
+SRC="gnr_kernels.hip gnr_head.hip gnr_post.hip gnr_img.hip gnr_pack.cpp gnr_host_rng.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -fno-slp-vectorize"
 # libgnr.so: the product (k_chain multiplies on the f16 matrix cores with fp32 operands as fp16 pairs).
 # libgnr_f32mfma.so: the same sources with the chain on the fp32-input MFMA (-DGNR_SPLIT16=0); measurement companion only:

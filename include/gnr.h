@@ -200,6 +200,34 @@ int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B
 int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int K,
                     int mode, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- image-side streaming ops of the 2D feature extractors (csrc/gnr_img.hip) ----------------------------------
+ * The residual U-Nets in front of the hot path (src/nr/network/ops.py:96-230, init_net.py:8-35, vis_encoder.py:6-22) are
+ * convolutions (left to MIOpen) glued by instance norms, activations, reflect paddings and two bilinear upsamplings; these
+ * entry points run the glue as single passes over the activation.  Layout: contiguous planes [planes = N*C][H][W] fp32.
+ *
+ * gnr_instnorm_act: y = act(InstanceNorm2d(x; weight, bias, eps) + res)   (ops.py:135-138: ELU; :101-121,215: ReLU, the
+ *   block's identity as `res`; biased variance, eps inside the square root).  res may be NULL.  mean / rstd [planes] are
+ *   written for the backward.  act: GNR_ACT_NONE / GNR_ACT_RELU / GNR_ACT_ELU (alpha = 1).
+ * gnr_instnorm_act_bwd: with g = dy * act'(out):  dx = weight * rstd * (g - mean_hw(g) - xhat * mean_hw(g * xhat)),
+ *   dres = g (NULL: not wanted), dbias[c] = sum_n sum_hw g, dweight[c] = sum_n sum_hw g * xhat (summed in a fixed order, no
+ *   atomics; s1 / s2 [planes]: scratch for the per-plane sums).  `out` = the forward's y (may be NULL for GNR_ACT_NONE).
+ * gnr_reflect_pad2d: F.pad(x, (pad,)*4, mode='reflect') as nn.Conv2d(padding_mode='reflect') applies it (ops.py:8,134,163):
+ *   y [planes][H+2 pad][W+2 pad];  pad < min(H, W).  _bwd: dx[h][w] = sum of dy over the padded positions reading x[h][w].
+ * gnr_upsample2x_bilinear: F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True) (ops.py:147): y [planes][2H][2W].
+ * All return GNR_OK / GNR_ERR_ARG (null pointer) / GNR_ERR_SHAPE / GNR_ERR_HIP; text in gnr_img_last_error(). */
+#define GNR_ACT_NONE 0
+#define GNR_ACT_RELU 1
+#define GNR_ACT_ELU 2
+const char* gnr_img_last_error(void);
+int gnr_instnorm_act(const float* x, const float* res, const float* weight, const float* bias, float* y, float* mean, float* rstd,
+                     long long planes, int C, int HW, float eps, int act, void* stream);
+int gnr_instnorm_act_bwd(const float* dy, const float* out, const float* x, const float* mean, const float* rstd, const float* weight,
+                         float* dx, float* dres, float* s1, float* s2, float* dweight, float* dbias, long long planes, int C, int HW, int act,
+                         void* stream);
+int gnr_reflect_pad2d(const float* x, float* y, long long planes, int H, int W, int pad, void* stream);
+int gnr_reflect_pad2d_bwd(const float* dy, float* dx, long long planes, int H, int W, int pad, void* stream);
+int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, int W, void* stream);
+
 /* ---- backward twins ------------------------------------------------------------------------
  * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
  * consumed by DepthLoss, loss.py:87-144).  sample_volume and the per-view chain of the render passes follow below;

@@ -51,7 +51,7 @@ def bucket(fileno, line):
     return fnname or '?'
 
 
-m = re.search(r'\n(_ZN3gnr7(%s)\w*):.*?\n\.Lfunc_end\d+:' % a.kern, txt, re.S)
+m = re.search(r'\n(_ZN3gnr\d+(%s)\w*):.*?\n\.Lfunc_end\d+:' % a.kern, txt, re.S)
 body = m.group(0).split('\n')
 V = int(re.search(r'ILi(\d+)E', m.group(1)).group(1))
 labels, loops = {}, []

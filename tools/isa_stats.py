@@ -51,7 +51,7 @@ def show(c):
     return {k: v for k, v in c.items() if not k.startswith('v:')}
 
 
-for m in re.finditer(r'\n(_ZN3gnr7(%s)\w*):.*?\n\.Lfunc_end\d+:' % a.kern, txt, re.S):
+for m in re.finditer(r'\n(_ZN3gnr\d+(%s)\w*):.*?\n\.Lfunc_end\d+:' % a.kern, txt, re.S):
     name = m.group(1)
     body = m.group(0).split('\n')
     V = int(re.search(r'ILi(\d+)E', name).group(1)) if re.search(r'ILi(\d+)E', name) else 1
