@@ -5,7 +5,8 @@
 //   k_view_setup     per view: H = K[R|t], camera centre, inverse-depth range
 //   k_points_volume  per voxel centre descriptor, column order, top->down  (renderer.py:167-170)
 //   k_coarse_depth / k_points_rays   ray samples (render_ops.py:4-52,146-170)
-//   k_chain<V,RENDER> THE hot kernel: per-(point,view) projection + gather + mixture decoder +
+//   k_chain<V,RENDER,SAVE,USEVIS,SP> THE hot kernel (SAVE: training forward keeping the per-view states; USEVIS: 4th decoder
+//                    branch; SP: fp16-pair operands, false = the fp32-MFMA twin): per-(point,view) projection + gather + mixture decoder +
 //                    prob-embed + IBRNet aggregation + geometry MLP, all layers as chained MFMAs with
 //                    activations resident in registers: fp32 values, multiplied on the f16 matrix cores
 //                    as fp16 pairs (v_mfma_f32_16x16x32_f16; short remainders on v_mfma_f32_16x16x4_f32)
@@ -867,14 +868,17 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             }
             float hit, vis;
             {
-                const float mean0 = softplus1(o5[0]), mean1 = softplus1(o5[1]);
-                const float var0 = softplus1(o5[2]) + 0.05f, var1 = softplus1(o5[3]) + 0.05f;
-                const float aw = sigmoid1(o5[4]);
+                // The four lane groups of a point hold the same o5: each evaluates ONE of the four logistic CDFs (mixture
+                // component g & 1 at the near (g < 2) or far edge) -- 2 softplus + 1 tanh per lane instead of 4 + 4 -- and the
+                // mixture sums over components / edges are the cross-group sums the dot products use anyway.
+                const bool m1 = (g & 1) != 0, far_edge = g >= 2;
+                const float meang = softplus1(m1 ? o5[1] : o5[0]);
+                const float varg = softplus1(m1 ? o5[3] : o5[2]) + 0.05f;
+                const float mix = sigmoid1(m1 ? -o5[4] : o5[4]);             // aw or 1 - aw = sigmoid(-logit)   (:128)
                 const float dinv = -rcp1(fmaxf(vg.z, 1e-5f));                 // dist_decoder.py:21-23
                 const float dhat = (dinv - vp[15]) * vp[17];
-                const float nearv = dhat - lo, farv = dhat + hi;
-                float c00 = 0.5f + 0.5f * tanh1((nearv - mean0) * var0), c01 = 0.5f + 0.5f * tanh1((nearv - mean1) * var1);
-                float c10 = 0.5f + 0.5f * tanh1((farv - mean0) * var0), c11 = 0.5f + 0.5f * tanh1((farv - mean1) * var1);
+                const float edge = far_edge ? dhat + hi : dhat - lo;
+                float cg = 0.5f + 0.5f * tanh1((edge - meang) * varg);
                 if constexpr (USEVIS) {   // dist_decoder_cfg.use_vis (dist_decoder.py:89-97,103-104,133-134); off in nrvgn_sdf.yaml
                     f4 acc[2];
                     float h1[8], h2[8];
@@ -890,10 +894,12 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                     else mm<8, 2, 0, LF>(lds + LO(pk::DECV2), lane, h1, acc);
                     elu_to<2, !SP || UA>(acc, h2);
                     const float pv = sigmoid1(gsum(dot8(lds + LO(pk::T_DECV3), g, h2)) + lds[LO(pk::T_VIS)]);
-                    c00 *= pv; c01 *= pv; c10 *= pv; c11 *= pv;
+                    cg *= pv;
                 }
-                vis = ((1.f - c00) * aw + (1.f - c01) * (1.f - aw)) * m;
-                hit = ((c10 - c00) * aw + (c11 - c01) * (1.f - aw)) * m;
+                // visibility = sum_mix (1 - cdf0) mix,  hit_prob = sum_mix (cdf1 - cdf0) mix     (dist_decoder.py:135-138)
+                const float mc = mix * cg;
+                vis = gsum(far_edge ? 0.f : mix - mc) * m;
+                hit = gsum(far_edge ? mc : -mc) * m;
             }
             // ---- prob embedding 34 -> 32 -> 32 (aggregate_net.py:46-54)
             {
