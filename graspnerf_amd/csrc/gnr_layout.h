@@ -51,6 +51,12 @@ constexpr int NR0_W = RGB4_B + 1, NR0_B = NR0_W + 256, NR2_W = NR0_B + 8, NR2_B 
 constexpr int VARIANCE = NR2_B + 1;
 constexpr int TOTAL = VARIANCE + 1;
 static_assert(TOTAL == 36958, "canonical size must equal the reference parameter count");
+// optional fourth decoder branch (dist_decoder_cfg.use_vis, dist_decoder.py:89-97), BEHIND the level's blob: a gradient blob of a
+// use_vis level has TOTAL_VIS floats (gnr_canonical_vis_floats() more), its weights travel separately (gnr_pack_vis_decoder*)
+constexpr int VISD0_W = TOTAL, VISD0_B = VISD0_W + 1024, VISD2_W = VISD0_B + 32, VISD2_B = VISD2_W + 1024;
+constexpr int VISD4_W = VISD2_B + 32, VISD4_B = VISD4_W + 32;
+constexpr int TOTAL_VIS = VISD4_B + 1;
+static_assert(TOTAL_VIS - TOTAL == 2145, "vis_decoder: 32x32 + 32 + 32x32 + 32 + 32 + 1");
 }  // namespace can
 
 // ---- packed blob of one level ------------------------------------------------------------
@@ -203,7 +209,10 @@ constexpr int V1_END = RDF2T + frag_floats(9, 1);
 constexpr int RGB2T = V1_END;                                // rgb_fc.2^T : 8 (padded to 16) -> 16                      4 x 1
 constexpr int RGB0HT = RGB2T + frag_floats(4, 1);            // rgb_fc.0[:, :32]^T : 16 -> 32                            4 x 2
 constexpr int T_RGB0V = RGB0HT + frag_floats(4, 2);          // rgb_fc.0[:, 32] as a [4][4] row table
-constexpr int TOTAL = T_RGB0V + 16;
+// fourth decoder branch (use_vis), zero unless gnr_pack_vis_decoder_bwd filled it; k_view1_bwd<true> copies it behind its image
+constexpr int DECV2T = T_RGB0V + 16;                         // vis_decoder.2^T                                          8 x 2
+constexpr int DECV1T = DECV2T + 1024;                        // vis_decoder.0^T, rows in the gather layout               8 x 2
+constexpr int TOTAL = DECV1T + 1024;
 }  // namespace pkb
 
 }  // namespace gnr

@@ -312,6 +312,22 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
     return GNR_OK;
 }
 
+// The fourth decoder branch's transposed fragments (use_vis training) into a blob of gnr_pack_weights_bwd.  v as in
+// gnr_pack_vis_decoder (state-dict order, 2 145 floats); output rows of vis_decoder.0^T land in the gather layout like DEC1T.
+extern "C" int gnr_pack_vis_decoder_bwd(const float* v, float* p) {
+    if (!v || !p) return GNR_ERR_ARG;
+    using namespace gnr;
+    const IdxFn natI = nat_in, natO = nat_out;
+    const IdxFn gatherO = [](int nb, int i) { return 8 * (i / 4) + 4 * nb + (i % 4); };
+    std::vector<float> t(1024);
+    for (int o = 0; o < 32; ++o) for (int i = 0; i < 32; ++i) t[i * 32 + o] = v[1056 + o * 32 + i];
+    pack_frag(p + pkb::DECV2T, t.data(), 32, 8, 2, natI, natO);
+    for (int o = 0; o < 32; ++o) for (int i = 0; i < 32; ++i) t[i * 32 + o] = v[o * 32 + i];
+    pack_frag(p + pkb::DECV1T, t.data(), 32, 8, 2, natI, gatherO);
+    return GNR_OK;
+}
+
+extern "C" int gnr_canonical_vis_floats(void) { return gnr::can::TOTAL_VIS - gnr::can::TOTAL; }
 extern "C" int gnr_canonical_weights_floats(void) { return gnr::can::TOTAL; }
 extern "C" int gnr_packed_weights_floats(void) { return gnr::pk::TOTAL; }
 

@@ -251,7 +251,7 @@ class HotPath:
         """Backward of the last sample_volume_train: dvol [B,1,R,R,R] -> (d_canonical [36958], d_ray_feats, d_img_feats)."""
         scene, keep, ws, res = self._train_ctx
         dvol = _f32(dvol, self.device)
-        dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
+        dcan = torch.zeros(self.L.gnr_canonical_weights_floats() + (self.L.gnr_canonical_vis_floats() if self.use_vis else 0), dtype=torch.float32, device=self.device)
         shp = (scene.B, scene.V, 32, scene.fh, scene.fw)
         dray = torch.zeros(shp, dtype=torch.float32, device=self.device) if want_feat_grads else None
         dimg = torch.zeros(shp, dtype=torch.float32, device=self.device) if want_feat_grads else None
@@ -300,7 +300,7 @@ class HotPath:
         dstats = _f32(dstats, self.device)
         dcolors = _f32(dcolors, self.device)
         assert dstats.shape[-1] == 65 and dcolors.shape[-1] == 3
-        dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
+        dcan = torch.zeros(self.L.gnr_canonical_weights_floats() + (self.L.gnr_canonical_vis_floats() if self.use_vis else 0), dtype=torch.float32, device=self.device)
         shp = (scene.B, scene.V, 32, scene.fh, scene.fw)
         dray = torch.empty(shp, dtype=torch.float32, device=self.device)
         dimg = torch.empty(shp, dtype=torch.float32, device=self.device)

@@ -138,8 +138,8 @@ class _SampleVolumeFn(torch.autograd.Function):
         hot = ctx.hot
         hot.check_generation(ctx.gen)
         dcan, dray, dimg = hot.sample_volume_bwd(dvol.contiguous(), hot.can_dev['coarse'])
-        g = _w.split_canonical(dcan, 'coarse')
-        return (None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys('coarse'))
+        g = _w.split_canonical(dcan, 'coarse', use_vis=hot.use_vis)
+        return (None, None, None, None, dray, dimg) + tuple(g[k] for k, _ in _w.level_keys('coarse', use_vis=hot.use_vis))
 
 
 _FW_KEYS = ('sdf_values', 'sdf_gradient', 'alpha_values', 'hit_prob_nr', 'pixel_colors_nr', 'render_depth', 'ray_mask',
@@ -176,8 +176,8 @@ class _RenderChainFn(torch.autograd.Function):
     def backward(ctx, dstats, dcolors, *_):
         ctx.hot.check_generation(ctx.gen)
         dcan, dray, dimg = ctx.hot.render_chain_bwd(ctx.hctx, dstats[..., :65].contiguous(), dcolors.contiguous())
-        g = _w.split_canonical(dcan, ctx.level)
-        return (None,) * 7 + (dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level))
+        g = _w.split_canonical(dcan, ctx.level, use_vis=ctx.hot.use_vis)
+        return (None,) * 7 + (dray, dimg) + tuple(g[k] for k, _ in _w.level_keys(ctx.level, use_vis=ctx.hot.use_vis))
 
 
 def randperm_prefix(n, k):
@@ -401,17 +401,27 @@ class NeuralRayRenderer(nn.Module):
             buf = self._pinned(name, a.size)
             buf.numpy()[:] = a
             return buf
+        vis = {'coarse': None, 'fine': None}
+        if self.use_vis:                                                    # non-default branch: its six tensors per level by per-key copies
+            sd = self._params()
+            vis = {lvl: _w.vis_blob(sd, lvl) for lvl in vis}
+
+        def fwd_pack(lvl):
+            out = _w.pack(can[lvl])
+            if vis[lvl] is not None:
+                _lib.check(_lib.lib().gnr_pack_vis_decoder(vis[lvl].ctypes.data_as(_lib.c_float_p), out.ctypes.data_as(_lib.c_float_p)), 'gnr_pack_vis_decoder')
+            return out
         if self._hot is None:
-            self._hot = HotPath(_w.pack(can['coarse']), _w.pack(can['fine']), device=dev)
+            self._hot = HotPath(fwd_pack('coarse'), fwd_pack('fine'), device=dev)
         else:
-            self._hot.wc.copy_(up('wc', _w.pack(can['coarse'])), non_blocking=True)
-            self._hot.wf.copy_(up('wf', _w.pack(can['fine'])), non_blocking=True)
+            self._hot.wc.copy_(up('wc', fwd_pack('coarse')), non_blocking=True)
+            self._hot.wf.copy_(up('wf', fwd_pack('fine')), non_blocking=True)
         wb = getattr(self._hot, 'wb', None)
         if wb is None or wb.get('fine') is None:
-            self._hot.set_bwd_weights(_w.pack_bwd(can['coarse']), _w.pack_bwd(can['fine']))
+            self._hot.set_bwd_weights(_w.pack_bwd(can['coarse'], vis['coarse']), _w.pack_bwd(can['fine'], vis['fine']))
         else:
-            wb['coarse'].copy_(up('wbc', _w.pack_bwd(can['coarse'])), non_blocking=True)
-            wb['fine'].copy_(up('wbf', _w.pack_bwd(can['fine'])), non_blocking=True)
+            wb['coarse'].copy_(up('wbc', _w.pack_bwd(can['coarse'], vis['coarse'])), non_blocking=True)
+            wb['fine'].copy_(up('wbf', _w.pack_bwd(can['fine'], vis['fine'])), non_blocking=True)
         self._repack_uploaded = torch.cuda.Event()
         self._repack_uploaded.record()
         self._hot.can_dev = can_dev
@@ -465,8 +475,6 @@ class NeuralRayRenderer(nn.Module):
         on = bool(is_train) and torch.is_grad_enabled()
         if on and self.cfg['fine_depth_use_all']:
             raise NotImplementedError('fine_depth_use_all is built for inference only (the backward twins hold <= 64 samples per ray)')
-        if on and self.use_vis:
-            raise NotImplementedError('use_vis is built for inference only (the backward twins do not differentiate the vis_decoder branch)')
         return on
 
     @staticmethod
@@ -484,7 +492,7 @@ class NeuralRayRenderer(nn.Module):
         -> (dict of [B*rn, ...] results of the pass, dict of its non-differentiable values incl. geometry / fine depths)."""
         agg = _w.LEVELS[level][1]
         st, co, *extra = _RenderChainFn.apply(hot, prep, que_b, depth, level, self._render_cfg(), want_fine_depth, ray_feats, img_feats,
-                                              *[P[k] for k, _ in _w.level_keys(level)])
+                                              *[P[k] for k, _ in _w.level_keys(level, use_vis=self.use_vis)])
         ex = dict(zip(_pass_value_names('imgs' in que_b, want_fine_depth), extra))
         B, rn, dn = ex['depth'].shape
         R = B * rn
@@ -573,7 +581,7 @@ class NeuralRayRenderer(nn.Module):
             hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
             P = self._params()
             return _SampleVolumeFn.apply(hot, bref, prep, self.cfg['volume_resolution'], ref_imgs_info['ray_feats'][None],
-                                         ref_imgs_info['img_feats'][None], *[P[k] for k, _ in _w.level_keys('coarse')])
+                                         ref_imgs_info['img_feats'][None], *[P[k] for k, _ in _w.level_keys('coarse', use_vis=self.use_vis)])
         bref, prep = _prep or self._prepare(ref_imgs_info)
         if not self.cfg.get('warn_low_valid_ratio', False):
             return self.hot().sample_volume(bref, self.cfg['volume_resolution'], prepared=prep)
@@ -740,7 +748,7 @@ class NeuralRayRenderer(nn.Module):
         if 'imgs' in ques[0]:
             que_b['imgs'] = torch.cat([q['imgs'] for q in ques])
         st = self._render_train(hot, prep, que_b, fine_u, ray_feats, img_feats)
-        st['volume'] = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse')])
+        st['volume'] = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse', use_vis=self.use_vis)])
         if want_depth:
             xy = coords.to(torch.float32)
             mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])

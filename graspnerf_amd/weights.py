@@ -42,12 +42,17 @@ AGG_KEYS = [
     ('agg_impl.neuray_fc.2.weight', (1, 8)), ('agg_impl.neuray_fc.2.bias', (1,)),
     ('deviation_network.variance', ()),
 ]
+VIS_KEYS = [('vis_decoder.0.weight', (32, 32)), ('vis_decoder.0.bias', (32,)), ('vis_decoder.2.weight', (32, 32)),
+            ('vis_decoder.2.bias', (32,)), ('vis_decoder.4.weight', (1, 32)), ('vis_decoder.4.bias', (1,))]
 LEVELS = {'coarse': ('dist_decoder.', 'agg_net.'), 'fine': ('fine_dist_decoder.', 'fine_agg_net.')}
 
 
-def level_keys(level, prefix=''):
+def level_keys(level, prefix='', use_vis=False):
+    """State-dict keys of a level in canonical order; use_vis: the vis_decoder's six tensors BEHIND them (the order of the
+    gradient blobs of a use_vis level, include/gnr.h)."""
     dec, agg = LEVELS[level]
-    return [(prefix + dec + k, s) for k, s in DEC_KEYS] + [(prefix + agg + k, s) for k, s in AGG_KEYS]
+    keys = [(prefix + dec + k, s) for k, s in DEC_KEYS] + [(prefix + agg + k, s) for k, s in AGG_KEYS]
+    return keys + ([(prefix + dec + k, s) for k, s in VIS_KEYS] if use_vis else [])
 
 
 def canonical_blob(state_dict, level, prefix=''):
@@ -78,46 +83,50 @@ def pack(canonical):
     return out
 
 
-VIS_KEYS = [('vis_decoder.0.weight', (32, 32)), ('vis_decoder.0.bias', (32,)), ('vis_decoder.2.weight', (32, 32)),
-            ('vis_decoder.2.bias', (32,)), ('vis_decoder.4.weight', (1, 32)), ('vis_decoder.4.bias', (1,))]
-
-
 def has_vis_decoder(state_dict, level, prefix=''):
     """cfg `use_vis: true` (dist_decoder.py:89-97): the level's decoder carries a fourth branch."""
     return prefix + LEVELS[level][0] + VIS_KEYS[0][0] in state_dict
+
+
+def vis_blob(state_dict, level, prefix=''):
+    """The vis_decoder's six tensors of a level in state-dict order -> float32 numpy [2145]."""
+    parts = []
+    for k, shape in VIS_KEYS:
+        v = state_dict[prefix + LEVELS[level][0] + k]
+        v = v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError(f'{k}: expected shape {shape}, got {tuple(v.shape)}')
+        parts.append(np.asarray(v, np.float32).reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts))
 
 
 def pack_state_dict(state_dict, level, prefix=''):
     """One level's packed blob from a state dict; a `vis_decoder` (use_vis) is packed behind it when the state dict has one."""
     out = pack(canonical_blob(state_dict, level, prefix))
     if has_vis_decoder(state_dict, level, prefix):
-        parts = []
-        for k, shape in VIS_KEYS:
-            v = state_dict[prefix + LEVELS[level][0] + k]
-            v = v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)
-            if tuple(v.shape) != tuple(shape):
-                raise ValueError(f'{k}: expected shape {shape}, got {tuple(v.shape)}')
-            parts.append(np.asarray(v, np.float32).reshape(-1))
-        vis = np.ascontiguousarray(np.concatenate(parts))
+        vis = vis_blob(state_dict, level, prefix)
         L = _lib.lib()
         _lib.check(L.gnr_pack_vis_decoder(vis.ctypes.data_as(_lib.c_float_p), out.ctypes.data_as(_lib.c_float_p)), 'gnr_pack_vis_decoder')
     return out
 
 
-def pack_bwd(canonical):
-    """canonical float32 [36958] -> transposed-fragment blob for the backward twins (host numpy)."""
+def pack_bwd(canonical, vis=None):
+    """canonical float32 [36958] (+ the level's vis_blob when use_vis) -> transposed-fragment blob for the backward twins (host numpy)."""
     L = _lib.lib()
     canonical = np.ascontiguousarray(canonical, np.float32)
     out = np.zeros(L.gnr_packed_bwd_floats(), np.float32)
     _lib.check(L.gnr_pack_weights_bwd(canonical.ctypes.data_as(_lib.c_float_p), out.ctypes.data_as(_lib.c_float_p)),
                'gnr_pack_weights_bwd')
+    if vis is not None:
+        vis = np.ascontiguousarray(vis, np.float32)
+        _lib.check(L.gnr_pack_vis_decoder_bwd(vis.ctypes.data_as(_lib.c_float_p), out.ctypes.data_as(_lib.c_float_p)), 'gnr_pack_vis_decoder_bwd')
     return out
 
 
-def split_canonical(flat, level, prefix=''):
+def split_canonical(flat, level, prefix='', use_vis=False):
     """A canonical-layout array (e.g. a gradient blob from a *_bwd entry point) -> {state-dict key: view}."""
     out, off = {}, 0
-    for k, shape in level_keys(level, prefix):
+    for k, shape in level_keys(level, prefix, use_vis):
         n = int(np.prod(shape)) if len(shape) else 1
         out[k] = flat[off:off + n].reshape(shape)
         off += n

@@ -41,8 +41,10 @@ typedef struct GnrScene {
     const float* Ks;          /* [B,V,3,3]                                                  */
     const float* depth_range; /* [B,V,2] near, far                                          */
     int use_vis;              /* cfg dist_decoder_cfg.use_vis (both levels, dist_decoder.py:89-97): 1 -> the packed level
-                                 blobs were completed with gnr_pack_vis_decoder and the chain runs the fourth decoder
-                                 branch (forward entry points only); 0 -> configs/nrvgn_sdf.yaml                       */
+                                 blobs were completed with gnr_pack_vis_decoder (training: the backward blobs with
+                                 gnr_pack_vis_decoder_bwd) and the chain runs the fourth decoder branch; the gradient
+                                 blobs of the *_bwd entry points then have gnr_canonical_weights_floats() +
+                                 gnr_canonical_vis_floats() floats; 0 -> configs/nrvgn_sdf.yaml                          */
 } GnrScene;
 
 /* Query rays of B scenes.  Replaces the `que_imgs_info` dict (imgs_info.py:126-135). */
@@ -108,8 +110,13 @@ int gnr_pack_weights(const float* canonical_host, float* packed_host);
 /* Optional: the fourth decoder branch of a level (cfg dist_decoder_cfg.use_vis: true; dist_decoder.py:89-97,103-104,133-134:
  * its sigmoid output multiplies both cdfs) into a blob gnr_pack_weights has filled.  vis_decoder_host = vis_decoder.{0.weight
  * [32][32], 0.bias [32], 2.weight [32][32], 2.bias [32], 4.weight [1][32], 4.bias [1]} in state-dict order (2145 floats).
- * Forward entry points only: the backward twins do not differentiate this branch. */
+ * Training (GnrScene.use_vis = 1 in gnr_sample_volume_fwd_train / _bwd, gnr_render_chain_fwd_train / _bwd): the same six tensors
+ * go into the backward blob with gnr_pack_vis_decoder_bwd (after gnr_pack_weights_bwd), and the gradient blob `d_canonical`
+ * carries their gradients BEHIND the level's 36958 floats, in the same state-dict order: gnr_canonical_vis_floats() = 2145
+ * more.  (gnr_depth_mean_* reads mean_decoder only and takes no notice.) */
 int gnr_pack_vis_decoder(const float* vis_decoder_host, float* packed_host);
+int gnr_pack_vis_decoder_bwd(const float* vis_decoder_host, float* packed_bwd_host);
+int gnr_canonical_vis_floats(void);       /* 2145 */
 /* float offset of a named section of the packed blob (see csrc/gnr_layout.h), -1 if unknown */
 int gnr_layout_offset(const char* name);
 

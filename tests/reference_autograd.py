@@ -87,6 +87,9 @@ def decode_hit_vis(P, dec, f_ray, z, mask, depth_range, lo, hi):
     mix = torch.cat([aw, 1 - aw], -1)
     cdf0 = 0.5 + 0.5 * torch.tanh((near - mean) * var)
     cdf1 = 0.5 + 0.5 * torch.tanh((far - mean) * var)
+    if dec + 'vis_decoder.0.weight' in P:            # dist_decoder_cfg.use_vis (dist_decoder.py:89-97,103-104,133-134)
+        pv = _mlp3(f_ray, P, dec + 'vis_decoder', torch.sigmoid)
+        cdf0, cdf1 = cdf0 * pv, cdf1 * pv
     m = mask.to(f_ray.dtype)
     return torch.sum((cdf1 - cdf0) * mix, -1) * m, torch.sum((1 - cdf0) * mix, -1) * m
 

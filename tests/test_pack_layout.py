@@ -255,7 +255,7 @@ def _bwd_offsets():
                    ('BASE1XT', ff(16, 3)), ('BASE1ET', ff(16, 2)), ('HOISTT_A', ff(16, 4)), ('HOISTT_B', ff(16, 4)),
                    ('HOISTT_C', ff(16, 1)), ('DEC2T', 3072), ('DEC1T', 3072), ('V1_PE2F', 1024), ('V1_B_PE2', 32), ('PE2T', 1024),
                    ('PE0T', 1024), ('T_PE0HV', 64), ('NR0T', ff(4, 2)), ('RDF2T', ff(9, 1)), ('RGB2T', ff(4, 1)),
-                   ('RGB0HT', ff(4, 2)), ('T_RGB0V', 16)]
+                   ('RGB0HT', ff(4, 2)), ('T_RGB0V', 16), ('DECV2T', 1024), ('DECV1T', 1024)]
     for name, n in order:
         BWD_OFF[name] = o
         o += n
@@ -266,9 +266,13 @@ def _bwd_offsets():
 def test_bwd_fragments_compute_transposed_products(weights_np):
     """dX = W^T dY through every transposed fragment, on one random 16-point tile, against numpy."""
     can = weights.canonical_blob(weights_np, 'coarse')
-    pb = weights.pack_bwd(can)
-    O = _bwd_offsets()
     rng = np.random.default_rng(0)
+    vis = rng.standard_normal(_lib.lib().gnr_canonical_vis_floats()).astype(np.float32)       # use_vis: the fourth decoder branch
+    assert vis.size == 2145
+    assert np.array_equal(weights.pack_bwd(can)[-2048:], np.zeros(2048, np.float32))          # absent: its sections stay zero
+    pb = weights.pack_bwd(can, vis)
+    assert np.array_equal(pb[:-2048], weights.pack_bwd(can)[:-2048])
+    O = _bwd_offsets()
     W = lambda k: weights_np['agg_net.agg_impl.' + k]
     gather = lambda nb, i: 8 * (i // 4) + 4 * nb + (i % 4)
     natO = lambda nb, i: 16 * nb + i
@@ -298,6 +302,8 @@ def test_bwd_fragments_compute_transposed_products(weights_np):
         ('RDF2T', W('ray_dir_fc.2.weight').T, 9, 1, xfeat, natO, 16),
         ('RGB2T', W('rgb_fc.2.weight').T, 4, 1, first8, natO, 16),
         ('RGB0HT', W('rgb_fc.0.weight')[:, :32].T, 4, 2, nat, natO, 32),
+        ('DECV2T', vis[1056:2080].reshape(32, 32).T, 8, 2, nat, natO, 32),
+        ('DECV1T', vis[:1024].reshape(32, 32).T, 8, 2, nat, gather, 32),
         ('GEO1T_A', W('geometry_fc.0.weight').T, 16, 4, nat, lambda nb, i: zslot(4 * nb + (i & 3), i >> 2), 86),
         ('HOISTT_A', W('base_fc.0.weight')[:, :140].T, 16, 4, nat, lambda nb, i: sslot(4 * nb + (i & 3), i >> 2), 140),
         ('HOISTT_C', W('base_fc.0.weight')[:, :140].T, 16, 1, nat, lambda nb, i: sslot(32 + (i & 3), i >> 2), 140),

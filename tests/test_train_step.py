@@ -33,16 +33,19 @@ render_depth: true
 
 
 FIXTURES = {'a': ('golden_train_step.npz', dict(scene_id=0, weight_seed=7, torch_seed=321, loss_seed=5)),
-            'b': ('golden_train_step_b.npz', dict(scene_id=3, weight_seed=11, torch_seed=77, loss_seed=9))}   # tools/make_goldens.py run_train_step
+            'b': ('golden_train_step_b.npz', dict(scene_id=3, weight_seed=11, torch_seed=77, loss_seed=9)),
+            # dist_decoder_cfg.use_vis: true on both levels (the fourth decoder branch, dist_decoder.py:89-97,103-104,133-134, under training)
+            'vis': ('golden_train_step_vis.npz', dict(scene_id=1, weight_seed=13, torch_seed=99, loss_seed=7, use_vis=True))}   # tools/make_goldens.py run_train_step
 
 
-def build(device='cpu', reference_statement=None, weight_seed=7):
+def build(device='cpu', reference_statement=None, weight_seed=7, use_vis=False):
     """The model mirror with synthetic parameters.  On the CPU (or with reference_statement=True) its training forward
     runs the differentiable PyTorch statement of the path (tests/reference_autograd.py: test infrastructure -- the product
     trains through its HIP twin pairs only and raises without a GPU)."""
     from graspnerf_amd.renderer import GraspNeRF
     from reference_autograd import use_reference_statement
-    net = GraspNeRF(CFG)
+    cfg = dict(CFG, dist_decoder_cfg={'use_vis': bool(use_vis)}, fine_dist_decoder_cfg={'use_vis': bool(use_vis)})
+    net = GraspNeRF(cfg)
     syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=weight_seed)
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()}, strict=True)
     if reference_statement if reference_statement is not None else (str(device) == 'cpu'):
@@ -85,15 +88,15 @@ def check_against_golden(net, terms, G, rtol_loss, rtol_grad, rtol_backbone=None
     assert worst[0] < (rtol_backbone or rtol_grad), f'gradient-norm mismatch {worst}'
 
 
-@pytest.mark.parametrize('fx', ['a', 'b'])
+@pytest.mark.parametrize('fx', ['a', 'b', 'vis'])
 def test_train_step_gradients_match_reference(fx):
-    """CPU, bitwise-same RNG draws as the reference: random fine samples, depth-loss pixels.  Two fixtures made by the imported
-    reference: two scenes, two parameter draws, two RNG streams."""
+    """CPU, bitwise-same RNG draws as the reference: random fine samples, depth-loss pixels.  Three fixtures made by the imported
+    reference: three scenes, parameter draws and RNG streams, the third with `use_vis: true`."""
     from graspnerf_amd.trainer import train_losses
     from graspnerf_amd import losses
     name, su = FIXTURES[fx]
     G = dict(np.load(os.path.join(ROOT, 'tests', 'golden', name)))
-    net = build(weight_seed=su['weight_seed']).train()
+    net = build(weight_seed=su['weight_seed'], use_vis=su.get('use_vis', False)).train()
     data = scene_data(scene_id=su['scene_id'], loss_seed=su['loss_seed'])
     torch.manual_seed(su['torch_seed'])
     out = net(data)
@@ -243,7 +246,7 @@ def test_product_refuses_to_train_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('fx', ['a', 'b'])
+@pytest.mark.parametrize('fx', ['a', 'b', 'vis'])
 def test_train_step_on_gpu_matches_reference_gradients(fx):
     """Same check with the model on the MI355X: the volumetric path in HIP in both directions (renderer.py autograd.Functions over
     csrc/gnr_bwd.inc), backbones / grasp head / losses under PyTorch autograd."""
@@ -251,7 +254,7 @@ def test_train_step_on_gpu_matches_reference_gradients(fx):
     from graspnerf_amd import losses
     name, su = FIXTURES[fx]
     G = dict(np.load(os.path.join(ROOT, 'tests', 'golden', name)))
-    net = build('cuda', weight_seed=su['weight_seed']).train()
+    net = build('cuda', weight_seed=su['weight_seed'], use_vis=su.get('use_vis', False)).train()
     data = scene_data('cuda', scene_id=su['scene_id'], loss_seed=su['loss_seed'])
     torch.manual_seed(su['torch_seed'])
     terms = train_losses(net(data), data)
