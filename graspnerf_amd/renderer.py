@@ -434,8 +434,7 @@ class NeuralRayRenderer(nn.Module):
         hot = self.hot_for_training()
         bref = self._batched_ref({**ref_imgs_info, 'ray_feats': ref_imgs_info['ray_feats'].detach(),
                                   'img_feats': ref_imgs_info['img_feats'].detach()})
-        prep = hot.prepare(bref, self.cfg.get('volume_resolution', 40), min(rn, self.cfg['ray_batch_num']),
-                           max(self.cfg['depth_sample_num'], self.cfg['fine_depth_sample_num']))
+        prep = hot.prepare(bref, self.cfg.get('volume_resolution', 40), min(rn, self.cfg['ray_batch_num']), self._dn_max())
         return hot, bref, prep
 
     @staticmethod
@@ -473,8 +472,6 @@ class NeuralRayRenderer(nn.Module):
     def _use_autograd(self, is_train):
         """Training (autograd on, parameters trainable): the HIP twin pairs behind autograd.Functions."""
         on = bool(is_train) and torch.is_grad_enabled()
-        if on and self.cfg['fine_depth_use_all']:
-            raise NotImplementedError('fine_depth_use_all is built for inference only (the backward twins hold <= 64 samples per ray)')
         return on
 
     @staticmethod
@@ -540,7 +537,10 @@ class NeuralRayRenderer(nn.Module):
             q = dict(que_b, coords=que_b['coords'][:, r0:r0 + chunk].contiguous(), fine_u=fine_u[:, r0:r0 + chunk].contiguous())
             n = q['coords'].shape[1]
             coarse, ex = self._train_pass(hot, prep, q, None, 'coarse', True, ray_feats, img_feats, P)
-            fine, _ = self._train_pass(hot, prep, q, ex['fine_depth'], 'fine', False, ray_feats, img_feats, P)
+            fine_depth = ex['fine_depth']
+            if self.cfg['fine_depth_use_all']:                              # renderer.py:145-146: coarse and resampled depths together
+                fine_depth = torch.sort(torch.cat([ex['depth'].reshape(B, n, -1), fine_depth], -1), -1)[0]
+            fine, _ = self._train_pass(hot, prep, q, fine_depth, 'fine', False, ray_feats, img_feats, P)
             parts.append(dict(self._stacked(coarse, B, n), **self._stacked(fine, B, n, '_fine')))
         st = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]} if len(parts) > 1 else parts[0]
         if not self.cfg['render_depth']:
@@ -741,7 +741,7 @@ class NeuralRayRenderer(nn.Module):
         bref = {'imgs': imgs.reshape(B, V, 3, h, w), 'img_feats': img_feats.detach(), 'ray_feats': ray_feats.detach(),
                 'poses': stack('poses', refs), 'Ks': stack('Ks', refs), 'depth_range': stack('depth_range', refs),
                 'bbox3d': stack('bbox3d', refs)}
-        prep = hot.prepare(bref, R, rn, max(c['depth_sample_num'], fdn))
+        prep = hot.prepare(bref, R, rn, self._dn_max())
         P = self._params()
         que_b = {'coords': torch.cat([q['coords'] for q in ques]), 'pose': torch.cat([q['poses'] for q in ques]),
                  'K': torch.cat([q['Ks'] for q in ques]), 'depth_range': torch.cat([q['depth_range'] for q in ques])}

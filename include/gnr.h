@@ -275,7 +275,10 @@ int gnr_sample_volume_bwd(const GnrScene* scene, int volume_res, const float* le
  * resampling and the sort (F1/F2) run in the forward kernels.  PyTorch autograd only connects the pairs with the losses.
  *   stats_out [B, rn*dn, 66] = mean(32) var(32) wbar n_valid_views (true scale); colors_out [B, rn*dn, 3]           */
 size_t gnr_render_chain_train_workspace_bytes(const GnrScene* scene, int rn, int dn);
-/*   depth == NULL: the coarse pass, sample_depth (render_ops.py:146-170) on the device (dn must be rays->dn).
+/*   depth == NULL: the coarse pass, sample_depth (render_ops.py:146-170) on the device (dn must be rays->dn, 3..64).
+ *   depth != NULL: dn caller-given depths per ray, 3..128 (fine_depth_use_all, renderer.py:145-146: the fine pass renders the
+ *   coarse and the resampled depths together); gnr_render_tail_fwd_train, gnr_ray_tail_dual_bwd and gnr_composite_bwd take the
+ *   same range (the inverse-CDF resampler, fine_depth_out, at most 64).
  *   depth_out [B,rn,dn], pts_out [B,rn*dn,3], qdir_out [B,rn,3] (each nullable): the depths the pass used and its ray
  *   geometry (render_ops.py:4-39: sample points, normalised query directions) for the tail / compositing backward.  */
 int gnr_render_chain_fwd_train(const GnrScene* scene, const GnrRays* rays, const float* depth, int dn, const float* level_weights,

@@ -319,6 +319,7 @@ def render(P, ref, que, cfg, fine_u=None):
     if fine_u is None:
         fine_u = ((0.5 + torch.arange(fdn, dtype=torch.float32, device=dev)) / fdn)[None].expand(rn, fdn)
     fd = sample_fine_depth(depth, out['hit_prob_nr'][0].detach(), que['depth_range'], fdn, fine_u.to(dev))
+    fd = torch.cat([depth, fd], -1) if cfg.get('fine_depth_use_all') else fd          # renderer.py:145-146
     fine = render_by_depth(P, ref, que, torch.sort(fd, -1)[0], 'fine_dist_decoder.', 'fine_agg_net.', cfg)
     out.update({k + '_fine': v for k, v in fine.items()})
     return out

@@ -258,7 +258,7 @@ def test_use_vis_matches_reference(weights_np, golden):
 
 def test_use_vis_model_mirror(weights_np, golden):
     """NeuralRayRenderer with use_vis: the state dict gains the reference's twelve vis_decoder keys, sample_volume through the
-    mirror equals the reference's volume, training is refused (the backward twins do not carry the branch)."""
+    mirror equals the reference's volume, and training is on (its gradients: tests/test_train_step.py, fixture vis)."""
     from graspnerf_amd.renderer import NeuralRayRenderer
     G = golden('cfg1_use_vis')
     base = {'network': 'grasp_nerf', 'init_net_type': 'cost_volume', 'agg_net_type': 'neus', 'use_hierarchical_sampling': True,

@@ -66,7 +66,7 @@ def _hip_core(hp, level):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('R,dn,level', [(33, 40, 'coarse'), (7, 16, 'fine'), (300, 40, 'fine'), (3, 64, 'coarse'), (11, 5, 'coarse')])
+@pytest.mark.parametrize('R,dn,level', [(33, 40, 'coarse'), (7, 16, 'fine'), (300, 40, 'fine'), (3, 64, 'coarse'), (11, 5, 'coarse'), (64, 64, 'fine'), (5, 80, 'fine'), (70, 128, 'fine')])
 def test_dual_core_kernel_matches_tensor_algebra(R, dn, level, weights_np):
     """k_ray_dual_bwd through the C ABI against ray_tail.attn_core on the same inputs (masked rows, clipped samples,
     rays straddling wavefronts, more rays than one workgroup holds)."""
@@ -89,7 +89,7 @@ def test_dual_core_kernel_matches_tensor_algebra(R, dn, level, weights_np):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('V,rn,dn', [(4, 5, 7), (6, 33, 40)])
+@pytest.mark.parametrize('V,rn,dn', [(4, 5, 7), (6, 33, 40), (3, 64, 64), (3, 20, 128)])
 def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
     """After the HIP chain of a pass: k_ray<true>'s sdf / gradient against sdf_tail on the chain's statistics, then the
     whole tail backward (HIP core) against autograd's double backward for random upstream (a, gamma)."""
@@ -101,7 +101,8 @@ def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
     prep = hp.prepare(bref, 1, rn, dn)
     rng = np.random.default_rng(rn)
     depth = torch.sort(torch.from_numpy(rng.uniform(0.25, 0.75, (rn, dn)).astype(np.float32)), -1)[0].cuda()
-    cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+    # (the pass runs on caller-given depths: up to 128 of them, fine_depth_use_all; the coarse sampler's own counts stay <= 64)
+    cfg = {'depth_sample_num': min(dn, 64), 'fine_depth_sample_num': min(dn, 64), 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
     bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
     stats, colors, geo, ctx = hp.render_chain_train(bq, depth[None], 'fine', cfg, prep)
     fw = hp.render_tail_train(ctx, bq, depth[None], colors)
@@ -129,7 +130,7 @@ def test_tail_forward_and_backward_on_a_render_pass(V, rn, dn, weights_np):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('R,dn,level', [(70, 40, 'coarse'), (5, 7, 'fine'), (130, 64, 'coarse')])
+@pytest.mark.parametrize('R,dn,level', [(70, 40, 'coarse'), (5, 7, 'fine'), (130, 64, 'coarse'), (33, 80, 'fine'), (70, 128, 'fine')])
 def test_composite_backward_kernel(R, dn, level, weights_np):
     """k_composite_bwd against autograd over reference_autograd.composite (NeuS alpha, cumprod compositing, eikonal term) for a
     random upstream on every output, including the gradient of deviation_network.variance."""

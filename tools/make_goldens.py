@@ -401,13 +401,14 @@ def run_full_forward(renderer):
     print('full forward golden:', {k: v.shape for k, v in g.items()})
 
 
-def run_train_step(renderer, scene_id=0, weight_seed=7, torch_seed=321, loss_seed=5, out_name='golden_train_step.npz', use_vis=False):
+def run_train_step(renderer, scene_id=0, weight_seed=7, torch_seed=321, loss_seed=5, out_name='golden_train_step.npz', use_vis=False, use_all=False):
     """One training step of the reference (trainer.py:142-158): GraspNeRF.forward in train mode on a cfg1 scene with
     synthetic supervision (synth_loss_case targets), the configured losses (loss: [render, depth, sdf, vgn]), backward.
     -> tests/golden/<out_name>: every loss term, the gradient of every hot-path parameter (full arrays) and the
     L2 norm of every parameter's gradient.  Two fixtures are kept: the defaults (golden_train_step.npz) and a
     second scene / parameter draw / RNG stream (golden_train_step_b.npz: scene 3, weight seed 11, torch seed 77, loss case 9); a third with
-    `use_vis: true` on both decoders (golden_train_step_vis.npz: the fourth decoder branch, dist_decoder.py:89-97, under training)."""
+    `use_vis: true` on both decoders (golden_train_step_vis.npz: the fourth decoder branch, dist_decoder.py:89-97, under training); a fourth with
+    `fine_depth_use_all: true` (golden_train_step_all.npz: 16 + 16 samples per ray in the fine pass, renderer.py:145-146)."""
     _stub_optional_modules()
     import network.loss as L
     cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
@@ -416,6 +417,9 @@ def run_train_step(renderer, scene_id=0, weight_seed=7, torch_seed=321, loss_see
     cfg['agg_net_cfg']['sample_num'] = cfg['fine_agg_net_cfg']['sample_num'] = 16
     if use_vis:
         cfg['dist_decoder_cfg']['use_vis'] = cfg['fine_dist_decoder_cfg']['use_vis'] = True
+    if use_all:                                       # renderer.py:145-146; the fine level's positional table must hold dn + fdn rows (ibrnet.py:491)
+        cfg['fine_depth_use_all'] = True
+        cfg['fine_agg_net_cfg']['sample_num'] = 32
     import utils.field_utils as fu
     fu.RESOLUTION, fu.VOXEL_SIZE = 16, fu.VOLUME_SIZE / 16
     fu.HALF_VOXEL_SIZE = fu.VOXEL_SIZE / 2
@@ -453,6 +457,7 @@ def run_train_step(renderer, scene_id=0, weight_seed=7, torch_seed=321, loss_see
     g['no_grad'] = np.array([k for k, p in net.named_parameters() if p.grad is None])
     g['setup'] = np.array([scene_id, weight_seed, torch_seed, loss_seed])
     g['use_vis'] = np.int64(1 if use_vis else 0)
+    g['fine_depth_use_all'] = np.int64(1 if use_all else 0)
     np.savez_compressed(ROOT + '/tests/golden/' + out_name, **g)
     print('train step golden: total', total.item(), {k: float(v.mean()) for k, v in terms.items() if k.startswith('loss')})
     print('  params', len(names), 'without grad', len(g['no_grad']), 'hot-path grads stored', sum(k.startswith('grad.') for k in g))
@@ -533,6 +538,8 @@ def main():
     if '--train-step-only' in sys.argv:
         if '--vis' in sys.argv:
             return run_train_step(renderer, 1, 13, 99, 7, 'golden_train_step_vis.npz', use_vis=True)
+        if '--use-all' in sys.argv:
+            return run_train_step(renderer, 2, 17, 55, 3, 'golden_train_step_all.npz', use_all=True)
         run_train_step(renderer)
         return run_train_step(renderer, 3, 11, 77, 9, 'golden_train_step_b.npz')
     if '--losses-only' in sys.argv:
@@ -582,6 +589,7 @@ def main():
     run_train_step(renderer)
     run_train_step(renderer, 3, 11, 77, 9, 'golden_train_step_b.npz')
     run_train_step(renderer, 1, 13, 99, 7, 'golden_train_step_vis.npz', use_vis=True)
+    run_train_step(renderer, 2, 17, 55, 3, 'golden_train_step_all.npz', use_all=True)
 
 
 if __name__ == '__main__':
