@@ -327,17 +327,17 @@ def test_bwd_fragments_compute_transposed_products(weights_np):
 
 
 def test_training_tail_entry_points_validate_arguments():
-    """The flat-list entry points of the render pass's backward refuse null pointers and sizes outside 3..64 samples before
+    """The flat-list entry points of the render pass's backward refuse null pointers and sizes outside 3..128 samples before
     touching the device (status codes of include/gnr.h: -1 bad argument, -2 bad shape); no compute call, runs without a GPU."""
     L = _lib.lib()
     p = 4096                                       # any non-null address: validation happens first
     assert L.gnr_ray_tail_grad_floats() == 1073
     assert L.gnr_ray_tail_dual_bwd(None, p, p, p, p, p, p, p, 4, 40, None) == -1
     assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 2, None) == -2
-    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 65, None) == -2
+    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 129, None) == -2
     assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 0, 40, None) == -2
     assert L.gnr_composite_bwd(p, p, p, p, p, p, None, None, None, None, None, p, p, p, p, 4, 40, None) == -1      # dpix is required
-    assert L.gnr_composite_bwd(p, p, p, p, p, p, p, None, None, None, None, p, p, p, p, 4, 70, None) == -2
+    assert L.gnr_composite_bwd(p, p, p, p, p, p, p, None, None, None, None, p, p, p, p, 4, 129, None) == -2
     assert L.gnr_geo_dual_fwd(p, p, p, None, p, p, 10, None) == -1
     assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 0, None) == -2
     assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, None, 10, p, 1 << 20, None) == -1
