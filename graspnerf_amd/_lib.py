@@ -59,6 +59,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise GnrError(f'{LIB_PATH} not found: build it with graspnerf_amd/csrc/build.sh '
                        f'(or __graft_entry__.build()); there is no CPU fallback for the hot path')
+    # torch first: the PyTorch-ROCm wheel ships its own ROCm runtime libraries, and device pointers / streams cross between the two
+    # (plumbing, include/gnr.h).  A process that dlopen()s libgnr.so before importing torch binds /opt/rocm's runtime, torch then
+    # loads its own next to it, and the second runtime finds no device (`python __graft_entry__.py smoke`: build() then smoke()).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.gnr_canonical_weights_floats.restype = C.c_int
     L.gnr_packed_weights_floats.restype = C.c_int

@@ -84,8 +84,15 @@ def test_dual_core_kernel_matches_tensor_algebra(R, dn, level, weights_np):
     hb, hdb, H = _hip_core(hp, level)(W, gg, gd, a, nvalid)
     torch.cuda.synchronize()
     assert _rel(hb, tb) < 5e-4 and _rel(hdb, tdb) < 5e-4
+    # the parameter gradients are sums over all R * dn samples (float atomics in the kernel, no fixed order); where thousands of
+    # O(1) terms cancel to ~1e-3 (LayerNorm bias, the folded output bias) "1e-3 of the result" asks for more than fp32 sums hold,
+    # so the float64 evaluation arbitrates: within 1e-3 of it, or no further from it than 5x the fp32 tensor algebra is
+    W64 = rt.tail_weights({k: v.double() for k, v in P.items()}, agg)
+    _, _, G64 = rt.attn_core(W64, gg.double(), gd.double(), a.double(), nvalid.double())
     for k in G:
-        assert _rel(H[k], G[k]) < 1e-3, k
+        scale = float(G64[k].abs().max())
+        e_hip, e_t32 = float((H[k].double() - G64[k]).abs().max()), float((G[k].double() - G64[k]).abs().max())
+        assert e_hip <= 1e-3 * scale or e_hip <= 5 * e_t32, (k, e_hip, e_t32, scale)
 
 
 @pytest.mark.gpu
