@@ -89,8 +89,11 @@ def newest_pmc(stamp_key, *sources):
 def recorded_bwd_traffic(scenes):
     """HBM-side bytes per launch of k_view1_bwd (volume points, 8 scenes) from the recorded PMC passes, or None."""
     d, src = newest_pmc('bwd_source_sha16', 'gnr_kernels.hip', 'gnr_bwd.inc')
+    if d is None:
+        return None, None
     try:
-        return (int(d['kernels']['k_view1_bwd']['hbm_bytes_corrected']), src) if (d and scenes == 8) else (None, None)
+        k = d['kernels'].get('k_view1_bwd<false>') or d['kernels']['k_view1_bwd']      # (a template since the use_vis twin; older files: plain)
+        return (int(k['hbm_bytes_corrected']), src) if scenes == 8 else (None, None)
     except KeyError:
         return None, None
 
