@@ -75,6 +75,7 @@ class HotPath:
     def prepare(self, ref, res=40, rn=0, dn=0):
         """Repack feature maps + per-view projection blocks (timed part of a forward)."""
         self.generation += 1
+        self._pass_seq = 0                               # render passes of this forward, counted for their persistent training workspaces
         scene, keep = self._scene(ref)
         ws = self._workspace(scene, res, rn, dn)
         _lib.check(self.L.gnr_prepare(C.byref(scene), ws.data_ptr(), ws.numel(), self._stream()), 'gnr_prepare')
@@ -280,7 +281,20 @@ class HotPath:
         need = self.L.gnr_workspace_bytes(C.byref(scene), 1, rn, dn)
         if ws.numel() < need:
             raise _lib.GnrError('render_chain_train: prepare() the workspace for the ray count first')
-        tws = torch.empty(self.L.gnr_render_chain_train_workspace_bytes(C.byref(scene), rn, dn), dtype=torch.uint8, device=self.device)
+        # the pass's training workspace (saved per-view states + gradient staging: ~1 GB at 8 scenes x 512 rays x 40 samples) is kept
+        # per (level, shape) across steps: allocating and releasing gigabyte blocks every step next to the feature extractors'
+        # activations left the caching allocator re-carving its pool, which showed up as occasional 50-80 ms host stalls inside the
+        # forward.  Keyed by the pass's position in its forward (every ray chunk's passes are alive until the backward) and its
+        # shape; safe to re-use across forwards: a training forward before the previous one's backward is refused (check_generation).
+        need_t = self.L.gnr_render_chain_train_workspace_bytes(C.byref(scene), rn, dn)
+        pool = self.__dict__.setdefault('_pass_tws', {})
+        seq = self._pass_seq = getattr(self, '_pass_seq', 0) + 1
+        key = (seq, level, scene.B, rn, dn)
+        if key not in pool or pool[key].numel() < need_t:
+            if len(pool) >= 16:                          # shapes keep changing (not a training loop): let the old ones go
+                pool.clear()
+            pool[key] = torch.empty(need_t, dtype=torch.uint8, device=self.device)
+        tws = pool[key]
         stats = torch.empty(B, rn * dn, 66, dtype=torch.float32, device=self.device)
         colors = torch.empty(B, rn * dn, 3, dtype=torch.float32, device=self.device)
         geo = {'depth': torch.empty(B, rn, dn, dtype=torch.float32, device=self.device) if depth is None else depth,

@@ -23,7 +23,7 @@ def opt(*a, **k):
     out = orig_opt(*a, **k); stamp('opt1'); return out
 net.forward_scenes, T.train_losses_stacked, tr._allreduce_grads, tr.optimizer.step = fs, tl, ar, opt
 rows = []
-for i in range(40):
+for i in range(80):
     marks.clear()
     torch.cuda.synchronize(); tp = time.perf_counter()
     tr.net.train(); tp1 = time.perf_counter()
@@ -37,7 +37,7 @@ for i in range(40):
     gpu = {marks[j + 1][0]: marks[j][2].elapsed_time(marks[j + 1][2]) for j in range(len(marks) - 1)}
     host['pre_train()'], host['pre_zero_grad'], host['step_start_to_fwd0'] = pre[0], pre[1], (marks[0][1] - t) * 1e3
     rows.append(((t_end - t) * 1e3, (t_ret - t) * 1e3, host, gpu))
-med = sorted(r[0] for r in rows)[20]
+med = sorted(r[0] for r in rows)[40]
 print('median step %.1f ms' % med)
 for i, (tot, ret, host, gpu) in enumerate(rows):
     if tot > med + 8 or i == 3 or max(host['pre_train()'], host['pre_zero_grad']) > 5:
