@@ -63,7 +63,8 @@ def _stream(t):
 class _InstNormActFn(torch.autograd.Function):
     """act(InstanceNorm2d(x) + res) in one pass per direction on the device (csrc/gnr_img.hip: the plane stays in registers
     between the statistics and the apply pass).  The op-by-op statement of the same arithmetic is `_InstanceNormFn` above plus
-    the residual add and F.relu / F.elu; tests/test_backbone_ops.py holds the two against each other."""
+    the residual add and F.relu / F.elu (kept as the readable form of the backward formula; the product no longer calls it);
+    tests/test_backbone_ops.py holds this kernel against ATen's instance norm + add + activation and against float64."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, act, res):
