@@ -515,3 +515,20 @@ def test_vis_decoder_branch(weights_np):
                 out[r] += packed[off('T_DECV3') + g * 8 + j] * h[r, nat(j, g)]
     np.testing.assert_allclose(out + packed[off('T_VIS')], x.astype(np.float64) @ sd['dist_decoder.vis_decoder.4.weight'][0] + sd['dist_decoder.vis_decoder.4.bias'][0],
                                rtol=2e-5, atol=2e-5)
+
+
+def test_gradient_blob_key_order_with_and_without_the_vis_decoder():
+    """weights.level_keys / split_canonical: the canonical order of a level (63 tensors, 36 958 floats) and, for a use_vis level, the
+    vis_decoder's six tensors BEHIND it (2 145 floats more: the layout of the *_bwd entry points' gradient blobs, include/gnr.h)."""
+    L = _lib.lib()
+    n, nv = L.gnr_canonical_weights_floats(), L.gnr_canonical_vis_floats()
+    assert (n, nv) == (36958, 2145)
+    for level, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')):
+        base, ext = weights.level_keys(level), weights.level_keys(level, use_vis=True)
+        assert ext[:len(base)] == base and [k for k, _ in ext[len(base):]] == [dec + k for k, _ in weights.VIS_KEYS]
+        flat = np.arange(n + nv, dtype=np.float32)
+        parts = weights.split_canonical(flat, level, use_vis=True)
+        assert list(parts) == [k for k, _ in ext]
+        assert parts[dec + 'vis_decoder.0.weight'].shape == (32, 32) and parts[dec + 'vis_decoder.0.weight'][0, 0] == n
+        assert parts[dec + 'vis_decoder.4.bias'].reshape(-1)[0] == n + nv - 1
+        assert sum(int(np.prod(s)) if len(s) else 1 for _, s in base) == n
