@@ -471,7 +471,7 @@ def main():
     ap.add_argument('--no-backbones', action='store_true', help='skip the images -> grasps figure')
     ap.add_argument('--no-f32-build', action='store_true', help='skip timing the fp32-MFMA companion build next to the product')
     ap.add_argument('--train-scenes', type=int, default=8)
-    ap.add_argument('--train-steps', type=int, default=8)
+    ap.add_argument('--train-steps', type=int, default=16, help='timed steps of the train_step record (16: one stalled step moves the mean by 5 %, not 12)')
     ap.add_argument('--train-warmup', type=int, default=10, help='the caching allocators and MIOpen settle over ~10 steps')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (the product); gloo only with --stub-step-ms')
     ap.add_argument('--stub-step-ms', type=float, default=0.0, help='> 0: no GPU, a step is a sleep of this length (control-flow test of the N > 1 branches)')
