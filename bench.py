@@ -472,7 +472,7 @@ def main():
     ap.add_argument('--no-f32-build', action='store_true', help='skip timing the fp32-MFMA companion build next to the product')
     ap.add_argument('--train-scenes', type=int, default=8)
     ap.add_argument('--train-steps', type=int, default=16, help='timed steps of the train_step record (16: one stalled step moves the mean by 5 %, not 12)')
-    ap.add_argument('--train-warmup', type=int, default=10, help='the caching allocators and MIOpen settle over ~10 steps')
+    ap.add_argument('--train-warmup', type=int, default=24, help='the caching allocators and MIOpen (solvers compiled on their first uses) settle over ~20 steps: profiles/r03_d, r03_f show stalled steps up to the 13th')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (the product); gloo only with --stub-step-ms')
     ap.add_argument('--stub-step-ms', type=float, default=0.0, help='> 0: no GPU, a step is a sleep of this length (control-flow test of the N > 1 branches)')
     ap.add_argument('--stub-parity-fail', action='store_true', help='with --stub-step-ms: rank 0 fails its parity gate (every rank must exit 3)')
