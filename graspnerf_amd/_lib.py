@@ -149,7 +149,9 @@ def lib():
     L.gnr_render_tail_fwd_train.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_int, C.c_void_p,
                                             C.POINTER(GnrRenderOut), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                             C.c_void_p]
-    L.gnr_composite_bwd.argtypes = [C.c_void_p] * 15 + [C.c_int, C.c_int, C.c_void_p]
+    L.gnr_composite_bwd.argtypes = [C.c_void_p] * 15 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_composite_bwd_workspace_bytes.argtypes = [C.c_int]
+    L.gnr_composite_bwd_workspace_bytes.restype = C.c_size_t
     L.gnr_host_randperm_prefix.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p]
     L.gnr_host_randperm_prefix.restype = C.c_int
     L.gnr_geo_dual_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
@@ -161,7 +163,10 @@ def lib():
     L.gnr_composite_bwd.restype = C.c_int
     L.gnr_render_tail_fwd_train.restype = C.c_int
     L.gnr_ray_tail_grad_floats.restype = C.c_int
-    L.gnr_ray_tail_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]
+    L.gnr_ray_tail_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_ray_tail_dual_bwd_workspace_bytes.restype = C.c_size_t
+    L.gnr_debug_poison_partials.argtypes = [C.c_int]
+    L.gnr_debug_poison_partials.restype = C.c_int
     L.gnr_ray_tail_dual_bwd.restype = C.c_int
     L.gnr_grasp_select_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.gnr_grasp_select_workspace_bytes.restype = C.c_size_t
@@ -205,7 +210,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
             'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
-            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_composite_bwd', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
+            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_debug_poison_partials', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
             'gnr_img_last_error', 'gnr_instnorm_act', 'gnr_instnorm_act_bwd', 'gnr_reflect_pad2d', 'gnr_reflect_pad2d_bwd', 'gnr_upsample2x_bilinear']
 
 

@@ -63,6 +63,14 @@ class HotPath:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _scratch(self, name, nbytes):
+        """Persistent per-purpose scratch of the backward twins (the partial sums of their deterministic parameter-gradient
+        reductions; stream-ordered, so one buffer per purpose serves every call)."""
+        bufs = self.__dict__.setdefault('_scratch_bufs', {})
+        if name not in bufs or bufs[name].numel() < nbytes:
+            bufs[name] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        return bufs[name]
+
     generation = 0
 
     def check_generation(self, gen):
@@ -387,10 +395,11 @@ class HotPath:
         dvar = torch.empty(1, dtype=torch.float32, device=self.device)
         ptr = lambda x: None if x is None else x.data_ptr()
         w = self.wc if level == 'coarse' else self.wf
+        scr = self._scratch('comp', self.L.gnr_composite_bwd_workspace_bytes(R))
         _lib.check(self.L.gnr_composite_bwd(w.data_ptr(), sdf.data_ptr(), grad.data_ptr(), col.data_ptr(), depth.data_ptr(),
                                             qdir.data_ptr(), dpix.data_ptr(), ptr(ddepth), ptr(wgerr), ptr(dalpha), ptr(dhit),
-                                            a.data_ptr(), gamma.data_ptr(), dcol.data_ptr(), dvar.data_ptr(), R, dn, self._stream()),
-                   'gnr_composite_bwd')
+                                            a.data_ptr(), gamma.data_ptr(), dcol.data_ptr(), dvar.data_ptr(), R, dn,
+                                            scr.data_ptr(), scr.numel(), self._stream()), 'gnr_composite_bwd')
         return a, gamma, dcol, dvar
 
     def ray_tail_dual_bwd(self, level, g, gd, a, nvalid):
@@ -401,9 +410,10 @@ class HotPath:
         gbar, gdbar = torch.empty_like(g), torch.empty_like(g)
         dtail = torch.empty(self.L.gnr_ray_tail_grad_floats(), dtype=torch.float32, device=self.device)
         w = self.wc if level == 'coarse' else self.wf
+        scr = self._scratch('tail', self.L.gnr_ray_tail_dual_bwd_workspace_bytes())
         _lib.check(self.L.gnr_ray_tail_dual_bwd(w.data_ptr(), g.data_ptr(), gd.data_ptr(), a.data_ptr(), nvalid.data_ptr(),
-                                                gbar.data_ptr(), gdbar.data_ptr(), dtail.data_ptr(), R, dn, self._stream()),
-                   'gnr_ray_tail_dual_bwd')
+                                                gbar.data_ptr(), gdbar.data_ptr(), dtail.data_ptr(), R, dn, scr.data_ptr(), scr.numel(),
+                                                self._stream()), 'gnr_ray_tail_dual_bwd')
         return gbar, gdbar, dtail
 
     def set_bwd_weights(self, packed_bwd_coarse, packed_bwd_fine=None):

@@ -236,6 +236,14 @@ int gnr_reflect_pad2d_bwd(const float* dy, float* dx, long long planes, int H, i
 int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, int W, void* stream);
 
 /* ---- backward twins ------------------------------------------------------------------------
+ * Parameter gradients are DETERMINISTIC: the kernels use no float atomics on them.  Points / rays are assigned to
+ * wavefronts statically, every wavefront stores its partial sums into its own slot of a partial buffer inside the
+ * caller-owned scratch / training workspace, and one reduction kernel per entry point adds the slots in slot order (in
+ * double) into d_canonical / dtail.  Two calls on the same inputs return the same bits (the reference's CPU backward is
+ * deterministic as well: ibrnet.py:497-504 + autograd).  Only the feature-map gradients (d_ray_feats, d_img_feats: a
+ * bilinear scatter, like ATen's grid_sampler backward on a GPU) are accumulated with float atomics.
+ * gnr_debug_poison_partials(1) fills the partial buffers with NaN patterns before the kernels run (tests: an entry no
+ * wavefront stores would show in the reduced gradient); returns the old setting.
  * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
  * consumed by DepthLoss, loss.py:87-144).  sample_volume and the per-view chain of the render passes follow below;
  * the render path's twin pairs (per-view chain, per-ray tail, compositing) follow further down.
@@ -244,7 +252,9 @@ int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, i
  *                         mean_decoder.{0,2,4}.{weight,bias} entries, state-dict order) and
  *                         d_ray_feats [B,V,32,fh,fw] (overwritten; NULL to skip).  Needs gnr_prepare's
  *                         workspace (feature maps in channel-last form) and a separate scratch buffer of
- *                         gnr_depth_mean_bwd_workspace_bytes(scene) for the channel-last gradient.           */
+ *                         gnr_depth_mean_bwd_workspace_bytes(scene) for the partial parameter gradients and the
+ *                         channel-last feature gradient (required, also with d_ray_feats == NULL).            */
+int gnr_debug_poison_partials(int on);
 int gnr_packed_bwd_floats(void);
 int gnr_pack_weights_bwd(const float* canonical_host, float* packed_bwd_host);
 size_t gnr_depth_mean_bwd_workspace_bytes(const GnrScene* scene);
@@ -314,7 +324,8 @@ int gnr_ray_tail_grad_floats(void);
 int gnr_geo_dual_fwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, float* g, float* gd,
                      int P, void* stream);
 /* bwd runs as two kernels (one lane per point; then the weight-gradient outer products over the points on the matrix cores) with the
- * per-point adjoints between them in caller-owned scratch of gnr_geo_dual_bwd_workspace_bytes(P) bytes (288 floats per point). */
+ * per-point adjoints between them (288 floats per point) and the partial weight gradients in caller-owned scratch of
+ * gnr_geo_dual_bwd_workspace_bytes(P) bytes. */
 size_t gnr_geo_dual_bwd_workspace_bytes(int P);
 int gnr_geo_dual_bwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, const float* gbar,
                      const float* gdbar, float* dstats, float* d_canonical, int P, void* scratch, size_t scratch_bytes, void* stream);
@@ -322,13 +333,18 @@ int gnr_geo_dual_bwd(const float* canonical_dev, const float* stats, const float
  * of rays, forward values taken from the tensors the forward wrote: sdf [nrays*dn], grad, col [nrays*dn,3], depth
  * [nrays*dn], qdir [nrays,3].  Upstream: dpix [nrays,3]; ddepth [nrays], wgerr [nrays] (d L / d sum_k (|grad_k|-1)^2 of the
  * ray), dalpha, dhit [nrays*dn] may be null.  Out: a_out = dL/d sdf, gamma_out = dL/d grad (the upstreams of
- * gnr_ray_tail_dual_bwd), dcol_out, dvar_out[0] = dL/d deviation_network.variance (all overwritten).               */
+ * gnr_ray_tail_dual_bwd), dcol_out, dvar_out[0] = dL/d deviation_network.variance (all overwritten).
+ * scratch: gnr_composite_bwd_workspace_bytes(nrays) / gnr_ray_tail_dual_bwd_workspace_bytes() bytes, caller-owned (the
+ * per-wavefront partial sums of the parameter gradients).                                                            */
+size_t gnr_composite_bwd_workspace_bytes(int nrays);
 int gnr_composite_bwd(const float* level_weights, const float* sdf, const float* grad, const float* col, const float* depth,
                       const float* qdir, const float* dpix, const float* ddepth, const float* wgerr, const float* dalpha,
                       const float* dhit, float* a_out, float* gamma_out, float* dcol_out, float* dvar_out, int nrays, int dn,
-                      void* stream);
+                      void* scratch, size_t scratch_bytes, void* stream);
+size_t gnr_ray_tail_dual_bwd_workspace_bytes(void);
 int gnr_ray_tail_dual_bwd(const float* level_weights, const float* g, const float* gd, const float* a, const float* nvalid,
-                          float* gbar, float* gdbar, float* dtail, int nrays, int dn, void* stream);
+                          float* gbar, float* gdbar, float* dtail, int nrays, int dn, void* scratch, size_t scratch_bytes,
+                          void* stream);
 
 /* ---- host helper ---------------------------------------------------------------------------
  * The first k entries of torch.randperm(n) on the CPU generator, bit-exact, in O(k + n/624) instead of n random-access swaps:

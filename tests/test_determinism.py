@@ -1,0 +1,150 @@
+"""Parameter gradients of the backward twins are deterministic (csrc/gnr_bwd.inc: per-wavefront partial slots + a
+fixed-order reduction in double, no float atomics): two calls on the same inputs return the same BITS, like the
+reference's CPU backward (ibrnet.py:497-504 + autograd, trainer.py:146-158), and every entry of every partial slot is
+stored by exactly one wavefront (the poisoned run would show a missing store as NaN in the reduced gradient).
+Only the feature-map gradients (a bilinear scatter with float atomics, like ATen's grid_sampler backward on a GPU) may
+differ between runs, within rounding."""
+import numpy as np
+import pytest
+import torch
+
+from graspnerf_amd import weights, _lib
+from graspnerf_amd.synth import make_scene, CONFIGS
+
+pytestmark = pytest.mark.gpu
+
+
+def _hot(weights_np):
+    from graspnerf_amd.hotpath import HotPath
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    hp.set_bwd_weights(weights.pack_bwd(weights.canonical_blob(weights_np, 'coarse')), weights.pack_bwd(weights.canonical_blob(weights_np, 'fine')))
+    hp.can_dev = {lvl: torch.from_numpy(weights.canonical_blob(weights_np, lvl)).cuda() for lvl in ('coarse', 'fine')}
+    return hp
+
+
+def _feat_close(a, b):
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9
+
+
+@pytest.fixture()
+def poison():
+    """Runs the test body with the partial buffers poisoned (NaN patterns) before every backward kernel."""
+    L = _lib.lib()
+    prev = L.gnr_debug_poison_partials(1)
+    yield
+    L.gnr_debug_poison_partials(prev)
+
+
+def _volume_case(hp, V, res, B, H=96, W=128):
+    from graspnerf_amd.hotpath import batch_scenes
+    scenes = [make_scene(90 + i, dict(CONFIGS['cfg1' if H == 96 else 'cfg2'], V=V, rn=4)) for i in range(B)]
+    bref, _ = batch_scenes(scenes)
+    hp.sample_volume_train(bref, res)
+    dvol = torch.from_numpy(np.random.default_rng(V + res).standard_normal((B, 1, res, res, res)).astype(np.float32)).cuda()
+    return dvol
+
+
+@pytest.mark.parametrize('V,res,B,H,W', [(3, 16, 2, 96, 128), (6, 40, 2, 288, 512)])
+def test_sample_volume_bwd_is_bit_reproducible(V, res, B, H, W, weights_np, poison):
+    """All five stages, the second case at the benchmark's scene size (6 views 288x512, 40^3: every CU's four wavefronts hold
+    tiles): parameter gradients equal bit for bit, no entry of a slot left unstored."""
+    hp = _hot(weights_np)
+    dvol = _volume_case(hp, V, res, B, H, W)
+    runs = [hp.sample_volume_bwd(dvol, hp.can_dev['coarse']) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(runs[0][0]).all())
+    assert float(runs[0][0].abs().max()) > 0
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0])
+        _feat_close(r[1], runs[0][1]); _feat_close(r[2], runs[0][2])
+
+
+@pytest.mark.parametrize('V,rn,dn', [(3, 33, 16), (6, 512, 40)])
+def test_render_pass_bwd_is_bit_reproducible(V, rn, dn, weights_np, poison):
+    """One training render pass backwards: per-view chain (k_red2 / k_view2<true> / k_hoist / k_view1), geometry_fc on dual numbers,
+    the per-ray tail with its second-order path and the compositing -- every parameter gradient equal bit for bit."""
+    from graspnerf_amd.hotpath import batch_scenes
+    hp = _hot(weights_np)
+    cfgs = dict(CONFIGS['cfg1'] if V == 3 else CONFIGS['cfg2'], V=V, rn=rn)
+    bref, bque = batch_scenes([make_scene(70 + i, cfgs) for i in range(2)])
+    B = 2
+    prep = hp.prepare(bref, 1, rn, dn)
+    rng = np.random.default_rng(rn)
+    depth = torch.sort(torch.from_numpy(rng.uniform(0.25, 0.75, (B, rn, dn)).astype(np.float32)), -1)[0].cuda()
+    cfg = {'depth_sample_num': min(dn, 64), 'fine_depth_sample_num': min(dn, 64), 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+    bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
+    stats, colors, geo, ctx = hp.render_chain_train(bq, depth, 'fine', cfg, prep)
+    fw = hp.render_tail_train(ctx, bq, depth, colors)
+    N = B * rn * dn
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    ds, dc, a, gamma = t(B, rn * dn, 65), t(B, rn * dn, 3), t(B * rn, dn), t(B * rn, dn, 3)
+    st = stats.reshape(N, 66)
+    canon = hp.can_dev['fine']
+    dpix, wg = t(B * rn, 3), torch.full((B * rn,), 1e-3, device='cuda')
+
+    def once():
+        dcan, dray, dimg = hp.render_chain_bwd(ctx, ds, dc)
+        g, gd = hp.geo_dual_fwd(canon, st, geo['pts'], gamma.reshape(-1, 3))
+        gbar, gdbar, dt = hp.ray_tail_dual_bwd('fine', g.reshape(B * rn, dn, 16), gd.reshape(B * rn, dn, 16), a, st[:, 65].reshape(B * rn, dn))
+        dstats, dgeo = hp.geo_dual_bwd(canon, st, geo['pts'], gamma.reshape(-1, 3), gbar.reshape(-1, 16), gdbar.reshape(-1, 16))
+        comp = hp.composite_bwd('fine', fw['sdf_values'].reshape(B * rn, dn), fw['sdf_gradient'].reshape(B * rn, dn, 3),
+                                colors.reshape(B * rn, dn, 3), depth.reshape(B * rn, dn), geo['qdir'], dpix, None, wg, a, None)
+        return dict(dcan=dcan.clone(), dt=dt.clone(), dgeo=dgeo.clone(), dvar=comp[3].clone(), gbar=gbar.clone(), dstats=dstats.clone(),
+                    a=comp[0].clone(), gamma=comp[1].clone()), (dray.clone(), dimg.clone())
+    (p0, f0), (p1, f1), (p2, f2) = once(), once(), once()
+    torch.cuda.synchronize()
+    for k, v in p0.items():
+        assert bool(torch.isfinite(v).all()), k
+        assert float(v.abs().max()) > 0, k
+        assert torch.equal(p1[k], v) and torch.equal(p2[k], v), k
+    _feat_close(f1[0], f0[0]); _feat_close(f1[1], f0[1])
+
+
+def test_depth_mean_bwd_is_bit_reproducible(weights_np, poison):
+    from graspnerf_amd.hotpath import batch_scenes
+    hp = _hot(weights_np)
+    bref, _ = batch_scenes([make_scene(s, 'cfg2') for s in (0, 1)])
+    rng = np.random.default_rng(4)
+    pn = 8192
+    coords = np.stack([rng.uniform(-1, 512, (2, pn)), rng.uniform(-1, 288, (2, pn))], -1).astype(np.float32)
+    dmean = rng.standard_normal((2, 6, pn, 2)).astype(np.float32)
+    prep = hp.prepare(bref, 1)
+    runs = [hp.depth_mean_bwd(bref, coords, dmean, 'coarse', prepared=prep) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(runs[0][0]).all()) and float(runs[0][0].abs().max()) > 0
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0])
+        _feat_close(r[1], runs[0][1])
+
+
+def test_train_step_path_gradients_are_bit_reproducible():
+    """The whole training step of BASELINE configs[4]'s kind (backbones, render, volume, depth-mean head, grasp head, losses;
+    two scenes stacked) run twice from the same state and the same RNG stream: the gradients of every parameter of the volumetric
+    path (dist decoders, aggregation nets: 122 tensors) come out bit-identical.  Their upstream gradients pass through the grasp
+    head and the losses, which are deterministic kernels as well; the 2D backbones' gradients depend on the feature-map scatter
+    (float atomics) and are compared to rounding only."""
+    from test_train_step import build, scene_data
+    from graspnerf_amd.trainer import train_losses_stacked
+    from graspnerf_amd import losses
+    net = build('cuda')
+    net.nr_net.cfg['ray_batch_num'] = 4096                     # all 64 rays of a scene in one chunk: the batched forward
+    net.train()
+    datas = [dict(scene_data('cuda', scene_id=i, loss_seed=5 + i), step=0) for i in range(2)]
+    grads = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        net.zero_grad(set_to_none=True)
+        st = net.forward_scenes(datas, stacked=True)
+        assert st is not None
+        losses.total_loss(train_losses_stacked(st, datas), scenes=2).backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    path = [k for k in grads[0] if 'dist_decoder' in k or 'agg_net' in k]
+    assert len(path) >= 120
+    for k in path:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+    for k in grads[0]:
+        if k not in path:
+            d, s = float((grads[0][k] - grads[1][k]).abs().max()), float(grads[0][k].abs().max())
+            assert d <= 1e-3 * s + 1e-7, (k, d, s)
