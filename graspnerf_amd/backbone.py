@@ -90,8 +90,9 @@ class _InstNormActFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[5]) else None
-        scratch = torch.empty(2 * n * c + 2 * c, dtype=torch.float32, device=x.device)   # per-plane sums, then d weight, d bias
-        s1, s2, dw, db = scratch[:n * c], scratch[n * c:2 * n * c], scratch[2 * n * c:2 * n * c + c], scratch[2 * n * c + c:]
+        scratch = torch.empty(2 * n * c, dtype=torch.float32, device=x.device)            # per-plane sums
+        wb = torch.empty(2 * c, dtype=torch.float32, device=x.device)                     # d weight, d bias: their own small tensor
+        s1, s2, dw, db = scratch[:n * c], scratch[n * c:], wb[:c], wb[c:]                 # (AccumulateGrad may keep the views as .grad)
         _img_check(L.gnr_instnorm_act_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(),
                                           dx.data_ptr(), dres.data_ptr() if dres is not None else None, s1.data_ptr(), s2.data_ptr(),
                                           dw.data_ptr(), db.data_ptr(), n * c, c, h * w, ctx.act, _stream(x)), 'gnr_instnorm_act_bwd')
@@ -145,7 +146,10 @@ HIP_GLUE = {'norm': True, 'pad': True, 'upsample': True}      # switches for A/B
 
 
 def _on_device(x, what=None):
-    return x.is_cuda and x.dtype == torch.float32 and (what is None or HIP_GLUE[what])
+    """The HIP glue kernels launch on the CURRENT device with the stream of x's device: take them only when the two agree
+    (a model on cuda:1 while cuda:0 is current, or nn.DataParallel replicas, keep the ATen path)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.device.index == torch.cuda.current_device()
+            and (what is None or HIP_GLUE[what]))
 
 
 def upsample2x(x):
@@ -162,7 +166,7 @@ class _InstanceNorm(nn.InstanceNorm2d):
     stock module followed by the stock ops."""
 
     def forward(self, x, act=ACT_NONE, res=None):
-        if _on_device(x, 'norm'):
+        if _on_device(x, 'norm') and x.shape[-1] * x.shape[-2] > 1 and self.weight.dtype == torch.float32 and self.weight.device == x.device:
             return _InstNormActFn.apply(x, self.weight, self.bias, self.eps, act, res)
         y = super().forward(x)
         if res is not None:

@@ -44,6 +44,10 @@ class HotPath:
 
     # ---- plumbing ------------------------------------------------------------------------
     def _stream(self):
+        # the library launches on the CURRENT device: refuse a mismatch instead of launching on the wrong GPU
+        if self.device.index is not None and self.device.index != torch.cuda.current_device():
+            raise _lib.GnrError(f'HotPath on {self.device} but the current device is cuda:{torch.cuda.current_device()}: '
+                                f'wrap the call in `with torch.cuda.device({self.device.index})`')
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _scene(self, ref):
@@ -297,10 +301,9 @@ class HotPath:
         need_t = self.L.gnr_render_chain_train_workspace_bytes(C.byref(scene), rn, dn)
         pool = self.__dict__.setdefault('_pass_tws', {})
         seq = self._pass_seq = getattr(self, '_pass_seq', 0) + 1
-        key = (seq, level, scene.B, rn, dn)
+        key = (seq, level)                               # one buffer per pass position, grown in place when a shape needs more
         if key not in pool or pool[key].numel() < need_t:
-            if len(pool) >= 16:                          # shapes keep changing (not a training loop): let the old ones go
-                pool.clear()
+            pool[key] = None                             # drop the smaller buffer before allocating its replacement
             pool[key] = torch.empty(need_t, dtype=torch.uint8, device=self.device)
         tws = pool[key]
         stats = torch.empty(B, rn * dn, 66, dtype=torch.float32, device=self.device)
@@ -415,6 +418,14 @@ class HotPath:
                                                 gbar.data_ptr(), gdbar.data_ptr(), dtail.data_ptr(), R, dn, scr.data_ptr(), scr.numel(),
                                                 self._stream()), 'gnr_ray_tail_dual_bwd')
         return gbar, gdbar, dtail
+
+    def release_training_workspaces(self):
+        """Give the per-pass training workspaces (about 1 GB each at 8 scenes x 512 rays x 40 samples), the volume's training
+        workspace and the backward scratch buffers back to the allocator (after training, before a long evaluation)."""
+        self.__dict__.pop('_pass_tws', None)
+        self.__dict__.pop('_scratch_bufs', None)
+        self._tws = None
+        self._dm_scratch = self._gd_scratch = None
 
     def set_bwd_weights(self, packed_bwd_coarse, packed_bwd_fine=None):
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)

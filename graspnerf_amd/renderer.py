@@ -298,6 +298,11 @@ class NeuralRayRenderer(nn.Module):
         self.use_sdf = True
         self._hot = None
 
+    def train(self, mode=True):
+        if not mode and self._hot is not None:             # leaving training: the gigabyte-sized per-pass workspaces go back to the allocator
+            self._hot.release_training_workspaces()
+        return super().train(mode)
+
     # ---- HIP hot path handle (re-packed when parameters change device or values) -----------------
     def _apply(self, fn, *a, **k):
         self._hot = None
