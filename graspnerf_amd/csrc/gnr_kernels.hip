@@ -472,13 +472,58 @@ DEV void inv3x3(const float* K, float* o) {
     o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
 }
 
+// Traversal order of a scene's rays for the inference render passes: perm[b][slot] = index of the ray that sits at position `slot`
+// of the scene's rays sorted by the Morton code of their pixel (render_ops.py:4-39: a ray is a pixel of the query view).
+// The kernels' internal per-point arrays (descriptors, records) are laid out in that order, so the 16-point tiles of neighbouring
+// workgroups hold neighbouring pixels' rays, whose samples project onto nearly the same epipolar lines of every reference view:
+// the feature-map lines they gather are shared in L1 / L2 instead of being fetched once per ray (random training rays: the order
+// of `coords` carries no locality).  Every user-visible array keeps the caller's ray order (outputs are written through perm).
+// One workgroup per scene, bitonic sort of (morton << 12 | index) keys in LDS; rn <= 4096.
+constexpr int MAX_SORT_RAYS = 4096;
+DEV unsigned spread10(unsigned v) {           // 10 bits -> every other bit
+    v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_ray_order(const float* __restrict__ coords, int* __restrict__ perm, int rn, int shift) {
+    __shared__ unsigned key[MAX_SORT_RAYS];
+    const int b = blockIdx.x;
+    int M = 1;
+    while (M < rn) M <<= 1;
+    for (int i = threadIdx.x; i < M; i += 256) {
+        unsigned k = 0xFFFFFFFFu;
+        if (i < rn) {
+            const float x = coords[((size_t)b * rn + i) * 2], y = coords[((size_t)b * rn + i) * 2 + 1];
+            const unsigned xi = (unsigned)min(max((int)x, 0) >> shift, 1023), yi = (unsigned)min(max((int)y, 0) >> shift, 1023);
+            k = ((spread10(xi) | (spread10(yi) << 1)) << 12) | (unsigned)i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= M; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < M; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned a = key[i], c = key[l];
+                    const bool up = (i & k2) == 0;
+                    if ((a > c) == up) { key[i] = c; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < rn; i += 256) perm[(size_t)b * rn + i] = (int)(key[i] & 0xFFFu);
+}
+
 // ref: render_ops.py:4-39 (rays, unnormalised directions), :41-52 + dist_decoder.py:34-38 (intervals)
+// perm (nullable): descriptor slot (b, s, k) holds sample k of ray perm[b][s] (k_ray_order); coords / depth are in the caller's order
 __global__ void k_points_rays(const float* __restrict__ coords, const float* __restrict__ que_pose,
                               const float* __restrict__ que_K, const float* __restrict__ que_dr,
-                              const float* __restrict__ depth, float* __restrict__ desc, int rn, int dn, int B) {
+                              const float* __restrict__ depth, float* __restrict__ desc, int rn, int dn, int B,
+                              const int* __restrict__ perm = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * rn * dn) return;
-    const int b = i / (rn * dn), ray = (i / dn) % rn, k = i % dn;
+    const int b = i / (rn * dn), slot = (i / dn) % rn, k = i % dn;
+    const int ray = perm ? perm[(size_t)b * rn + slot] : slot;
     const float* P = que_pose + b * 12;
     float Ki[9];
     inv3x3(que_K + b * 9, Ki);
@@ -540,6 +585,9 @@ struct ChainArgs {
     // launch with only_if_flagged != 0 (the fp32-MFMA twin behind every pair launch) returns at once while the word is zero
     unsigned* range_flag;
     int only_if_flagged;
+    // inference render passes: the points are laid out in the Morton order of their rays (k_ray_order); the user-visible
+    // per-point outputs (colours, view masks) go to the caller's ray order: point (slot s, sample k) -> ray_perm[b][s] * dn + k
+    const int* ray_perm; int perm_rn, perm_dn;
 };
 
 struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
@@ -754,6 +802,11 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         const bool row_ok = n_raw < a.P;
         const int n = row_ok ? n_raw : a.P - 1;
         const size_t pt = (size_t)b * a.P + n;
+        size_t opt = pt;                                   // where the point's user-visible outputs go (caller's ray order)
+        if (RENDER && !SAVE && a.ray_perm) {
+            const int s_ = n / a.perm_dn;
+            opt = (size_t)b * a.P + (size_t)a.ray_perm[(size_t)b * a.perm_rn + s_] * a.perm_dn + (n - s_ * a.perm_dn);
+        }
         float p[3], qd[3], lo, hi;
         {
             const f4 d0 = reinterpret_cast<const f4*>(a.desc)[pt * 2], d1 = reinterpret_cast<const f4*>(a.desc)[pt * 2 + 1];
@@ -1157,7 +1210,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             float den = 0.f, num = 0.f;
 #pragma unroll
             for (int v = 0; v < V; ++v) { const float e = __expf(S(v, 9) - cmax); den += e; num += S(v, 19) * e; }
-            if (g < 3 && row_ok) a.colors[pt * 3 + g] = num * rcp1(den);
+            if (g < 3 && row_ok) a.colors[opt * 3 + g] = num * rcp1(den);
         }
         if (SAVE && a.saveZ) {
             float* sp = a.saveZ + ((size_t)b * tps + ts) * 18 * 64 + lane;
@@ -1205,7 +1258,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             } else {
                 if (g == 0) rec[16] = msum;
             }
-            if (a.vmask && g == 0) a.vmask[pt] = (unsigned char)vbits;
+            if (a.vmask && g == 0) a.vmask[opt] = (unsigned char)vbits;
             if (a.dbg && g == 0) {
                 float* d = a.dbg + pt * 32;
                 d[24] = msum; d[25] = wbar; d[26] = Z[0] * kLn2; d[27] = Z[8] * kLn2 * kLn2; d[28] = SV[8]; d[29] = G[0].x * kLn2; d[30] = gg[0] * kLn2; d[31] = vsum;
@@ -1245,6 +1298,8 @@ struct RayArgs {
     // inverse-CDF resampling (coarse pass only; nullable)
     float* fine_depth; int* fine_inds; int fdn;
     const float* fine_u;     // [nrays][fdn] caller-drawn samples (is_train) or null (eval midpoints)
+    const int* ray_perm;     // RENDER, nullable: rec / desc are in Morton order of the rays (k_ray_order); slot s of scene b holds ray
+                             // ray_perm[b][s]; every other array (inputs depth / colours / fine_u, all outputs) is in the caller's order
 };
 
 // LDS floats per ray after the attention scratch is dead (RENDER tail): per-ray reductions + resampling arrays
@@ -1321,6 +1376,11 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
     float* St = OVL ? sc + dn * 32 : sc + dn * 68;    // [dn][12]   shift[4] (log2 domain), 1/sum[4], rs[4]
     (void)Qb; (void)St; (void)Ob;
     const size_t pt = (size_t)ray * dn + i;
+    // the ray in the caller's order (RENDER with sorted descriptors): index of every user-visible array
+    int oray = ray;
+    if (RENDER && a.ray_perm) oray = (ray / a.rays_per_scene) * a.rays_per_scene + a.ray_perm[ray];
+    const size_t opt = (size_t)oray * dn + i;
+    (void)opt;
     constexpr int REC = RENDER ? REC_RAY : REC_VOL;
     const float* rec = a.rec + pt * REC;
     const float* W = a.wpk;
@@ -1626,8 +1686,8 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
                       + 4.f * c4 * de[15 + c] - 4.f * s4 * de[18 + c];
         }
         // ================= NeuS alpha (aggregate_net.py:105-121), compositing (render_ops.py:72-80)
-        const float z = a.depth[pt];
-        const float znext = a.depth[pt + ((i + 1 < dn) ? 1 : 0)];
+        const float z = a.depth[opt];
+        const float znext = a.depth[opt + ((i + 1 < dn) ? 1 : 0)];
         const float dist = (i + 1 < dn) ? znext - z : 1e6f;
         const float inv_s = fminf(fmaxf(__expf(W[pk::R_VARIANCE] * 10.f), 1e-6f), 1e6f);
         const float tcos = -(qd[0] * grad[0] + qd[1] * grad[1] + qd[2] * grad[2]);
@@ -1650,24 +1710,24 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
         const float gn = sqrtf(grad[0] * grad[0] + grad[1] * grad[1] + grad[2] * grad[2]) - 1.f;
         const float hp = __fadd_rn(hitp, 1e-5f);
         if (act) {
-            const float cr = a.colors[pt * 3], cg = a.colors[pt * 3 + 1], cb = a.colors[pt * 3 + 2];
+            const float cr = a.colors[opt * 3], cg = a.colors[opt * 3 + 1], cb = a.colors[opt * 3 + 2];
             Red[i] = hitp * cr; Red[rt::W + i] = hitp * cg; Red[2 * rt::W + i] = hitp * cb; Red[3 * rt::W + i] = hitp * z;
             Red[4 * rt::W + i] = gn * gn; Red[5 * rt::W + i] = (nvalid > (float)a.view_num) ? 1.f : 0.f;
             Hp[i] = hp;
-            if (a.sdf) a.sdf[pt] = sdf;
-            if (a.alpha) a.alpha[pt] = alpha;
-            if (a.hit) a.hit[pt] = hitp;
-            if (a.grad) { a.grad[pt * 3] = grad[0]; a.grad[pt * 3 + 1] = grad[1]; a.grad[pt * 3 + 2] = grad[2]; }
+            if (a.sdf) a.sdf[opt] = sdf;
+            if (a.alpha) a.alpha[opt] = alpha;
+            if (a.hit) a.hit[opt] = hitp;
+            if (a.grad) { a.grad[opt * 3] = grad[0]; a.grad[opt * 3 + 1] = grad[1]; a.grad[opt * 3 + 2] = grad[2]; }
         }
         __syncthreads();
         if (rvalid) {
             for (int qn = slot; qn < 6; qn += S) {      // slot q sums quantity q (q, q+S, .. when a ray has < 6 slots)
                 float s = 0.f;
                 for (int j = 0; j < dn; ++j) s += Red[qn * rt::W + j];
-                if (qn < 3) { if (a.pix) a.pix[(size_t)ray * 3 + qn] = s; }
-                else if (qn == 3) { if (a.rdepth) a.rdepth[ray] = s; }
-                else if (qn == 4) { if (a.gerr_part) a.gerr_part[ray] = s; }
-                else { if (a.rmask) a.rmask[ray] = (s > (float)a.point_num) ? 1 : 0; }     // renderer.py:130-132
+                if (qn < 3) { if (a.pix) a.pix[(size_t)oray * 3 + qn] = s; }
+                else if (qn == 3) { if (a.rdepth) a.rdepth[oray] = s; }
+                else if (qn == 4) { if (a.gerr_part) a.gerr_part[oray] = s; }
+                else { if (a.rmask) a.rmask[oray] = (s > (float)a.point_num) ? 1 : 0; }     // renderer.py:130-132
             }
         }
         // ================= inverse-CDF resampling for the fine pass (render_ops.py:172-229)
@@ -1707,7 +1767,7 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
             const bool fact = rvalid && slot < fdn;
             const int fs = min(slot, fdn - 1);
             const float interval = 1.f / (float)fdn;
-            const float u = a.fine_u ? a.fine_u[(size_t)ray * fdn + fs]
+            const float u = a.fine_u ? a.fine_u[(size_t)oray * fdn + fs]
                                      : __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)fs, interval));
             int inds = 0;
 #pragma unroll 8
@@ -1726,8 +1786,8 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
                 int rank = 0;                                                    // stable rank sort (renderer.py:148)
 #pragma unroll 8
                 for (int j = 0; j < fdn; ++j) { const float o2 = Fd[j]; rank += (o2 < fd || (o2 == fd && j < fs)) ? 1 : 0; }
-                a.fine_depth[(size_t)ray * fdn + rank] = fd;
-                if (a.fine_inds) a.fine_inds[(size_t)ray * fdn + fs] = inds;
+                a.fine_depth[(size_t)oray * fdn + rank] = fd;
+                if (a.fine_inds) a.fine_inds[(size_t)oray * fdn + fs] = inds;
             }
         }
     }

@@ -139,6 +139,10 @@ int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, 
  * gnr_force_fp32_chain(1) makes every chain launch run the fp32-MFMA kernel (tests, measurements); returns the old setting. */
 int gnr_range_status(const GnrScene* scene, const void* workspace, size_t workspace_bytes, unsigned* flags_out, void* stream);
 int gnr_force_fp32_chain(int on);
+/* gnr_debug_ray_order(1): the inference render passes traverse a scene's rays in the Morton order of their pixels (internal
+ * layout only: every array of the ABI keeps the caller's ray order, results are bit-identical).  Off by default: measured, it does
+ * not change the render launches' time (tools/ab_ray_order.py).  Returns the old setting. */
+int gnr_debug_ray_order(int on);
 
 /* sample_volume (renderer.py:164-199), volume_type [sdf]:
  *   sdf_out[b,x,y,z] for voxel centre bbox_min[b] + ((x,y,z)+.5)*(0.3/res).

@@ -119,11 +119,13 @@ def test_depth_mean_bwd_is_bit_reproducible(weights_np, poison):
 
 
 def test_train_step_path_gradients_are_bit_reproducible():
-    """The whole training step of BASELINE configs[4]'s kind (backbones, render, volume, depth-mean head, grasp head, losses;
-    two scenes stacked) run twice from the same state and the same RNG stream: the gradients of every parameter of the volumetric
-    path (dist decoders, aggregation nets: 122 tensors) come out bit-identical.  Their upstream gradients pass through the grasp
-    head and the losses, which are deterministic kernels as well; the 2D backbones' gradients depend on the feature-map scatter
-    (float atomics) and are compared to rounding only."""
+    """A training step of BASELINE configs[4]'s kind (render, volume, depth-mean head, grasp head, losses; two scenes stacked)
+    run twice from the same state, the same RNG stream and the same feature maps: every output of the forward and the gradient
+    of every parameter of the volumetric path (dist decoders, aggregation nets: 122 tensors) come out bit-identical -- their
+    upstream gradients pass through the losses and the grasp head, deterministic kernels as well.  The 2D feature extractors
+    are held fixed here (their outputs are recorded once and replayed): MIOpen's convolutions are outside this library and not
+    bit-reproducible from call to call on this stack; the feature-map gradients the path hands them (a bilinear scatter with
+    float atomics) are compared to rounding only."""
     from test_train_step import build, scene_data
     from graspnerf_amd.trainer import train_losses_stacked
     from graspnerf_amd import losses
@@ -131,8 +133,26 @@ def test_train_step_path_gradients_are_bit_reproducible():
     net.nr_net.cfg['ray_batch_num'] = 4096                     # all 64 rays of a scene in one chunk: the batched forward
     net.train()
     datas = [dict(scene_data('cuda', scene_id=i, loss_seed=5 + i), step=0) for i in range(2)]
-    grads = []
-    for _ in range(2):
+    nr = net.nr_net
+    with torch.no_grad():                                      # record the feature maps once
+        imgs = torch.cat([d['ref_imgs_info']['imgs'] for d in datas])
+        f_img = nr.image_encoder(imgs)
+        f_ray = nr.vis_encoder(nr.init_net({'imgs': imgs}, None, True), f_img)
+    leaves = {}
+
+    class Replay(torch.nn.Module):
+        def __init__(self, name, value):
+            super().__init__()
+            self.name, self.value = name, value
+
+        def forward(self, *a, **k):
+            leaves[self.name] = self.value.clone().requires_grad_(True)
+            return leaves[self.name]
+    nr.image_encoder = Replay('img', f_img)
+    nr.init_net = Replay('init', f_ray)
+    nr.vis_encoder = Replay('ray', f_ray)
+    grads, fwd, feat = [], [], []
+    for it in range(2):
         torch.manual_seed(11)
         net.zero_grad(set_to_none=True)
         st = net.forward_scenes(datas, stacked=True)
@@ -140,11 +160,14 @@ def test_train_step_path_gradients_are_bit_reproducible():
         losses.total_loss(train_losses_stacked(st, datas), scenes=2).backward()
         torch.cuda.synchronize()
         grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        fwd.append({k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)})
+        feat.append({k: v.grad.clone() for k, v in leaves.items() if v.grad is not None})
+    for k in fwd[0]:                                               # the forward of the path has no atomics at all
+        assert torch.equal(fwd[0][k], fwd[1][k]), ('forward', k)
     path = [k for k in grads[0] if 'dist_decoder' in k or 'agg_net' in k]
     assert len(path) >= 120
-    for k in path:
-        assert torch.equal(grads[0][k], grads[1][k]), k
-    for k in grads[0]:
-        if k not in path:
-            d, s = float((grads[0][k] - grads[1][k]).abs().max()), float(grads[0][k].abs().max())
-            assert d <= 1e-3 * s + 1e-7, (k, d, s)
+    bad = [k for k in path if not torch.equal(grads[0][k], grads[1][k])]
+    assert not bad, (len(bad), bad[:6], [float((grads[0][k] - grads[1][k]).abs().max()) for k in bad[:6]])
+    assert len(feat[0]) >= 2
+    for k in feat[0]:
+        _feat_close(feat[1][k], feat[0][k])

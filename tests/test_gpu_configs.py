@@ -280,3 +280,31 @@ def test_use_vis_model_mirror(weights_np, golden):
         vol = net.sample_volume(info).cpu().numpy()
     close(vol, G['volume'], 'use_vis volume through the model mirror')
     assert net._use_autograd(True)                         # trains too: tests/test_train_step.py fixture 'vis'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg_name,extra', [('cfg1', {}), ('cfg2', {}), ('cfg1', {'fine_depth_use_all': True}), ('cfg1', {'ray_batch_num': 24})])
+def test_ray_traversal_order_is_invisible(cfg_name, extra, weights_np):
+    """gnr_debug_ray_order(1): the inference render passes lay their internal per-point arrays out in the Morton order of the rays'
+    pixels (k_ray_order) and write every output through the permutation -- all outputs, both levels, the resampling indices and the
+    per-chunk eikonal terms equal bit for bit to the caller-order run."""
+    from graspnerf_amd import _lib
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    L = _lib.lib()
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    bref, bque = batch_scenes([make_scene(s, cfg_name) for s in (0, 1, 2)])
+    n = 16 if cfg_name == 'cfg1' else 40
+    cfg = dict({'depth_sample_num': n, 'fine_depth_sample_num': n}, **extra)
+    outs = []
+    prev = L.gnr_debug_ray_order(0)
+    try:
+        for on in (0, 1):
+            L.gnr_debug_ray_order(on)
+            outs.append(hp.render(bref, bque, cfg, debug=True))
+    finally:
+        L.gnr_debug_ray_order(prev)
+    torch.cuda.synchronize()
+    for lvl in (0, 1):
+        for k in outs[0][lvl]:
+            assert torch.equal(outs[0][lvl][k], outs[1][lvl][k]), (lvl, k)
+    assert torch.equal(outs[0][2], outs[1][2])
