@@ -15,3 +15,10 @@ hipcc $FLAGS -DGNR_SPLIT16=0 -o libgnr_f32mfma.so $SRC "$@" &
 P2=$!
 wait $P1
 wait $P2
+# libgnr_torch.so: torch.ops.graspnerf.* (gnr_torch_ops.cpp: TORCH_LIBRARY registration of the C ABI; host C++ only, links libgnr.so)
+TORCH_DIR=$(python -c 'import os, torch; print(os.path.dirname(torch.__file__))')
+ABI=$(python -c 'import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))')
+g++ -O2 -std=c++17 -shared -fPIC -D__HIP_PLATFORM_AMD__=1 -DUSE_ROCM=1 -D_GLIBCXX_USE_CXX11_ABI=$ABI -Wno-deprecated-declarations \
+    -I$TORCH_DIR/include -I$TORCH_DIR/include/torch/csrc/api/include -I/opt/rocm/include \
+    gnr_torch_ops.cpp -o libgnr_torch.so -L$TORCH_DIR/lib -ltorch -ltorch_cpu -lc10 -lc10_hip -ltorch_hip -L. -lgnr \
+    -Wl,-rpath,'$ORIGIN' -Wl,-rpath,$TORCH_DIR/lib
