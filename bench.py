@@ -228,7 +228,10 @@ def cpu_baseline(weights_np):
     same scene at os.cpu_count() threads in a child process under a 90 s cap (`all_cores`: measured in this run, or reported as
     capped -- on the GPU box's 256-thread host torch's intra-op pool collapses from oversubscription on these op sizes)."""
     from oracle import graspnerf_oracle as O
-    cores = min(os.cpu_count() or 1, 16)
+    from graspnerf_amd.hostenv import cpu_budget
+    budget = cpu_budget()                                  # CPUs the container may use (cgroup quota / affinity), not the 256 it sees
+    cores = min(budget, 16)
+    prev_threads = torch.get_num_threads()
     W = {k: torch.from_numpy(v) for k, v in weights_np.items()}
     ref, que = make_scene(0, 'cfg2')
     inp, q = O.to_torch(ref), O.to_torch(que)
@@ -245,9 +248,12 @@ def cpu_baseline(weights_np):
     med = 0.5 * (ts[4] + ts[5])
     torch.set_num_threads(1)
     t1 = one()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(prev_threads)
     return {'value': round(1.0 / med, 4), 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
             'value_1_thread': round(1.0 / t1, 4),
+            'host': {'cpus_visible': os.cpu_count(), 'cpu_budget': budget,
+                     'note': 'the container sees every hardware thread of the node but its cgroup grants cpu_budget of them: the `cores` '
+                             'figure runs inside the budget, all_cores (os.cpu_count() threads, SURVEY 8d) oversubscribes it and is throttled'},
             'all_cores': cpu_baseline_all_cores() if (os.cpu_count() or 1) > cores else {'cores': cores, 'same_as': 'value'},
             'sample': f'whole scenes (6 views 288x512, 40^3 volume + 512 rays x (40+40) samples), oracle/graspnerf_oracle.py (torch '
                       f'{torch.__version__} CPU fp32): 3 warm-ups + median of 10 at {cores} threads ({med:.3f} s, min {ts[0]:.3f}, max '
@@ -341,6 +347,11 @@ def train_leg(args, world, rank, dev, dist, sync):
     for _ in range(args.train_warmup):
         log = tr.step(scenes)
     sync()
+    # the model, the optimizer state and the autograd Function classes are long-lived: move them out of the cyclic collector's
+    # young generations (a generation-1 / -2 pass over them cost one step in ~25 its 6-7 ms: tools/dbg/train_step_series.py)
+    import gc
+    gc.collect()
+    gc.freeze()
     dom = 'k_view1_bwd@gnr_sample_volume_bwd'          # dominant backward kernel of the path: first view loop, volume points
     if rank == 0:
         _lib.timing_begin(only=dom)                    # the timed steps bracket this kernel only
@@ -513,6 +524,11 @@ def main():
     ap.add_argument('--stub-step-ms', type=float, default=0.0, help='> 0: no GPU, a step is a sleep of this length (control-flow test of the N > 1 branches)')
     ap.add_argument('--stub-parity-fail', action='store_true', help='with --stub-step-ms: rank 0 fails its parity gate (every rank must exit 3)')
     args = ap.parse_args()
+    # host threads: the node shows 256 hardware threads, the container's cgroup grants 16 of them; torch's default 128-thread pool
+    # exhausts that quota on one small CPU op and the kernel throttles the whole process for the rest of the 100 ms period
+    # (graspnerf_amd/hostenv.py): every rank takes its share
+    from graspnerf_amd.hostenv import limit_host_threads, cpu_budget
+    host_threads = limit_host_threads(int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))
     stub = args.stub_step_ms > 0
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -652,6 +668,7 @@ def main():
                           'fp16 range make the launch fall back to the fp32-input MFMA (range_flags); f32_mfma_build is the same step with '
                           'every product on fp32 instructions',
             'parity_checked': parity is not None, 'parity': parity, 'range_flags': range_flags,
+            'host_threads': {'torch_intra_op': host_threads, 'cpu_budget': cpu_budget(), 'cpus_visible': os.cpu_count()},
             'config': {'workload': f'{B} scenes/GPU/step, 6 views 288x512 (feature maps 72x128x32 x2), 40^3 TSDF volume + '
                                    f'512 rays x (40 coarse + 40 fine) samples incl. pixel_colors_gt, forward only, eval-mode resampling, '
                                    f'inputs resident in HBM (BASELINE.json configs[2]; configs[3] = the same on 8 GPUs)',
