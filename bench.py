@@ -680,6 +680,9 @@ def main():
             # What binds it is VALU issue (`valu`): 12 vector instructions per MFMA (activations, operand splitting, queue moves).
             'roofline': {'bound': 'mfma', 'binding_resource': 'valu_issue', 'achieved': round(achieved, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic,
+                         # the same launch priced by its ALGORITHMIC work: un-hoisted SURVEY 8d fp32 FLOPs (one per MAC, not the three
+                         # f16 partial products the kernel executes per MAC) over the same time and the same dense f16 peak
+                         'frac_algorithmic': round(fl_alg / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                          'kernel': 'k_chain<6,false> on the volume points', 'ms_per_launch': round(ms, 4),
                          'launches_timed': n_vol, 'ms_per_launch_standalone': round(ms_alone, 4),
                          'flops_per_launch': fl_exe,

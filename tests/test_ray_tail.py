@@ -86,17 +86,18 @@ def test_dual_core_kernel_matches_tensor_algebra(R, dn, level, weights_np):
     assert _rel(hb, tb) < 5e-4 and _rel(hdb, tdb) < 5e-4
     # the parameter gradients are sums over all R * dn samples.  The kernel carries the cancellation-prone scalar sums
     # (beff = sum of d sdf; lnw, lnb, weff follow from sum of d sdf * LayerNorm output) in double from the lane on, and the four
-    # matrices through fp32 MFMA partials that a fixed-order reduction adds in double: every entry within 1e-3 of the largest entry
-    # of the float64 evaluation -- also where 6 700 O(1) terms cancel to 9e-3 (case 70-128-fine: beff)
+    # matrices through fp32 MFMA partials that a fixed-order reduction adds in double: every entry within 2e-5 of the largest entry
+    # of the float64 evaluation (measured: <= 7e-7, profiles/r04_*_parity_errors.json) -- also where 6 700 O(1) terms cancel to
+    # 9e-3 (case 70-128-fine, beff: 4e-8 of the result; the atomics of round 3 left it at 1.7e-3)
     W64 = rt.tail_weights({k: v.double() for k, v in P.items()}, agg)
     _, _, G64 = rt.attn_core(W64, gg.double(), gd.double(), a.double(), nvalid.double())
     from conftest import PARITY_LOG
     for k in G:
         scale = float(G64[k].abs().max())
         e_hip, e_t32 = float((H[k].double() - G64[k]).abs().max()), float((G[k].double() - G64[k]).abs().max())
-        PARITY_LOG.append({'what': f'k_ray_dual_bwd d {k} vs float64 [{R}x{dn} {level}]', 'max_abs': e_hip, 'tol': 1e-3 * scale,
-                           'max_over_tol': e_hip / (1e-3 * scale), 'torch_fp32_abs': e_t32})
-        assert e_hip <= 1e-3 * scale, (k, e_hip, e_t32, scale)
+        PARITY_LOG.append({'what': f'k_ray_dual_bwd d {k} vs float64 [{R}x{dn} {level}]', 'max_abs': e_hip, 'tol': 2e-5 * scale,
+                           'max_over_tol': e_hip / (2e-5 * scale), 'torch_fp32_abs': e_t32})
+        assert e_hip <= 2e-5 * scale, (k, e_hip, e_t32, scale)
 
 
 @pytest.mark.gpu
