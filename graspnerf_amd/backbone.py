@@ -335,9 +335,12 @@ class _Decoder(nn.Module):
         self.conv1, self.conv2, self.conv3 = _c3d(64, 64, 3), _c3d(64, 32, 3), _c3d(32, 16, 5)
 
     def forward(self, x):
-        x = F.interpolate(F.relu(self.conv1(x)), 10)        # nearest, fixed sizes 10/20/40 (networks.py:88-96)
-        x = F.interpolate(F.relu(self.conv2(x)), 20)
-        return F.interpolate(F.relu(conv3d_same(x, self.conv3.weight, self.conv3.bias)), 40)      # k5 at 20^3: HIP under autograd
+        # nearest upsampling to the fixed sizes 10 / 20 / 40 (networks.py:88-96).  All three stride-1 convolutions run on the HIP path
+        # under autograd (conv3d_same): k5 at 20^3 since round 2 (MIOpen: im2col + GEMM), the two k3 layers at 5^3 / 10^3 since round 4
+        # (MIOpen spends 0.3 ms per step of 8 scenes on their im2col / col2im launches; tools/dbg/head_k3_route.py: 4.69 -> 4.38 ms)
+        x = F.interpolate(F.relu(conv3d_same(x, self.conv1.weight, self.conv1.bias)), 10)
+        x = F.interpolate(F.relu(conv3d_same(x, self.conv2.weight, self.conv2.bias)), 20)
+        return F.interpolate(F.relu(conv3d_same(x, self.conv3.weight, self.conv3.bias)), 40)
 
 
 _CONV_WS = {}
