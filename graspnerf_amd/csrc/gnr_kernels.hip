@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_repack_feats(const float* __restrict__ 
 __global__ void k_view_setup(const float* __restrict__ poses, const float* __restrict__ Ks,
                              const float* __restrict__ dr, float* __restrict__ viewp, int nviews, unsigned* __restrict__ range_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && range_flag) *range_flag = 0u;            // gnr_prepare launches this kernel first: a new watch word per prepare
+    if (i < 64 && range_flag) range_flag[i] = 0u;          // gnr_prepare launches this kernel first: new watch words per prepare (word 0 + one per launch slot)
     if (i >= nviews) return;
     const float* P = poses + i * 12;
     const float* K = Ks + i * 9;
@@ -585,6 +585,8 @@ struct ChainArgs {
     // launch with only_if_flagged != 0 (the fp32-MFMA twin behind every pair launch) returns at once while the word is zero
     unsigned* range_flag;
     int only_if_flagged;
+    unsigned* range_launch;       // this launch's own watch word (bit 1: an activation / statistic of THIS launch left the fp16-pair range); word 0
+                                  // (range_flag) keeps the bits that concern every launch of the prepared scene: 0 = a feature, 2 = a weight
     // inference render passes: the points are laid out in the Morton order of their rays (k_ray_order); the user-visible
     // per-point outputs (colours, view masks) go to the caller's ray order: point (slot s, sample k) -> ray_perm[b][s] * dn + k
     const int* ray_perm; int perm_rn, perm_dn;
@@ -729,13 +731,20 @@ template <int V, bool RENDER, bool SAVE = false, bool USEVIS = false, bool SP = 
 __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
-    if (a.only_if_flagged && (a.range_flag == nullptr || __builtin_nontemporal_load(a.range_flag) == 0u)) return;   // wave-uniform
+    if (a.only_if_flagged) {                                // the fp32 twin: runs only when the scene's or this launch's watch word is set
+        const unsigned w0 = a.range_flag ? __builtin_nontemporal_load(a.range_flag) : 0u;
+        const unsigned w1 = a.range_launch ? __builtin_nontemporal_load(a.range_launch) : 0u;
+        if ((w0 | w1) == 0u) return;                        // wave-uniform
+    }
     if constexpr (SP && GNR_RANGE_GUARD != 0) {
         // a weight without an fp16 pair (gnr_pack.cpp build_c16): bit 2, and the whole launch is the fp32 twin's
         if (a.range_flag && a.wpk[pk::T_VIS + 2] != 0.f) {
             if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 4u);
             return;
         }
+        // a feature beyond the pair range (bit 0, k_repack_feats) or a weight flagged by an earlier launch: the twin recomputes the
+        // whole launch anyway, the pair kernel's work would be wasted (and would run on inf / NaN operands)
+        if (a.range_flag && (__builtin_nontemporal_load(a.range_flag) & 5u) != 0u) return;
     }
     bool range_tripped = false;                           // wave-uniform
     constexpr bool UA = SP && GNR_UNSCALED_ACT != 0;       // inner layers on unscaled activation pairs (split8u / mm16u)
@@ -1266,7 +1275,10 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         }
     }
     if constexpr (SP) {      // range guard
-        if (a.range_flag && range_tripped && lane == 0) atomicOr(a.range_flag, 2u);
+        if (range_tripped && lane == 0) {
+            if (a.range_launch) atomicOr(a.range_launch, 2u);
+            else if (a.range_flag) atomicOr(a.range_flag, 2u);
+        }
     }
 }
 

@@ -136,6 +136,9 @@ int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, 
  * gnr_range_status reads the watch word of the last gnr_prepare on this workspace (synchronises `stream`):
  *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range;
  *   bit 2: a weight beyond the fp16 range (gnr_pack_weights marks such a blob instead of refusing it).
+ * Bits 0 and 2 hold for every launch on the prepared scene (the pair kernel then returns at once and the twin computes the launch);
+ * bit 1 is watched per launch slot (volume, coarse pass, fine pass, the training forwards), so a scene whose coarse pass tripped it
+ * does not pay the recomputation on its volume or fine pass; the status word is the OR over the slots.
  * gnr_force_fp32_chain(1) makes every chain launch run the fp32-MFMA kernel (tests, measurements); returns the old setting. */
 int gnr_range_status(const GnrScene* scene, const void* workspace, size_t workspace_bytes, unsigned* flags_out, void* stream);
 int gnr_force_fp32_chain(int on);
