@@ -326,7 +326,12 @@ class _Encoder(nn.Module):
         self.conv1, self.conv2, self.conv3 = _c3d(1, 16, 5, 2), _c3d(16, 32, 3, 2), _c3d(32, 64, 3, 2)
 
     def forward(self, x):
-        return F.relu(self.conv3(F.relu(self.conv2(F.relu(self.conv1(x))))))
+        for conv in (self.conv1, self.conv2, self.conv3):
+            if _s2d_route(x, conv.weight):
+                x = F.relu(conv3d_stride2(x, conv.weight, conv.bias))
+            else:
+                x = F.relu(conv(x))
+        return x
 
 
 class _Decoder(nn.Module):
@@ -334,21 +339,119 @@ class _Decoder(nn.Module):
         super().__init__()
         self.conv1, self.conv2, self.conv3 = _c3d(64, 64, 3), _c3d(64, 32, 3), _c3d(32, 16, 5)
 
-    def forward(self, x):
+    def forward(self, x, upsample_last=True):
         # nearest upsampling to the fixed sizes 10 / 20 / 40 (networks.py:88-96).  All three stride-1 convolutions run on the HIP path
         # under autograd (conv3d_same): k5 at 20^3 since round 2 (MIOpen: im2col + GEMM), the two k3 layers at 5^3 / 10^3 since round 4
         # (MIOpen spends 0.3 ms per step of 8 scenes on their im2col / col2im launches; tools/dbg/head_k3_route.py: 4.69 -> 4.38 ms)
         x = F.interpolate(F.relu(conv3d_same(x, self.conv1.weight, self.conv1.bias)), 10)
-        x = F.interpolate(F.relu(conv3d_same(x, self.conv2.weight, self.conv2.bias)), 20)
-        return F.interpolate(F.relu(conv3d_same(x, self.conv3.weight, self.conv3.bias)), 40)
+        x = F.relu(conv3d_same(x, self.conv2.weight, self.conv2.bias))
+        if _fold_route(x, self.conv3.weight) and tuple(x.shape[2:]) == (10, 10, 10):
+            x = F.relu(upconv5_x2(x, self.conv3.weight, self.conv3.bias))          # = conv3(F.interpolate(x, 20)), the 20^3 x 32 tensor never built
+        else:
+            x = F.relu(conv3d_same(F.interpolate(x, 20), self.conv3.weight, self.conv3.bias))
+        return F.interpolate(x, 40) if upsample_last else x
+
+
+FOLD_UPSAMPLED_K5 = True            # tests switch it off to get the plain statement of the same layers
+
+
+def _fold_route(x, w):
+    """The folded form is taken where conv3d_same would run its HIP kernels (GPU, fp32, under autograd)."""
+    return (FOLD_UPSAMPLED_K5 and x.is_cuda and x.dtype == torch.float32 and w.shape[-1] == 5 and torch.is_grad_enabled()
+            and (x.requires_grad or w.requires_grad))
+
+
+STRIDE2_AS_S2D = True               # the same for the encoder's stride-2 layers
+
+
+def _s2d_route(x, w):
+    return (STRIDE2_AS_S2D and x.is_cuda and x.dtype == torch.float32 and w.shape[-1] in (3, 5) and torch.is_grad_enabled()
+            and (x.requires_grad or w.requires_grad) and all(d % 2 == 0 for d in x.shape[2:]))
+
+
+_FOLD_MATS = {}
+
+
+def _stride2_matrix(k, device):
+    """0/1 matrix [k^3, 8 * 27].  A stride-2 convolution (padding k // 2, even input size) reads x[2 o + d], d = t - k // 2, for output o:
+    with d = 2 s + r (r = parity, s = d // 2 in {-1, 0, 1}) that is X_r[o + s] on the parity sub-grid X_r[m] = x[2 m + r] -- a k = 3
+    same-padding stride-1 convolution over the 8 Cin channels of the space-to-depth input, every k^3 tap landing in exactly one
+    (parity, offset) slot (the other slots stay zero).  Row k-tap, column (parity, k3 tap)."""
+    key = (k, str(device))
+    if key not in _FOLD_MATS:
+        ax = torch.zeros(k, 2, 3)
+        for t in range(k):
+            d = t - k // 2
+            ax[t, d % 2, d // 2 + 1] = 1
+        _FOLD_MATS[key] = torch.einsum('aip,bjq,ckr->abcijkpqr', ax, ax, ax).reshape(k ** 3, 216).to(device)
+    return _FOLD_MATS[key]
+
+
+def conv3d_stride2(x, w, b):
+    """F.conv3d(x, w, b, stride=2, padding=k // 2) (k = 3 or 5, even sizes: the encoder of gd/networks.py:59-76) as a space-to-depth
+    shuffle and ONE stride-1 k = 3 convolution on the HIP path in all three directions (MIOpen runs these three small layers as
+    im2col / col2im + GEMM and a naive fallback kernel: 1.4 ms per training step of 8 volumes for 3 % of the head's MACs)."""
+    co, ci, k = w.shape[0], w.shape[1], w.shape[-1]
+    B, _, D, H, W = x.shape
+    xs = x.view(B, ci, D // 2, 2, H // 2, 2, W // 2, 2).permute(0, 3, 5, 7, 1, 2, 4, 6).reshape(B, 8 * ci, D // 2, H // 2, W // 2)
+    wf = (w.reshape(co * ci, k ** 3) @ _stride2_matrix(k, w.device)).reshape(co, ci, 8, 27).permute(0, 2, 1, 3).reshape(co, 8 * ci, 3, 3, 3)
+    return conv3d_same(xs, wf, b, _stride2_tap_mask(k, ci, co, w.device) if x.is_cuda else None)
+
+
+_TAP_MASKS = {}
+
+
+def _stride2_tap_mask(k, ci, co, device):
+    """Tap mask (include/gnr.h gnr_conv3d_tap_mask) of conv3d_stride2's k3 weights [co, 8 ci, 27]: of the 8 x 27 (parity, tap) slots per
+    input channel the 27 (k = 3) or 125 (k = 5) that a weight lands in.  Built once per layer shape from the 0/1 matrix itself (the
+    structure, not the weights' values); the HIP kernels skip the other taps of every 16 x 16 channel block in all three directions."""
+    key = (k, ci, co, str(device))
+    if key not in _TAP_MASKS:
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        pat = (_stride2_matrix(k, device).sum(0) > 0).float().reshape(1, 1, 8, 27).expand(co, ci, 8, 27).permute(0, 2, 1, 3).reshape(co, 8 * ci, 27).contiguous()
+        mask = torch.zeros(L.gnr_conv3d_tap_mask_words(8 * ci, co), dtype=torch.int32, device=device)
+        _lib.check(L.gnr_conv3d_tap_mask(pat.data_ptr(), mask.data_ptr(), 8 * ci, co, 3, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                   'gnr_conv3d_tap_mask')
+        _TAP_MASKS[key] = mask
+    return _TAP_MASKS[key]
+
+
+def _upfold_matrix(device):
+    """0/1 matrix [125, 8 * 27].  A k = 5 same-padding convolution on a x2 nearest-upsampled grid x[j] = u[j // 2] reads, for the output
+    voxel 2 s + c (c = parity per axis), tap t at j = 2 s + c + t - 2, i.e. source voxel s + (c + t - 2) // 2: offsets -1, 0, +1 -- per
+    parity class a k = 3 same-padding convolution on the SOURCE grid whose weights are sums of the k = 5 weights (the zero padding of the
+    upsampled grid is the zero padding of the source grid).  Column (class, k3 tap), row k5 tap."""
+    key = ('up', str(device))
+    if key not in _FOLD_MATS:
+        ax = torch.zeros(5, 2, 3)
+        for c in range(2):
+            for t in range(5):
+                ax[t, c, (c + t - 2) // 2 + 1] = 1
+        _FOLD_MATS[key] = torch.einsum('aip,bjq,ckr->abcijkpqr', ax, ax, ax).reshape(125, 216).to(device)
+    return _FOLD_MATS[key]
+
+
+def upconv5_x2(u, w, b):
+    """F.conv3d(F.interpolate(u, scale 2, nearest), w, b, padding=2) for a k = 5 kernel without the upsampled tensor (networks.py:91-96
+    followed by a k5 convolution: decoder.conv3 and the three heads, 92 % of the head's MACs): ONE k = 3 convolution on the source grid
+    with 8 x Cout output channels (one group per output parity class, weights pre-summed by a constant 0/1 matrix, so autograd returns
+    the k = 5 weight gradient through the same matrix) and a depth-to-space shuffle.  125 / 27 = 4.6x fewer MACs in all three directions,
+    no Cout padding for the 6-channel heads (48 = 3 MFMA row blocks), and neither the upsampled activation nor its gradient exist."""
+    co, ci = w.shape[:2]
+    B, _, D, H, W = u.shape
+    wf = (w.reshape(co * ci, 125) @ _upfold_matrix(w.device)).reshape(co, ci, 8, 27).permute(2, 0, 1, 3).reshape(8 * co, ci, 3, 3, 3)
+    y8 = conv3d_same(u, wf, b.repeat(8))
+    return y8.view(B, 2, 2, 2, co, D, H, W).permute(0, 4, 5, 1, 6, 2, 7, 3).reshape(B, co, 2 * D, 2 * H, 2 * W)
 
 
 _CONV_WS = {}
 
 
-def _hip_conv3d_same(x, w, b, mode):
-    """gnr_conv3d_same through the C ABI: mode 0 forward (x [B,Cin,D,H,W] -> y [B,Cout,..] + b), mode 1 backward data
-    (x = dy [B,Cout,..] -> dx [B,Cin,..])."""
+def _hip_conv3d_same(x, w, b, mode, mask=None):
+    """gnr_conv3d_same(_masked) through the C ABI: mode 0 forward (x [B,Cin,D,H,W] -> y [B,Cout,..] + b), mode 1 backward data
+    (x = dy [B,Cout,..] -> dx [B,Cin,..]); mask = the layer's tap mask (_tap_mask) or None."""
     import ctypes as C
     from . import _lib
     L = _lib.lib()
@@ -361,8 +464,9 @@ def _hip_conv3d_same(x, w, b, mode):
         _CONV_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
     ws = _CONV_WS[key]
     y = torch.empty(B, cin if mode else cout, D, H, W, dtype=torch.float32, device=x.device)
-    rc = L.gnr_conv3d_same(x.data_ptr(), w.data_ptr(), b.contiguous().data_ptr() if (b is not None and not mode) else None, y.data_ptr(),
-                           B, cin, cout, D, H, W, k, mode, ws.data_ptr(), ws.numel(), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    rc = L.gnr_conv3d_same_masked(x.data_ptr(), w.data_ptr(), b.contiguous().data_ptr() if (b is not None and not mode) else None, y.data_ptr(),
+                                  B, cin, cout, D, H, W, k, mode, mask.data_ptr() if mask is not None else None, ws.data_ptr(), ws.numel(),
+                                  C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc:
         raise _lib.GnrError(f'gnr_conv3d_same failed: {_lib.ERRORS.get(rc, rc)} ({L.gnr_head_last_error().decode(errors="replace")})')
     return y
@@ -376,9 +480,10 @@ class _Conv3dSame(torch.autograd.Function):
     8 scenes for forward + backward-data, and 75 ms for the weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, mask=None):
         ctx.save_for_backward(x, w)
-        return _hip_conv3d_same(x, w, b, 0)
+        ctx.mask = mask
+        return _hip_conv3d_same(x, w, b, 0, mask)
 
     @staticmethod
     def backward(ctx, dy):
@@ -387,7 +492,8 @@ class _Conv3dSame(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         k = w.shape[-1]
-        dx = _hip_conv3d_same(dy, w, None, 1) if ctx.needs_input_grad[0] else None
+        mask = ctx.mask
+        dx = _hip_conv3d_same(dy, w, None, 1, mask) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
@@ -398,18 +504,19 @@ class _Conv3dSame(torch.autograd.Function):
             key = (x.device, 'wgrad', need)
             if key not in _CONV_WS:
                 _CONV_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
-            rc = L.gnr_conv3d_same_bwd_weight(xc.data_ptr(), dy.data_ptr(), dw.data_ptr(), *dims, _CONV_WS[key].data_ptr(), need,
-                                              C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            rc = L.gnr_conv3d_same_bwd_weight_masked(xc.data_ptr(), dy.data_ptr(), dw.data_ptr(), *dims, mask.data_ptr() if mask is not None else None,
+                                                     _CONV_WS[key].data_ptr(), need, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             if rc:
                 raise _lib.GnrError(f'gnr_conv3d_same_bwd_weight failed: {rc}')
         db = dy.sum((0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def conv3d_same(x, w, b):
-    """Stride-1 same-padding conv3d; on the GPU under autograd all three directions run in HIP (_Conv3dSame)."""
+def conv3d_same(x, w, b, mask=None):
+    """Stride-1 same-padding conv3d; on the GPU under autograd all three directions run in HIP (_Conv3dSame).  mask: the tap mask of a
+    structurally sparse weight tensor (_tap_mask), None = dense."""
     if x.is_cuda and x.dtype == torch.float32 and w.shape[-1] in (3, 5) and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-        return _Conv3dSame.apply(x, w, b)
+        return _Conv3dSame.apply(x, w, b, mask)
     return F.conv3d(x, w, b, padding=w.shape[-1] // 2)
 
 
@@ -420,10 +527,13 @@ class ConvNet(nn.Module):
         self.conv_qual, self.conv_rot, self.conv_width = _c3d(16, 1, 5), _c3d(16, 4, 5), _c3d(16, 1, 5)
 
     def forward(self, x):
-        f = self.decoder(self.encoder(x))
         # the three heads read the same 16-channel volume: one 16 -> 6 convolution (identical per output channel) so that
         # autograd runs ONE conv3d backward instead of three (MIOpen: 9.4 ms each at 40^3)
         w = torch.cat([self.conv_qual.weight, self.conv_rot.weight, self.conv_width.weight], 0)
         b = torch.cat([self.conv_qual.bias, self.conv_rot.bias, self.conv_width.bias], 0)
-        y = conv3d_same(f, w, b)
+        e = self.encoder(x)
+        if _fold_route(e, w):
+            y = upconv5_x2(self.decoder(e, upsample_last=False), w, b)      # the heads on the 20^3 decoder output, upsampling folded in
+        else:
+            y = conv3d_same(self.decoder(e), w, b)
         return torch.sigmoid(y[:, :1]), F.normalize(y[:, 1:5], dim=1), y[:, 5:6]

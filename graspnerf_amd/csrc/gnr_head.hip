@@ -607,7 +607,27 @@ struct Conv1Args {
     const float* bias;     // [cout] or null
     float* out;            // [B][cout][D][H][W]
     int B, cin, cout, D, H, W, nchunks, nbt;
+    const unsigned* mask;  // tap mask [forward Cin block][forward Cout block][4 words] (k_conv3d_tap_mask) or null = dense
+    int mode;              // 0: chunks = forward Cin blocks, nb = forward Cout block;  1 (backward data): the other way round, taps flipped
 };
+
+// Which taps of a (16 input channels, 16 output channels) block hold a structural non-zero: bit `tap` of mask[bi][bo][tap / 32].  The
+// pattern is a [Cout][Cin][K^3] tensor of the layer's shape whose non-zeros mark the weights that exist (a stride-2 layer run as a
+// stride-1 k3 convolution over its space-to-depth input has 27 of its 8 x 27 (parity, tap) slots per input channel; backbone.conv3d_stride2).
+__global__ void k_conv3d_tap_mask(const float* __restrict__ pattern, unsigned* __restrict__ mask, int Cin, int Cout, int K3, int nbo) {
+    const int bi = blockIdx.x / nbo, bo = blockIdx.x - bi * nbo, lane = threadIdx.x;
+    unsigned words[4] = {0u, 0u, 0u, 0u};
+    for (int tap = 0; tap < K3; ++tap) {
+        bool nz = false;
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane * 4 + q, o = 16 * bo + (e >> 4), i = 16 * bi + (e & 15);
+            if (o < Cout && i < Cin) nz = nz || pattern[((size_t)o * Cin + i) * K3 + tap] != 0.f;
+        }
+        if (__ballot(nz)) words[tap >> 5] |= 1u << (tap & 31);
+    }
+    if (lane == 0)
+        for (int q = 0; q < 4; ++q) mask[(size_t)blockIdx.x * 4 + q] = words[q];
+}
 
 template <int KS>
 __global__ __launch_bounds__(256, 2) void k_conv3d_s1(Conv1Args a) {
@@ -641,16 +661,34 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_s1(Conv1Args a) {
     const int lx = ox - bx8, ly = (oy - by8) * HX;
     const float* hg = halo + g * HALO;                    // lane group g = input channel 4c + g of the chunk
     for (int ch = 0; ch < a.nchunks; ++ch) {
+        unsigned mw[4] = {~0u, ~0u, ~0u, ~0u};
+        if (a.mask) {                                     // wave-uniform: scalar loads
+            const unsigned* mp = a.mask + (size_t)(a.mode ? nb * a.nchunks + ch : ch * a.nbt + nb) * 4;
+            mw[0] = mp[0]; mw[1] = mp[1]; mw[2] = mp[2]; mw[3] = mp[3];
+            if (!(mw[0] | mw[1] | mw[2] | mw[3])) continue;   // no weight joins this chunk to this output block
+        }
+        auto tap_on = [&](int tap) { const int t = a.mode ? TAPS - 1 - tap : tap; return (mw[t >> 5] >> (t & 31)) & 1u; };
         __syncthreads();                                  // everybody is done with the previous chunk's halo
         const float* in = a.in + ((size_t)b * a.cin + 16 * ch) * V3;
-        for (int i = threadIdx.x; i < 16 * HALO; i += 256) {
-            const int c = i / HALO, rem = i - c * HALO;
-            const int z = bz4 - PAD + rem / (HX * HY), y = by8 - PAD + (rem / HX) % HY, x = bx8 - PAD + rem % HX;
-            const bool ok = 16 * ch + c < a.cin && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            halo[i] = ok ? in[(size_t)c * V3 + ((size_t)z * a.H + y) * a.W + x] : 0.f;
+        for (int i0 = threadIdx.x; i0 < 16 * HALO; i0 += 256 * 8) {     // eight loads in flight per lane, then the LDS stores
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u, c = i / HALO, rem = i - c * HALO;
+                const int z = bz4 - PAD + rem / (HX * HY), y = by8 - PAD + (rem / HX) % HY, x = bx8 - PAD + rem % HX;
+                const bool ok = i < 16 * HALO && 16 * ch + c < a.cin && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                v[u] = ok ? in[(size_t)c * V3 + ((size_t)z * a.H + y) * a.W + x] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 256 * u < 16 * HALO) halo[i0 + 256 * u] = v[u];
         }
         const float* fr = a.frag + ((size_t)ch * TAPS * 4 * a.nbt + nb) * 64;      // + ((tap * 4 + c) * nbt) * 64 + lane
         for (int row = 0; row < KS * KS; ++row) {         // (tz, ty) row of KS x-taps
+            unsigned rowbits = 0;
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) rowbits |= tap_on(row * KS + tx) << tx;
+            if (!rowbits) continue;                       // structurally empty row (uniform over the workgroup)
             __syncthreads();                              // previous slice consumed / halo written
             for (int i = threadIdx.x; i < TS * AFL; i += 256) {
                 const int ln = i & 63, c = (i >> 6) & 3, tp = i >> 8;
@@ -661,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_s1(Conv1Args a) {
             const int base = (tz * HY + ty) * HX + ly + lx;
 #pragma unroll
             for (int tx = 0; tx < KS; ++tx) {
+                if (!((rowbits >> tx) & 1u)) continue;
                 const f4 av = *reinterpret_cast<const f4*>(asl + (tx * 64 + lane) * 4);
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
@@ -689,6 +728,119 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_s1(Conv1Args a) {
     }
 }
 
+
+// K = 3 form of k_conv3d_s1 for the small grids of the head under training (5^3 .. 20^3, where every layer is a k3 convolution since
+// the x2 upsamplings and the stride-2 layers were folded into k3 weights): a chunk's WHOLE weight slice (27 taps x 16 x 16) goes to
+// LDS with its halo, so a chunk costs two barriers instead of 2 x 9, and the next chunk's halo + weights are requested into registers
+// (38 + 27 loads per lane, all in flight) before the current chunk's MFMAs -- the first form spent its time on 7+ dependent global-load
+// phases per chunk (enc.conv3, 16 chunks on 64 workgroups: 230 us for 55 MMAC).  Same tiling, same fragment layout, same mask semantics.
+__global__ __launch_bounds__(256, 2) void k_conv3d_s1_k3(Conv1Args a) {
+    constexpr int KS = 3, PAD = 1, TAPS = 27;
+    constexpr int HX = 10, HY = 10, HZ = 6, HALO = HX * HY * HZ;
+    constexpr int NH = (16 * HALO + 255) / 256;           // halo floats per lane (38)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                                   // [16][HALO]
+    float* asl = smem + 16 * HALO;                        // [27 taps][64 lanes][4 c]
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int nbx = (a.W + 7) >> 3, nby = (a.H + 7) >> 3, nbz = (a.D + 3) >> 2;
+    const int blk = blockIdx.x;
+    const int b = blk / (nbx * nby * nbz), br = blk - b * nbx * nby * nbz;
+    const int bz4 = (br / (nbx * nby)) * 4, by8 = ((br / nbx) % nby) * 8, bx8 = (br % nbx) * 8;
+    const int ox = bx8 + (wave & 1) * 4 + (r & 3), oy = by8 + (wave >> 1) * 4 + (r >> 2);
+    const int nb = blockIdx.y;
+    const size_t V3 = (size_t)a.D * a.H * a.W;
+    f4 acc[4];
+    {
+        f4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const int o = 16 * nb + 4 * g;
+            b4.x = o < a.cout ? a.bias[o] : 0.f; b4.y = o + 1 < a.cout ? a.bias[o + 1] : 0.f;
+            b4.z = o + 2 < a.cout ? a.bias[o + 2] : 0.f; b4.w = o + 3 < a.cout ? a.bias[o + 3] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = b4;
+    }
+    // per-lane halo cell of each of this lane's NH staging slots (the same for every chunk): global offset or -1
+    unsigned hoff[NH];                                    // BYTE offset from the chunk's first channel (wave-uniform base + 32-bit lane offset)
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+        const int i = threadIdx.x + 256 * u, c = i / HALO, rem = i - c * HALO;
+        const int z = bz4 - PAD + rem / (HX * HY), y = by8 - PAD + (rem / HX) % HY, x = bx8 - PAD + rem % HX;
+        const bool ok = i < 16 * HALO && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        hoff[u] = ok ? (unsigned)((c * V3 + ((size_t)z * a.H + y) * a.W + x) * sizeof(float)) : 0xffffffffu;   // all ones: zero border
+    }
+    auto chunk_mask = [&](int ch) -> unsigned {           // 27 bits, in THIS launch's tap order (backward data: flipped)
+        if (!a.mask) return (1u << TAPS) - 1u;
+        const unsigned m = a.mask[(size_t)(a.mode ? nb * a.nchunks + ch : ch * a.nbt + nb) * 4];
+        return a.mode ? __builtin_bitreverse32(m) >> (32 - TAPS) : m;
+    };
+    auto next_chunk = [&](int ch) { while (ch < a.nchunks && !chunk_mask(ch)) ++ch; return ch; };
+    float hv[NH], av[TAPS];
+    auto request = [&](int ch, unsigned m) {              // all loads of a chunk in flight
+        // buffer loads: offsets past the chunk's existing channels and the all-ones border offset come back as 0.0 from the range check
+        const int cleft = a.cin - 16 * ch;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + ((size_t)b * a.cin + 16 * ch) * V3), 0,
+                                                          (int)((cleft < 16 ? cleft : 16) * V3 * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NH; ++u) hv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)hoff[u], 0, 0));
+        const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.frag + ((size_t)ch * TAPS * 4 * a.nbt + nb) * 64), 0,
+                                                          (int)((TAPS * 4 - 1) * a.nbt * 64 + 64) * (int)sizeof(float), 0x00020000);
+        const int fo = (int)(((threadIdx.x >> 6) * a.nbt * 64 + (threadIdx.x & 63)) * sizeof(float));
+        const int fstep = (int)(4 * a.nbt * 64 * sizeof(float));
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+            av[tp] = ((m >> tp) & 1u) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, fo + tp * fstep, 0, 0)) : 0.f;
+    };
+    const int lx = ox - bx8, ly = (oy - by8) * HX;
+    const float* hg = halo + g * HALO;
+    int ch = next_chunk(0);
+    unsigned m = ch < a.nchunks ? chunk_mask(ch) : 0u;
+    if (ch < a.nchunks) request(ch, m);
+    while (ch < a.nchunks) {
+        __syncthreads();                                  // the previous chunk's MFMAs are done with the tiles
+#pragma unroll
+        for (int u = 0; u < NH; ++u)
+            if (threadIdx.x + 256 * u < 16 * HALO) halo[threadIdx.x + 256 * u] = hv[u];
+        {
+            const int ln = threadIdx.x & 63, c = threadIdx.x >> 6;
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) asl[(tp * 64 + ln) * 4 + c] = av[tp];
+        }
+        __syncthreads();
+        const unsigned mc = m;
+        const int nx = next_chunk(ch + 1);
+        if (nx < a.nchunks) { m = chunk_mask(nx); request(nx, m); }
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+            if (!((mc >> tp) & 1u)) continue;             // wave-uniform
+            const int tz = tp / 9, ty = (tp / 3) % 3, tx = tp % 3;
+            const int base = (tz * HY + ty) * HX + ly + lx + tx;
+            const f4 aw = *reinterpret_cast<const f4*>(asl + (tp * 64 + lane) * 4);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[cc], hg[4 * cc * HALO + base + t * HX * HY], acc[t], 0, 0, 0);
+            }
+        }
+        ch = nx;
+    }
+    if (ox < a.W && oy < a.H && b < a.B) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oz = bz4 + t;
+            if (oz >= a.D) continue;
+            const size_t v = ((size_t)oz * a.H + oy) * a.W + ox;
+            const float e[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = 16 * nb + 4 * g + q;
+                if (o < a.cout) a.out[((size_t)b * a.cout + o) * V3 + v] = e[q];
+            }
+        }
+    }
+}
+
 }  // namespace gnr_head
 
 extern "C" size_t gnr_conv3d_same_workspace_bytes(int Cin, int Cout, int K) {
@@ -700,8 +852,32 @@ extern "C" size_t gnr_conv3d_same_workspace_bytes(int Cin, int Cout, int K) {
 
 // mode 0: x [B][Cin][D][H][W] -> y [B][Cout][D][H][W] (+ bias [Cout] or NULL);  mode 1: x = dy [B][Cout][..] -> y = dx [B][Cin][..]
 // (bias ignored).  w = the layer's canonical weights [Cout][Cin][K][K][K] on the device.  K = 3 or 5.
+extern "C" size_t gnr_conv3d_tap_mask_words(int Cin, int Cout) {
+    if (Cin < 1 || Cout < 1) return 0;
+    return (size_t)((Cin + 15) / 16) * ((Cout + 15) / 16) * 4;
+}
+
+// mask [Cin blocks][Cout blocks][4 words] <- which taps of each 16 x 16 weight block exist in `pattern` [Cout][Cin][K^3] (device, any
+// non-zero = the weight exists).  Made once per layer shape; the masked entry points below skip the absent taps in all three directions.
+extern "C" int gnr_conv3d_tap_mask(const float* pattern, unsigned* mask, int Cin, int Cout, int K, void* stream) {
+    if (!pattern || !mask || Cin < 1 || Cout < 1 || (K != 3 && K != 5)) return GNR_ERR_ARG;
+    const int nbi = (Cin + 15) / 16, nbo = (Cout + 15) / 16;
+    hipLaunchKernelGGL(gnr_head::k_conv3d_tap_mask, dim3(nbi * nbo), dim3(64), 0, (hipStream_t)stream, pattern, mask, Cin, Cout, K * K * K, nbo);
+    HCHK(hipGetLastError());
+    return GNR_OK;
+}
+
+extern "C" int gnr_conv3d_same_masked(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H,
+                                      int W, int K, int mode, const unsigned* mask, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H,
                                int W, int K, int mode, void* ws, size_t ws_bytes, void* stream) {
+    return gnr_conv3d_same_masked(x, w, bias, y, B, Cin, Cout, D, H, W, K, mode, nullptr, ws, ws_bytes, stream);
+}
+
+// `mask` = gnr_conv3d_tap_mask of the layer's weight pattern (or NULL: dense): taps without a weight are skipped.
+extern "C" int gnr_conv3d_same_masked(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H,
+                                      int W, int K, int mode, const unsigned* mask, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !y || !ws) { snprintf(h_err, sizeof(h_err), "gnr_conv3d_same: null pointer"); return GNR_ERR_ARG; }
     if (B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5) || (mode != 0 && mode != 1)) {
         snprintf(h_err, sizeof(h_err), "gnr_conv3d_same: bad shape / mode (K must be 3 or 5)"); return GNR_ERR_SHAPE; }
@@ -716,7 +892,7 @@ extern "C" int gnr_conv3d_same(const float* x, const float* w, const float* bias
         hipLaunchKernelGGL(gnr_head::k_pack_conv3d_frag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, frag, Cin, Cout, K, mode, nchunks, nbt);
         HCHK(hipGetLastError());
     }
-    gnr_head::Conv1Args a{x, frag, mode ? nullptr : bias, y, B, cin, cout, D, H, W, nchunks, nbt};
+    gnr_head::Conv1Args a{x, frag, mode ? nullptr : bias, y, B, cin, cout, D, H, W, nchunks, nbt, mask, mode};
     const long blocks = (long)B * ((W + 7) / 8) * ((H + 7) / 8) * ((D + 3) / 4);
     HeadScope hs(mode ? "k_conv3d_s1.bwd_data@gnr_conv3d_same" : "k_conv3d_s1.fwd@gnr_conv3d_same", stream);
     if (K == 5) {
@@ -725,10 +901,10 @@ extern "C" int gnr_conv3d_same(const float* x, const float* w, const float* bias
         if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
         hipLaunchKernelGGL(gnr_head::k_conv3d_s1<5>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
     } else {
-        const size_t lds = (16 * (10 * 10 * 6) + 3 * 256) * sizeof(float);
+        const size_t lds = (16 * (10 * 10 * 6) + 27 * 256) * sizeof(float);
         static std::atomic<unsigned long long> attr{0};
-        if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
-        hipLaunchKernelGGL(gnr_head::k_conv3d_s1<3>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
+        if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1_k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+        hipLaunchKernelGGL(gnr_head::k_conv3d_s1_k3, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
     }
     HCHK(hipGetLastError());
     return GNR_OK;
@@ -750,7 +926,7 @@ namespace gnr_head {
 
 template <int KS>
 __global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_s1(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                                            int B, int Cin, int Cout, int D, int H, int W, int nbi) {
+                                                            int B, int Cin, int Cout, int D, int H, int W, int nbi, const unsigned* __restrict__ mask) {
     constexpr int PAD = KS / 2, TAPS = KS * KS * KS, TPW = (TAPS + 3) / 4;      // taps per wavefront
     constexpr int HX = 8 + KS - 1, HY = 8 + KS - 1, HZ = 4 + KS - 1, HALO = HX * HY * HZ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -763,11 +939,21 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_s1(const float* __restr
     const size_t V3 = (size_t)D * H * W;
     f4 acc[TPW];
     int off[TPW];
+    unsigned act = 0;                                     // bit j: this wavefront's tap wave + 4 j has weights in block (bi, bo)
+    const int nbo = gridDim.y / nbi;
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         acc[j] = f4{0.f, 0.f, 0.f, 0.f};
-        const int tap = wave + 4 * j, t = tap < TAPS ? tap : 0;
+        const int tap = __builtin_amdgcn_readfirstlane(wave) + 4 * j, t = tap < TAPS ? tap : 0;
         off[j] = ((t / (KS * KS)) * HY + (t / KS) % KS) * HX + t % KS;
+        const unsigned on = mask ? (tap < TAPS ? (mask[((size_t)bi * nbo + bo) * 4 + (t >> 5)] >> (t & 31)) & 1u : 0u) : 1u;
+        act |= on << j;
+    }
+    if (mask && !__builtin_amdgcn_readfirstlane(mask[((size_t)bi * nbo + bo) * 4] | mask[((size_t)bi * nbo + bo) * 4 + 1] |
+                                                mask[((size_t)bi * nbo + bo) * 4 + 2] | mask[((size_t)bi * nbo + bo) * 4 + 3])) {
+        float* pp0 = part + (((size_t)pair * gridDim.x + blockIdx.x) * TAPS) * 256;       // nothing joins the two blocks: zeros
+        for (int i = threadIdx.x; i < TAPS * 256; i += 256) pp0[i] = 0.f;
+        return;
     }
     for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
         const int b = brick / (nbx * nby * nbz), br = brick - b * nbx * nby * nbz;
@@ -775,34 +961,169 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_s1(const float* __restr
         __syncthreads();                                  // the previous brick's MFMAs are done with the tiles
         {
             const float* xin = x + ((size_t)b * Cin + 16 * bi) * V3;
-            for (int i = threadIdx.x; i < 16 * HALO; i += 256) {
-                const int c = i / HALO, cell = i - c * HALO;
-                const int z = bz4 - PAD + cell / (HX * HY), y = by8 - PAD + (cell / HX) % HY, xx = bx8 - PAD + cell % HX;
-                const bool ok = 16 * bi + c < Cin && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-                halo[cell * 16 + c] = ok ? xin[(size_t)c * V3 + ((size_t)z * H + y) * W + xx] : 0.f;
+            for (int i0 = threadIdx.x; i0 < 16 * HALO; i0 += 256 * 8) {     // eight loads in flight per lane, then the LDS stores
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 256 * u, c = i / HALO, cell = i - c * HALO;
+                    const int z = bz4 - PAD + cell / (HX * HY), y = by8 - PAD + (cell / HX) % HY, xx = bx8 - PAD + cell % HX;
+                    const bool ok = i < 16 * HALO && 16 * bi + c < Cin && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+                    v[u] = ok ? xin[(size_t)c * V3 + ((size_t)z * H + y) * W + xx] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 256 * u, c = i / HALO, cell = i - c * HALO;
+                    if (i < 16 * HALO) halo[cell * 16 + c] = v[u];
+                }
             }
             const float* din = dy + ((size_t)b * Cout + 16 * bo) * V3;
-            for (int i = threadIdx.x; i < 16 * 256; i += 256) {
-                const int o = i >> 8, v = i & 255;
-                const int z = bz4 + (v >> 6), y = by8 + ((v >> 3) & 7), xx = bx8 + (v & 7);
-                const bool ok = 16 * bo + o < Cout && z < D && y < H && xx < W;
-                dyt[v * 16 + o] = ok ? din[(size_t)o * V3 + ((size_t)z * H + y) * W + xx] : 0.f;
+            {
+                float v[16];
+#pragma unroll
+                for (int o = 0; o < 16; ++o) {                // lane = voxel of the brick, sixteen output channels in flight
+                    const int vx = threadIdx.x;
+                    const int z = bz4 + (vx >> 6), y = by8 + ((vx >> 3) & 7), xx = bx8 + (vx & 7);
+                    const bool ok = 16 * bo + o < Cout && z < D && y < H && xx < W;
+                    v[o] = ok ? din[(size_t)o * V3 + ((size_t)z * H + y) * W + xx] : 0.f;
+                }
+#pragma unroll
+                for (int o = 0; o < 16; ++o) dyt[threadIdx.x * 16 + o] = v[o];
             }
         }
         __syncthreads();
+        if (act == (TPW >= 32 ? ~0u : (1u << (TPW & 31)) - 1u)) {                    // dense block: every tap of this wavefront (straight-line MFMA chain)
 #pragma unroll 2
-        for (int s = 0; s < 64; ++s) {                    // k-step s = voxels 4s .. 4s+3 (consecutive x)
-            const float av = dyt[64 * s + lane];          // A: row o = lane % 16, k = lane / 16  <->  dyt[(4s + k) * 16 + o]
-            const int cellbase = ((s >> 4) * HY + ((s >> 1) & 7)) * HX + 4 * (s & 1);
-            const float* hb = halo + cellbase * 16 + lane;        // B: col i = lane % 16, k = lane / 16  <->  halo[(cell + k) * 16 + i]
+            for (int s = 0; s < 64; ++s) {                // k-step s = voxels 4s .. 4s+3 (consecutive x)
+                const float av = dyt[64 * s + lane];      // A: row o = lane % 16, k = lane / 16  <->  dyt[(4s + k) * 16 + o]
+                const int cellbase = ((s >> 4) * HY + ((s >> 1) & 7)) * HX + 4 * (s & 1);
+                const float* hb = halo + cellbase * 16 + lane;    // B: col i = lane % 16, k = lane / 16  <->  halo[(cell + k) * 16 + i]
 #pragma unroll
-            for (int j = 0; j < TPW; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hb[off[j] * 16], acc[j], 0, 0, 0);
+                for (int j = 0; j < TPW; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hb[off[j] * 16], acc[j], 0, 0, 0);
+            }
+        } else if (act) {                                 // structurally sparse block: only the taps that hold a weight
+            for (int s = 0; s < 64; ++s) {
+                const float av = dyt[64 * s + lane];
+                const int cellbase = ((s >> 4) * HY + ((s >> 1) & 7)) * HX + 4 * (s & 1);
+                const float* hb = halo + cellbase * 16 + lane;
+#pragma unroll
+                for (int j = 0; j < TPW; ++j)
+                    if ((act >> j) & 1u) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hb[off[j] * 16], acc[j], 0, 0, 0);
+            }
         }
     }
     // partial sums of this workgroup: part[pair][workgroup][tap][o = 4 kg + q][i = lane % 16] (plain stores; hundreds of
     // workgroups adding atomically into the same few thousand weights serialise at the memory side: 1.2 ms of a 1.5 ms kernel)
     float* pp = part + (((size_t)pair * gridDim.x + blockIdx.x) * TAPS) * 256;
+    const int kg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int tap = wave + 4 * j;
+        if (tap >= TAPS) continue;
+        const float e[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pp[(size_t)tap * 256 + (4 * kg + q) * 16 + (lane & 15)] = e[q];
+    }
+}
+
+// K = 3 form of the weight-gradient kernel (every layer of the head under training is a k3 convolution on a 5^3 .. 20^3 grid since the
+// upsamplings / strides were folded): the brick's halo and dy tile are REQUESTED into registers (38 + 16 buffer loads per lane, all in
+// flight; the zero border and the channels past Cin / Cout come back as 0.0 from the descriptor's range check -- no predicated loads)
+// while the previous brick's MFMAs run, lanes take the channel as their fast index so that the LDS stores are linear, and a structurally
+// sparse block (tap mask) runs tap-outer over its few present taps.  Same partial-block layout as k_conv3d_wgrad_s1<3>.
+__global__ __launch_bounds__(256, 1) void k_conv3d_wgrad_k3(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                            int B, int Cin, int Cout, int D, int H, int W, int nbi, const unsigned* __restrict__ mask) {
+    constexpr int KS = 3, PAD = 1, TAPS = 27, TPW = 7;
+    constexpr int HX = 10, HY = 10, HZ = 6, HALO = HX * HY * HZ;
+    constexpr int NH = (HALO + 15) / 16;                  // halo cells per lane (38): lane = (cell group, channel)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                                   // [HALO cells][16 input channels]
+    float* dyt = smem + HALO * 16;                        // [256 voxels][16 output channels]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.y, bi = pair % nbi, bo = pair / nbi, nbo = gridDim.y / nbi;
+    const int nbx = (W + 7) >> 3, nby = (H + 7) >> 3, nbz = (D + 3) >> 2;
+    const int nbricks = B * nbx * nby * nbz;
+    const size_t V3 = (size_t)D * H * W;
+    float* pp = part + (((size_t)pair * gridDim.x + blockIdx.x) * TAPS) * 256;
+    const unsigned mword = mask ? mask[((size_t)bi * nbo + bo) * 4] : (1u << TAPS) - 1u;
+    if (!mword) {                                         // nothing joins the two channel blocks: zeros
+        for (int i = threadIdx.x; i < TAPS * 256; i += 256) pp[i] = 0.f;
+        return;
+    }
+    f4 acc[TPW];
+    int off[TPW];
+    unsigned act = 0;                                     // bit j: tap wave + 4 j exists in block (bi, bo)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+        const int tap = wave + 4 * j, t = tap < TAPS ? tap : 0;
+        off[j] = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * 16;
+        act |= (tap < TAPS ? (mword >> t) & 1u : (mask ? 0u : 1u)) << j;
+    }
+    const int hc = threadIdx.x & 15, hg = threadIdx.x >> 4;               // staging: channel, first cell
+    const int cin_left = Cin - 16 * bi, cout_left = Cout - 16 * bo;
+    float hv[NH], dv[16];
+    auto request = [&](int brick) {
+        const int b = brick / (nbx * nby * nbz), br = brick - b * nbx * nby * nbz;
+        const int bz4 = (br / (nbx * nby)) * 4, by8 = ((br / nbx) % nby) * 8, bx8 = (br % nbx) * 8;
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + ((size_t)b * Cin + 16 * bi) * V3), 0,
+                                                          (int)((cin_left < 16 ? cin_left : 16) * V3 * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+            const int cell = hg + 16 * u;
+            const int z = bz4 - PAD + cell / (HX * HY), y = by8 - PAD + (cell / HX) % HY, xx = bx8 - PAD + cell % HX;
+            const bool ok = cell < HALO && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const int o = ok ? (int)((hc * V3 + ((size_t)z * H + y) * W + xx) * sizeof(float)) : -1;
+            hv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        }
+        const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + ((size_t)b * Cout + 16 * bo) * V3), 0,
+                                                          (int)((cout_left < 16 ? cout_left : 16) * V3 * sizeof(float)), 0x00020000);
+        const int vx = threadIdx.x;
+        const int z = bz4 + (vx >> 6), y = by8 + ((vx >> 3) & 7), xx = bx8 + (vx & 7);
+        const bool ok = z < D && y < H && xx < W;
+        const int vo = (int)((((size_t)z * H + y) * W + xx) * sizeof(float));
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+            dv[o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, ok ? vo + (int)(o * V3 * sizeof(float)) : -1, 0, 0));
+    };
+    int brick = blockIdx.x;
+    if (brick < nbricks) request(brick);
+    for (; brick < nbricks; brick += gridDim.x) {
+        __syncthreads();                                  // the previous brick's MFMAs are done with the tiles
+#pragma unroll
+        for (int u = 0; u < NH; ++u)
+            if (hg + 16 * u < HALO) halo[(hg + 16 * u) * 16 + hc] = hv[u];          // linear in the lane index
+#pragma unroll
+        for (int o = 0; o < 16; o += 4)
+            *reinterpret_cast<f4*>(dyt + threadIdx.x * 16 + o) = f4{dv[o], dv[o + 1], dv[o + 2], dv[o + 3]};
+        __syncthreads();
+        if (brick + (int)gridDim.x < nbricks) request(brick + gridDim.x);
+        if (act == (1u << TPW) - 1u) {                    // dense block: k-step outer, the wavefront's seven taps share the dy operand
+#pragma unroll 2
+            for (int s = 0; s < 64; ++s) {                // k-step s = voxels 4s .. 4s+3 (consecutive x)
+                const float av = dyt[64 * s + lane];      // A: row o = lane % 16, k = lane / 16  <->  dyt[(4s + k) * 16 + o]
+                const int cellbase = ((s >> 4) * HY + ((s >> 1) & 7)) * HX + 4 * (s & 1);
+                const float* hb = halo + cellbase * 16 + lane;    // B: col i = lane % 16, k = lane / 16  <->  halo[(cell + k) * 16 + i]
+#pragma unroll
+                for (int j = 0; j < TPW; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, hb[off[j]], acc[j], 0, 0, 0);
+            }
+        } else {                                          // structurally sparse block: tap outer, only the taps that hold a weight
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (!((act >> j) & 1u)) continue;
+                const float* hj = halo + off[j] + lane;
+                f4 a0 = acc[j], a1 = f4{0.f, 0.f, 0.f, 0.f};      // two chains: the dependent-MFMA latency is not hidden by other taps here
+#pragma unroll 4
+                for (int s = 0; s < 64; s += 2) {
+                    const int c0 = (((s >> 4) * HY + ((s >> 1) & 7)) * HX) * 16;      // s even: 4 * (s & 1) = 0; s + 1: + 4 cells
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dyt[64 * s + lane], hj[c0], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dyt[64 * s + 64 + lane], hj[c0 + 64], a1, 0, 0, 0);
+                }
+                acc[j] = a0 + a1;
+            }
+        }
+    }
     const int kg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
@@ -825,9 +1146,18 @@ __global__ void k_conv3d_wgrad_reduce(const float* __restrict__ part, float* __r
     const int o = 16 * bo + o16, i = 16 * bi + i16;
     if (o >= Cout || i >= Cin) return;
     const float* p = part + ((size_t)pair * nwg * taps) * 256 + rem;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += p[(size_t)w * taps * 256];
-    dw[((size_t)o * Cin + i) * taps + tap] += s;
+    const size_t st = (size_t)taps * 256;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};                   // four interleaved sums in a fixed order: the loads of a lane overlap (up to 256 blocks)
+    int w = 0;
+    for (; w + 8 <= nwg; w += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(w + u) * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s4[u & 3] += v[u];
+    }
+    for (; w < nwg; ++w) s4[w & 3] += p[(size_t)w * st];
+    dw[((size_t)o * Cin + i) * taps + tap] += (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
 }  // namespace gnr_head
@@ -850,8 +1180,17 @@ extern "C" size_t gnr_conv3d_same_bwd_weight_workspace_bytes(int B, int Cin, int
 }
 
 // dw [Cout][Cin][K][K][K] is ACCUMULATED (zero it first); K = 3 or 5; workspace = gnr_conv3d_same_bwd_weight_workspace_bytes(...).
+extern "C" int gnr_conv3d_same_bwd_weight_masked(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W,
+                                                 int K, const unsigned* mask, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
                                           void* ws, size_t ws_bytes, void* stream) {
+    return gnr_conv3d_same_bwd_weight_masked(x, dy, dw, B, Cin, Cout, D, H, W, K, nullptr, ws, ws_bytes, stream);
+}
+
+// `mask` = gnr_conv3d_tap_mask of the layer's weight pattern (or NULL): the gradient of an absent weight is not computed (stays as it was in dw).
+extern "C" int gnr_conv3d_same_bwd_weight_masked(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W,
+                                                 int K, const unsigned* mask, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !dy || !dw || !ws || B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5)) return GNR_ERR_ARG;
     if (ws_bytes < gnr_conv3d_same_bwd_weight_workspace_bytes(B, Cin, Cout, D, H, W, K)) return GNR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -864,12 +1203,12 @@ extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float
             const size_t lds = (16 * (12 * 12 * 8) + 16 * 256) * sizeof(float);
             static std::atomic<unsigned long long> attr{0};
             if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
-            hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi);
+            hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi, mask);
         } else {
             const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
             static std::atomic<unsigned long long> attr{0};
-            if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
-            hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<3>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi);
+            if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+            hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_k3, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi, mask);
         }
         HCHK(hipGetLastError());
     }

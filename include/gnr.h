@@ -213,6 +213,18 @@ int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float* dw, int B
                                void* workspace, size_t workspace_bytes, void* stream);
 int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W, int K,
                     int mode, void* workspace, size_t workspace_bytes, void* stream);
+/* Structurally sparse weights (round 4).  The encoder's stride-2 layers (gd/networks.py:33-37,59-76) run as ONE stride-1 k3 convolution
+ * over the space-to-depth input (8 Cin channels, backbone.conv3d_stride2): of the 8 x 27 (parity, tap) slots per input channel 27 hold a
+ * weight.  gnr_conv3d_tap_mask reads a pattern tensor [Cout][Cin][K^3] (non-zero = the weight exists; the STRUCTURE, not the values: a
+ * weight that happens to be 0.0 still has a gradient) and writes gnr_conv3d_tap_mask_words(Cin, Cout) uint32 words: per (16 input
+ * channels, 16 output channels) block the set of taps that exist.  The _masked entry points are gnr_conv3d_same /
+ * gnr_conv3d_same_bwd_weight that skip the absent taps (mask == NULL: dense, the same as the plain entry points). */
+size_t gnr_conv3d_tap_mask_words(int Cin, int Cout);
+int gnr_conv3d_tap_mask(const float* pattern, unsigned* mask, int Cin, int Cout, int K, void* stream);
+int gnr_conv3d_same_masked(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
+                           int K, int mode, const unsigned* mask, void* workspace, size_t workspace_bytes, void* stream);
+int gnr_conv3d_same_bwd_weight_masked(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W, int K,
+                                      const unsigned* mask, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- image-side streaming ops of the 2D feature extractors (csrc/gnr_img.hip) ----------------------------------
  * The residual U-Nets in front of the hot path (src/nr/network/ops.py:96-230, init_net.py:8-35, vis_encoder.py:6-22) are

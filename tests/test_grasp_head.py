@@ -70,10 +70,83 @@ def test_conv3d_same_all_three_directions(B, Cin, Cout, D, H, W, K):
         assert a.shape == r.shape and (a - r).abs().max() <= 2e-4 * r.abs().max() + 1e-5, name
 
 
+def test_folded_upsample_k5_is_the_plain_convolution():
+    """backbone.upconv5_x2 = F.conv3d(F.interpolate(u, x2 nearest), w, b, padding=2) in values and in all three gradients (float64 on
+    the CPU, ragged sizes: the fold is exact algebra, the zero padding of the upsampled grid included)."""
+    from graspnerf_amd import backbone
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    u = torch.randn(2, 5, 6, 4, 7, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(3, 5, 5, 5, 5, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(3, dtype=torch.float64, requires_grad=True)
+    saved = dict(backbone._FOLD_MATS)
+    try:
+        backbone._FOLD_MATS.clear()
+        backbone._FOLD_MATS[('up', 'cpu')] = backbone._upfold_matrix('cpu').double()
+        y = backbone.upconv5_x2(u, w, b)
+    finally:
+        backbone._FOLD_MATS.clear(); backbone._FOLD_MATS.update(saved)
+    r = F.conv3d(F.interpolate(u, scale_factor=2, mode='nearest'), w, b, padding=2)
+    assert y.shape == r.shape and float((y - r).abs().max()) < 1e-12
+    g = torch.randn_like(r)
+    for a, c in zip(torch.autograd.grad((y * g).sum(), (u, w, b)), torch.autograd.grad((r * g).sum(), (u, w, b))):
+        assert float((a - c).abs().max()) < 1e-11
+
+
+@pytest.mark.parametrize('k,ci,co,dims', [(3, 4, 5, (6, 4, 8)), (5, 1, 3, (8, 6, 4)), (5, 2, 3, (4, 4, 4)), (3, 3, 2, (2, 2, 2))])
+def test_stride2_as_space_to_depth_is_the_plain_convolution(k, ci, co, dims):
+    """backbone.conv3d_stride2 = F.conv3d(x, w, b, stride=2, padding=k // 2) in values and all three gradients (float64, CPU)."""
+    from graspnerf_amd import backbone
+    import torch.nn.functional as F
+    torch.manual_seed(k + ci)
+    x = torch.randn(2, ci, *dims, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(co, ci, k, k, k, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(co, dtype=torch.float64, requires_grad=True)
+    saved = dict(backbone._FOLD_MATS)
+    try:
+        backbone._FOLD_MATS.clear()
+        backbone._FOLD_MATS[(k, 'cpu')] = backbone._stride2_matrix(k, 'cpu').double()
+        y = backbone.conv3d_stride2(x, w, b)
+    finally:
+        backbone._FOLD_MATS.clear(); backbone._FOLD_MATS.update(saved)
+    r = F.conv3d(x, w, b, stride=2, padding=k // 2)
+    assert y.shape == r.shape and float((y - r).abs().max()) < 1e-12
+    g = torch.randn_like(r)
+    for a, c in zip(torch.autograd.grad((y * g).sum(), (x, w, b)), torch.autograd.grad((r * g).sum(), (x, w, b))):
+        assert float((a - c).abs().max()) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,ci,co,n,B', [(5, 1, 16, 40, 2), (3, 16, 32, 20, 2), (3, 32, 64, 10, 3), (3, 20, 24, 6, 1), (5, 3, 5, 8, 2)])
+def test_stride2_layers_on_the_hip_path(k, ci, co, n, B):
+    """The encoder's stride-2 layers (gd/networks.py:33-37) as space-to-depth + masked k3 convolution (gnr_conv3d_same_masked,
+    gnr_conv3d_same_bwd_weight_masked: taps without a weight skipped per 16 x 16 channel block) against F.conv3d(stride=2): outputs
+    and all three gradients.  Some weights are set to exactly 0.0: the mask is structure, their gradients must still come out."""
+    from graspnerf_amd import backbone
+    import torch.nn.functional as F
+    torch.manual_seed(k * 100 + ci)
+    x = torch.randn(B, ci, n, n, n, device='cuda', requires_grad=True)
+    w = (torch.randn(co, ci, k, k, k, device='cuda') * 0.2)
+    w[:, :, 0] = 0.0
+    w[: co // 2, :, :, 1] = 0.0
+    w.requires_grad_(True)
+    b = torch.randn(co, device='cuda', requires_grad=True)
+    y = backbone.conv3d_stride2(x, w, b)
+    r = F.conv3d(x, w, b, stride=2, padding=k // 2)
+    assert y.shape == r.shape and float((y - r).detach().abs().max()) <= 2e-5 * float(r.detach().abs().max())
+    g = torch.randn_like(r)
+    ga = torch.autograd.grad((y * g).sum(), (x, w, b))
+    gr = torch.autograd.grad((r * g).sum(), (x, w, b))
+    for name, a, c in zip(('dx', 'dw', 'db'), ga, gr):
+        assert float((a - c).abs().max()) <= 1e-4 * float(c.abs().max()) + 1e-6, name
+    assert float(ga[1][:, :, 0].abs().max()) > 0                      # a gradient where the weight's VALUE is zero
+
+
 @pytest.mark.gpu
 def test_convnet_under_autograd_matches_pytorch():
-    """gd.networks.ConvNet mirror in training mode (HIP convolutions for decoder.conv3 and the fused heads) against the same
-    module with every convolution in PyTorch: outputs and all 18 parameter gradients."""
+    """gd.networks.ConvNet mirror in training mode (HIP convolutions; decoder.conv3 and the fused heads with their x2 upsampling
+    folded into pre-summed k3 weights, backbone.upconv5_x2; the encoder's stride-2 layers as space-to-depth + k3, backbone.conv3d_stride2) against the same module stated plainly in PyTorch (F.interpolate +
+    F.conv3d, no folding): outputs and all 18 parameter gradients."""
     from graspnerf_amd import backbone
     torch.manual_seed(0)
     net = backbone.ConvNet().cuda()
@@ -82,14 +155,15 @@ def test_convnet_under_autograd_matches_pytorch():
     res = {}
     for hip in (True, False):
         net.zero_grad(set_to_none=True)
-        orig = backbone.conv3d_same
+        orig, fold, s2d = backbone.conv3d_same, backbone.FOLD_UPSAMPLED_K5, backbone.STRIDE2_AS_S2D
         if not hip:
             backbone.conv3d_same = lambda x, w, b: torch.nn.functional.conv3d(x, w, b, padding=w.shape[-1] // 2)
+            backbone.FOLD_UPSAMPLED_K5 = backbone.STRIDE2_AS_S2D = False
         try:
             out = net(vol)
             sum((o * u).sum() for o, u in zip(out, ups)).backward()
         finally:
-            backbone.conv3d_same = orig
+            backbone.conv3d_same, backbone.FOLD_UPSAMPLED_K5, backbone.STRIDE2_AS_S2D = orig, fold, s2d
         torch.cuda.synchronize()
         res[hip] = ([o.detach().clone() for o in out], {k: p.grad.clone() for k, p in net.named_parameters()})
     for a, r in zip(res[True][0], res[False][0]):
