@@ -717,6 +717,9 @@ constexpr int SW = 20;     // per-view state width: X[9] E[8] gate m rgb  /  H2[
 constexpr int rows_a(int V) { return GNR_TWO_QUEUES ? (V + 1) / 2 : V; }
 constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
 
+#ifndef GNR_SKIP_MASKED
+#define GNR_SKIP_MASKED 1      // skip the (tile, view) pairs without a single valid point (inference kernels)
+#endif
 #ifndef GNR_CHAIN_THREADS
 #define GNR_CHAIN_THREADS 512     // 8 wavefronts = 2 per SIMD at 250 registers; 256 (1 per SIMD, 512 registers) was measured too;
                                   // 768 / 1024 (3 / 4 per SIMD) would spill 356 / 524 B per lane: S[V][20] alone is 120 registers
@@ -877,6 +880,21 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             const float m = vg.m;
             msum += m;
             vbits |= (m != 0.f ? 1u : 0u) << v;
+#if GNR_SKIP_MASKED
+            // No point of the tile lies inside this view (render_ops.py:24-31 mask == 0 for all 16): everything the view would hand to
+            // the cross-view reductions carries the weight m = 0 (ibrnet.py:466-472: x, e1 and the gate enter as value * weight), so its
+            // row is zeros and the gathers, the decoder and the embedding are not run.  A quarter of a ray's (sample, view) pairs are
+            // masked on the benchmark's cameras and 7 % of its (tile, view) pairs entirely so; on the volume points next to none (1.3 % of
+            // the pairs), and there the branch costs more than it saves (volume launch 3.28 -> 3.35 ms): ray points only.
+            if constexpr (!SAVE && RENDER) {
+                if (__ballot(m != 0.f) == 0ull) {
+#pragma unroll
+                    for (int q = 0; q < SW; ++q) Sv[q] = 0.f;
+                    if (a.dbg && g == 0 && row_ok) { a.dbg[pt * 32 + v] = 0.f; a.dbg[pt * 32 + 8 + v] = 0.f; }
+                    continue;
+                }
+            }
+#endif
 
             // ---- gather: ray channels 8g..8g+7, image-feature channels 8g..8g+7, rgb channel g
             float FR[8], XI[9];
@@ -1090,6 +1108,18 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             for (int j = 0; j < 8; ++j) E[j] = Rv[9 + j];
             const float m = Rv[18];
             const float w = m * inv_msum;
+#if GNR_SKIP_MASKED
+            if constexpr (!SAVE && RENDER) {                                    // the same (tile, view) pairs as in phase 1: visibility 0,
+                if (__ballot(m != 0.f) == 0ull) {                               // colour logit -1e9, features with weight 0 (ibrnet.py:479-484,509)
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) Q[NQ - 1][j] = 0.f;
+                    Q[NQ - 1][9] = RENDER ? -1e9f : 0.f;
+                    Q[NQ - 1][19] = Rv[19];
+                    if (a.dbg && g == 0 && row_ok) a.dbg[pt * 32 + 16 + v] = 0.f;
+                    continue;
+                }
+            }
+#endif
             float Hh[8];
             {
                 f4 acc4[4] = {G[0], G[1], G[2], G[3]};
