@@ -852,6 +852,11 @@ extern "C" size_t gnr_conv3d_same_workspace_bytes(int Cin, int Cout, int K) {
 
 // mode 0: x [B][Cin][D][H][W] -> y [B][Cout][D][H][W] (+ bias [Cout] or NULL);  mode 1: x = dy [B][Cout][..] -> y = dx [B][Cin][..]
 // (bias ignored).  w = the layer's canonical weights [Cout][Cin][K][K][K] on the device.  K = 3 or 5.
+static std::atomic<int> g_conv3d_first_gen{0};
+// Debug switch (tests): route the K = 3 calls through the first-generation kernels (the path taken for volumes beyond the buffer
+// loads' 32-bit offsets).  Returns the previous setting.
+extern "C" int gnr_debug_conv3d_first_gen(int on) { return g_conv3d_first_gen.exchange(on ? 1 : 0); }
+
 extern "C" size_t gnr_conv3d_tap_mask_words(int Cin, int Cout) {
     if (Cin < 1 || Cout < 1) return 0;
     return (size_t)((Cin + 15) / 16) * ((Cout + 15) / 16) * 4;
@@ -900,6 +905,12 @@ extern "C" int gnr_conv3d_same_masked(const float* x, const float* w, const floa
         static std::atomic<unsigned long long> attr{0};
         if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
         hipLaunchKernelGGL(gnr_head::k_conv3d_s1<5>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
+    } else if (g_conv3d_first_gen.load() || (size_t)16 * D * H * W * sizeof(float) >= ((size_t)1 << 31) || (size_t)27 * 4 * nbt * 64 * sizeof(float) >= ((size_t)1 << 31)) {
+        // a chunk's 16 channels do not fit the 32-bit byte offsets of the buffer loads (> 32 M voxels): the first-generation kernel
+        const size_t lds = (16 * (10 * 10 * 6) + 3 * 256) * sizeof(float);
+        static std::atomic<unsigned long long> attr{0};
+        if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+        hipLaunchKernelGGL(gnr_head::k_conv3d_s1<3>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
     } else {
         const size_t lds = (16 * (10 * 10 * 6) + 27 * 256) * sizeof(float);
         static std::atomic<unsigned long long> attr{0};
@@ -1204,6 +1215,11 @@ extern "C" int gnr_conv3d_same_bwd_weight_masked(const float* x, const float* dy
             static std::atomic<unsigned long long> attr{0};
             if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
             hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi, mask);
+        } else if (g_conv3d_first_gen.load() || (size_t)16 * D * H * W * sizeof(float) >= ((size_t)1 << 31)) {      // beyond the buffer loads' 32-bit byte offsets
+            const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
+            static std::atomic<unsigned long long> attr{0};
+            if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+            hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<3>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi, mask);
         } else {
             const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
             static std::atomic<unsigned long long> attr{0};

@@ -219,6 +219,7 @@ int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y,
  * weight that happens to be 0.0 still has a gradient) and writes gnr_conv3d_tap_mask_words(Cin, Cout) uint32 words: per (16 input
  * channels, 16 output channels) block the set of taps that exist.  The _masked entry points are gnr_conv3d_same /
  * gnr_conv3d_same_bwd_weight that skip the absent taps (mask == NULL: dense, the same as the plain entry points). */
+int gnr_debug_conv3d_first_gen(int on);   /* tests: K = 3 calls through the first-generation kernels (the > 32 M voxel path); returns the previous setting */
 size_t gnr_conv3d_tap_mask_words(int Cin, int Cout);
 int gnr_conv3d_tap_mask(const float* pattern, unsigned* mask, int Cin, int Cout, int K, void* stream);
 int gnr_conv3d_same_masked(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,

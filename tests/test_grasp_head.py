@@ -143,6 +143,38 @@ def test_stride2_layers_on_the_hip_path(k, ci, co, n, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('masked', [False, True])
+def test_k3_kernel_generations_agree(masked):
+    """The pipelined K = 3 kernels (k_conv3d_s1_k3 / k_conv3d_wgrad_k3: buffer loads, register prefetch) against the first-generation
+    ones they replace (kept for volumes beyond 32-bit byte offsets; gnr_debug_conv3d_first_gen): same products in the same order per
+    output, so forward and backward data agree to rounding of the MFMA chain and the weight gradient to 1e-5 of its scale."""
+    from graspnerf_amd import backbone, _lib
+    L = _lib.lib()
+    torch.manual_seed(5)
+    if masked:
+        x = torch.randn(2, 16, 20, 20, 20, device='cuda', requires_grad=True)
+        w = (torch.randn(32, 16, 3, 3, 3, device='cuda') * 0.1).requires_grad_(True)
+        f = lambda: backbone.conv3d_stride2(x, w, b)
+    else:
+        x = torch.randn(2, 40, 9, 10, 11, device='cuda', requires_grad=True)
+        w = (torch.randn(24, 40, 3, 3, 3, device='cuda') * 0.1).requires_grad_(True)
+        f = lambda: backbone.conv3d_same(x, w, b)
+    b = torch.randn(w.shape[0], device='cuda', requires_grad=True)
+    res = []
+    for gen in (0, 1):
+        prev = L.gnr_debug_conv3d_first_gen(gen)
+        try:
+            y = f()
+            g = torch.autograd.grad((y * torch.cos(y.detach())).sum(), (x, w))
+            torch.cuda.synchronize()
+        finally:
+            L.gnr_debug_conv3d_first_gen(prev)
+        res.append((y.detach(), g[0], g[1]))
+    for a, c in zip(*res):
+        assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max()) + 1e-7
+
+
+@pytest.mark.gpu
 def test_convnet_under_autograd_matches_pytorch():
     """gd.networks.ConvNet mirror in training mode (HIP convolutions; decoder.conv3 and the fused heads with their x2 upsampling
     folded into pre-summed k3 weights, backbone.upconv5_x2; the encoder's stride-2 layers as space-to-depth + k3, backbone.conv3d_stride2) against the same module stated plainly in PyTorch (F.interpolate +
