@@ -308,3 +308,38 @@ def test_ray_traversal_order_is_invisible(cfg_name, extra, weights_np):
         for k in outs[0][lvl]:
             assert torch.equal(outs[0][lvl][k], outs[1][lvl][k]), (lvl, k)
     assert torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.gpu
+def test_a_view_that_sees_nothing(weights_np):
+    """A reference view whose principal point lies 10 000 pixels outside its image (every projection out of bounds: mask 0 everywhere,
+    render_ops.py:24-31; a camera that merely looks away would not do, :101 keeps points BEHIND a camera valid) at the benchmark's scene
+    size: on the ray points all its (tile, view) pairs take k_chain's skip, on the volume points the masked arithmetic.  Outputs against
+    the oracle on the same seven views (volume, both render levels on a subset of rays, masks bit-exact) -- and NOT equal to the six-view
+    run: ibrnet.py:488 feeds weight.mean over ALL views (1 / V) into geometry_fc, the count of views is an input of the network."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    W = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    ref, que = make_scene(3, 'cfg2')
+    r7 = {k: v.copy() for k, v in ref.items()}
+    for k in ('imgs', 'img_feats', 'ray_feats', 'Ks', 'depth_range', 'poses'):
+        r7[k] = np.concatenate([ref[k], ref[k][:1]], 0)
+    r7['Ks'][6, 0, 2] = r7['Ks'][6, 1, 2] = -1.0e4
+    res = 24                                                           # the oracle's volume on the CPU: 24^3 x 7 views in a few seconds
+    bref, bque = batch_scenes([(r7, que)])
+    vol, vm = hp.sample_volume(bref, res, want_mask=True)
+    co, fi, inds = hp.render(bref, bque, {'depth_sample_num': 40, 'fine_depth_sample_num': 40}, debug=True)
+    b6, q6 = batch_scenes([(ref, que)])
+    vol6 = hp.sample_volume(b6, res)
+    torch.cuda.synchronize()
+    assert int((vm >> 6).max()) == 0                                   # the seventh view's mask bit is never set
+    assert float((vol - vol6).abs().max()) > 1e-3                      # ... and yet the view counts: 1 / V (ibrnet.py:488)
+    close(vol.cpu().numpy()[0], O.sample_volume(W, O.to_torch(r7), res).numpy()[0], 'volume with an unseeing seventh view')
+    sel = np.arange(0, que['coords'].shape[0], 4)                      # 128 of the 512 rays
+    sque = dict(que, coords=que['coords'][sel])
+    ref_o = O.render(W, O.to_torch(r7), O.to_torch(sque), {}, fine_depth_override=fi['depth'][0, sel].cpu())
+    for k in VALUE_KEYS:
+        close(co[k][0, sel].cpu().numpy(), ref_o[k].numpy()[0], f'unseeing view, coarse {k}', atol=ATOLS.get(k, ATOL_A))
+        close(fi[k][0, sel].cpu().numpy(), ref_o[k + '_fine'].numpy()[0], f'unseeing view, fine {k}', atol=ATOLS.get(k, ATOL_A))
+    assert np.array_equal(co['ray_mask'][0, sel].cpu().numpy(), ref_o['ray_mask'].numpy()[0])
+    assert np.array_equal(fi['ray_mask'][0, sel].cpu().numpy(), ref_o['ray_mask_fine'].numpy()[0])
