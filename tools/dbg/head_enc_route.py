@@ -5,6 +5,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch.nn.functional as F
 from graspnerf_amd import backbone as BB
+BB.FOLD_UPSAMPLED_K5 = BB.STRIDE2_AS_S2D = False      # this tool measures the routes of the UNFOLDED module (round-4 history; the product folds, tools/dbg/head_train_prof.py)
 from graspnerf_amd.backbone import ConvNet
 
 ORIG = BB._Encoder.forward

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from graspnerf_amd.backbone import ConvNet
 import torch.nn.functional as F
 from graspnerf_amd import backbone as BB
+BB.FOLD_UPSAMPLED_K5 = BB.STRIDE2_AS_S2D = False      # this tool measures the routes of the UNFOLDED module (round-4 history; the product folds, tools/dbg/head_train_prof.py)
 
 
 def _route(mode):
