@@ -341,7 +341,7 @@ def train_leg(args, world, rank, dev, dist, sync):
     from graspnerf_amd.trainer import Trainer
     n = args.train_scenes
     net = build_model(dev)
-    tr = Trainer(net)
+    tr = Trainer(net, log_every=args.train_log_step)
     scenes = train_scenes(n, rank * n, dev)
     torch.cuda.reset_peak_memory_stats(dev)
     for _ in range(args.train_warmup):
@@ -365,10 +365,22 @@ def train_leg(args, world, rank, dev, dist, sync):
         host.append((time.perf_counter() - h0) * 1e3)
         marks[i + 1].record()                              # per-step spans on the stream (no synchronisation added)
     sync()
+    log = tr.last_log()                                    # the terms of the last timed step (on a logging step step() returned them itself)
     dt = max_over_ranks(time.perf_counter() - t0, dev)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.train_steps)]
     table = _lib.timing_end() if rank == 0 else {}
     K = args.train_steps
+    # the same steps with the loss terms read back at the end of EVERY step (log_every = 1: what a per-step progress bar costs,
+    # trainer.py:190 of the reference): eight steps, reported next to the headline, not in it
+    every = tr.log_every
+    tr.log_every = 1
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(8):
+        tr.step(scenes)
+    sync()
+    ms_log1 = max_over_ranks(time.perf_counter() - t1, dev) / 8 * 1e3
+    tr.log_every = every
     # per-kernel table of the library: two further steps with every launch bracketed (outside the timed region: ~60 event
     # pairs per step would perturb it)
     if rank == 0:
@@ -389,7 +401,7 @@ def train_leg(args, world, rank, dev, dist, sync):
         rec = {
             'metric': 'train scenes/sec (fwd + losses + bwd + gradient all-reduce + Adam), 6-view 40^3 grid + 512 rays x (40+40)',
             'value': round(world * n * K / dt, 3), 'unit': 'scenes/s', 'ms_per_step': round(dt / K * 1e3, 3), 'steps': K,
-            'warmup': args.train_warmup, 'scenes_per_gpu': n, 'global_batch': world * n, 'n_gpus': world, 'dtype': 'f32', 'data': 'synthetic',
+            'warmup': args.train_warmup, 'log_every': args.train_log_step, 'ms_per_step_with_log_every_1': round(ms_log1, 3), 'scenes_per_gpu': n, 'global_batch': world * n, 'n_gpus': world, 'dtype': 'f32', 'data': 'synthetic',
             'config': 'BASELINE.json configs[4]: backbones + nr TSDF + render + depth-mean head + grasp head + losses (render, depth, sdf, vgn), '
                       'batch 8/GPU, one flat fp32 gradient all-reduce (4.66 M parameters), Adam',
             'ms_each_step': [round(x, 2) for x in step_ms], 'ms_per_step_median': round(float(np.median(step_ms)), 3),
@@ -519,6 +531,7 @@ def main():
     ap.add_argument('--no-f32-build', action='store_true', help='skip timing the fp32-MFMA companion build next to the product')
     ap.add_argument('--train-scenes', type=int, default=8)
     ap.add_argument('--train-steps', type=int, default=16, help='timed steps of the train_step record (16: one stalled step moves the mean by 5 %, not 12)')
+    ap.add_argument('--train-log-step', type=int, default=20, help="the loss terms leave the device every N-th step, the reference's train_log_step (trainer.py:31,159: 20); 1 = a device-to-host copy the host waits for at the end of EVERY step (what the reference's progress bar does, trainer.py:190)")
     ap.add_argument('--train-warmup', type=int, default=24, help='the caching allocators and MIOpen (solvers compiled on their first uses) settle over ~20 steps: profiles/r03_d, r03_f show stalled steps up to the 13th')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (the product); gloo only with --stub-step-ms')
     ap.add_argument('--stub-step-ms', type=float, default=0.0, help='> 0: no GPU, a step is a sleep of this length (control-flow test of the N > 1 branches)')

@@ -44,9 +44,16 @@ def exp_decay_lr(step, lr_init=1e-4, decay_step=100000, decay_rate=0.5, lr_min=1
 
 
 class Trainer:
-    def __init__(self, net, lr_cfg=None, batched=True):
+    def __init__(self, net, lr_cfg=None, batched=True, log_every=1):
+        """log_every: the loss terms leave the device every log_every-th step only (the reference writes its log every
+        `train_log_step` = 20 steps, trainer.py:31,159; what it reads back EVERY step is the loss shown in its progress bar, :190).  With
+        log_every = 1 every step() returns floats -- and ends in a device-to-host copy the host waits for, so the queue of the next step
+        starts empty: the GPU idles while the host launches its first kernels, every step.  In between step() returns only `lr`; the terms
+        of the latest step stay on the device until last_log() asks for them."""
         self.net = net
         self.batched = batched
+        self.log_every = max(int(log_every), 1)
+        self._pending = None
         self.lr_cfg = lr_cfg or {}
         self.params = [p for p in net.parameters()]
         self.optimizer = torch.optim.Adam(self.params, lr=1e-3)            # lr_common_manager.py:9-13
@@ -108,10 +115,20 @@ class Trainer:
             return {'lr': lr}
         if isinstance(all_terms, dict):                    # [B] vectors: the mean over the local scenes is the mean of each
             keys = list(all_terms)
-            means = torch.stack([all_terms[k].detach().float().mean() for k in keys]).tolist()
+            means = torch.stack([all_terms[k].detach().float().mean() for k in keys])
         else:
             keys = list(all_terms[0])
-            means = torch.stack([torch.stack([t[k].detach().float().mean() for k in keys]) for t in all_terms]).mean(0).tolist()
-        log = dict(zip(keys, means))
+            means = torch.stack([torch.stack([t[k].detach().float().mean() for k in keys]) for t in all_terms]).mean(0)
+        self._pending = (keys, means, lr)
+        if self.step_id % self.log_every:                  # not a logging step: nothing leaves the device, the host runs on
+            return {'lr': lr}
+        return self.last_log()
+
+    def last_log(self):
+        """Loss terms of the latest step as floats (one device-to-host copy; the only synchronisation of a step)."""
+        if self._pending is None:
+            return {}
+        keys, means, lr = self._pending
+        log = dict(zip(keys, means.tolist()))
         log['lr'] = lr
         return log

@@ -232,6 +232,28 @@ def test_optimizer_step_changes_parameters_and_reduces_loss():
     assert tr.step_id == 2 and l0['lr'] == 1e-3
 
 
+def test_loss_terms_leave_the_device_on_logging_steps_only():
+    """Trainer(log_every=N), the reference's train_log_step (trainer.py:31,159): step() returns the terms as floats every N-th step and
+    only `lr` in between (no device-to-host copy: the host is free to queue the next step); last_log() reads the latest terms on demand,
+    and the parameter updates do not depend on the cadence."""
+    from graspnerf_amd.trainer import Trainer
+    data = scene_data()
+    runs = {}
+    for every in (1, 3):
+        net = build()
+        tr = Trainer(net, {'lr_init': 1e-3}, log_every=every)
+        logs = []
+        for i in range(3):
+            torch.manual_seed(10 + i)
+            logs.append(tr.step([data]))
+        runs[every] = (logs, tr.last_log(), [p.detach().clone() for p in net.parameters()])
+    l1, l3 = runs[1][0], runs[3][0]
+    assert all(any(k.startswith('loss') for k in l) for l in l1)
+    assert set(l3[0]) == {'lr'} and set(l3[1]) == {'lr'} and set(l3[2]) == set(l1[2])
+    assert l3[2] == l1[2] == runs[3][1] == runs[1][1]
+    assert all(torch.equal(a, b) for a, b in zip(runs[1][2], runs[3][2]))
+
+
 def test_trainer_with_several_scenes_on_cpu_uses_the_per_scene_loop():
     """Off the GPU forward_scenes() declines (None) and the trainer runs forward + backward scene by scene."""
     from graspnerf_amd.trainer import Trainer

@@ -54,7 +54,7 @@ net = GraspNeRF(CFG)
 syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
 net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
 net = net.to(dev)
-tr = Trainer(net)
+tr = Trainer(net, log_every=int(os.environ.get('LOG_EVERY', 20)))   # the reference's train_log_step (trainer.py:31)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 scenes = []
 for i in range(a.scenes):
