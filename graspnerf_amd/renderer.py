@@ -330,6 +330,7 @@ class NeuralRayRenderer(nn.Module):
         Needed only after in-place writes that bypass autograd's version counters (p.data.copy_, EMA swaps through .data)."""
         self._hot_ver = None
         self._repack_pending = None
+        self.__dict__.pop('_param_dict', None)
 
     def hot(self):
         """The HIP path with weights packed from the CURRENT parameter values: re-packed whenever a parameter was updated in
@@ -486,7 +487,13 @@ class NeuralRayRenderer(nn.Module):
                                 'there is no PyTorch / CPU fallback')
 
     def _params(self):
-        return dict(self.named_parameters())
+        """name -> Parameter of this module tree.  Cached (named_parameters() walks ~1 000 modules, several times per training step:
+        2 ms of a step's host time); the Parameter OBJECTS are stable across optimizer steps, and whatever replaces them -- _apply
+        (device / dtype moves), load_state_dict, invalidate_packed() -- drops the cache together with the packed weights."""
+        d = self.__dict__.get('_param_dict')
+        if d is None or self._hot is None:
+            d = self.__dict__['_param_dict'] = dict(self.named_parameters())
+        return d
 
     def _train_pass(self, hot, prep, que_b, depth, level, want_fine_depth, ray_feats, img_feats, P):
         """One render pass (renderer.py:90-138) of B scenes in training mode: per-view chain -> per-ray tail -> NeuS alpha /

@@ -81,7 +81,8 @@ class Trainer:
         """scenes: list of `data` dicts (this rank's share of the global batch).  Gradients of the per-scene total
         losses are accumulated, all-reduced, averaged over the global scene count; one Adam update.
         -> dict of loss terms averaged over the local scenes, lr."""
-        self.net.train()
+        if not self.net.training:                           # (train() walks every sub-module: not every step)
+            self.net.train()
         lr = exp_decay_lr(self.step_id, **self.lr_cfg)
         for g in self.optimizer.param_groups:
             g['lr'] = lr
