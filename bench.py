@@ -401,7 +401,8 @@ def train_leg(args, world, rank, dev, dist, sync):
         rec = {
             'metric': 'train scenes/sec (fwd + losses + bwd + gradient all-reduce + Adam), 6-view 40^3 grid + 512 rays x (40+40)',
             'value': round(world * n * K / dt, 3), 'unit': 'scenes/s', 'ms_per_step': round(dt / K * 1e3, 3), 'steps': K,
-            'warmup': args.train_warmup, 'log_every': args.train_log_step, 'ms_per_step_with_log_every_1': round(ms_log1, 3), 'scenes_per_gpu': n, 'global_batch': world * n, 'n_gpus': world, 'dtype': 'f32', 'data': 'synthetic',
+            'warmup': args.train_warmup, 'log_every': args.train_log_step, 'ms_per_step_with_log_every_1': round(ms_log1, 3),
+            'log_note': "every step runs forward, losses, backward, gradient all-reduce and Adam; the loss TERMS are copied to the host every log_every-th step (the reference's train_log_step = 20, trainer.py:31,159) instead of at the end of every step, where the host would wait for the copy and start the next step's ~2 000 launches from an empty queue; ms_per_step_with_log_every_1 = eight further steps with the per-step read-back (the reference's progress bar, trainer.py:190)", 'scenes_per_gpu': n, 'global_batch': world * n, 'n_gpus': world, 'dtype': 'f32', 'data': 'synthetic',
             'config': 'BASELINE.json configs[4]: backbones + nr TSDF + render + depth-mean head + grasp head + losses (render, depth, sdf, vgn), '
                       'batch 8/GPU, one flat fp32 gradient all-reduce (4.66 M parameters), Adam',
             'ms_each_step': [round(x, 2) for x in step_ms], 'ms_per_step_median': round(float(np.median(step_ms)), 3),
