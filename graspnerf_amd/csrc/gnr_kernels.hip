@@ -1926,5 +1926,14 @@ __global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restri
 
 }  // namespace gnr
 
+#ifndef GNR_PROTO_P1
+#define GNR_PROTO_P1 0          // 1: measurement builds with the phase-1 prototype of the 8-point x (view pair) tile (gnr_chain_p1.inc)
+#endif
+#if GNR_PROTO_P1
+#include "gnr_chain_p1.inc"
+#endif
 #include "gnr_bwd.inc"
 #include "gnr_capi.inc"
+#if GNR_PROTO_P1
+#include "gnr_chain_p1_capi.inc"
+#endif
