@@ -73,6 +73,9 @@ def lib():
     L.gnr_pack_vis_decoder_bwd.argtypes = [c_float_p, c_float_p]
     L.gnr_pack_vis_decoder_bwd.restype = C.c_int
     L.gnr_canonical_vis_floats.restype = C.c_int
+    for name in ('gnr_pack_weights_device', 'gnr_pack_weights_bwd_device', 'gnr_pack_vis_decoder_device', 'gnr_pack_vis_decoder_bwd_device'):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        getattr(L, name).restype = C.c_int
     L.gnr_layout_offset.argtypes = [C.c_char_p]
     L.gnr_layout_offset.restype = C.c_int
     L.gnr_workspace_bytes.argtypes = [C.POINTER(GnrScene), C.c_int, C.c_int, C.c_int]
@@ -213,7 +216,7 @@ def lib():
     return L
 
 
-EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_pack_vis_decoder', 'gnr_pack_vis_decoder_bwd', 'gnr_canonical_vis_floats', 'gnr_layout_offset', 'gnr_workspace_bytes',
+EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_pack_vis_decoder', 'gnr_pack_vis_decoder_bwd', 'gnr_canonical_vis_floats', 'gnr_pack_weights_device', 'gnr_pack_weights_bwd_device', 'gnr_pack_vis_decoder_device', 'gnr_pack_vis_decoder_bwd_device', 'gnr_layout_offset', 'gnr_workspace_bytes',
             'gnr_prepare', 'gnr_range_status', 'gnr_force_fp32_chain', 'gnr_debug_ray_order', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',

@@ -188,8 +188,9 @@ GNR_HD inline C16Plan c16_plan(int n) {
 }
 constexpr int C16_PLANS_ALL = 19;
 
-// fp32 fragment of one layer (src) -> its C16 form at dst (the padded tails of short blocks are NOT written: zero by construction
-// of the blob).  *bad is set to 1.f when a weight is outside the fp16 range.
+// fp32 fragment of one layer (src) -> its C16 form at dst; EVERY float of the slot's pair blocks and left-over fragment is written
+// (zero-padded tails of short blocks included).  *bad0 / *bad1 are set to 1.f when a weight is outside the fp16 range (its
+// pair is left zero).
 template <class Ex>
 GNR_HD void to_pairs(const Ex& ex, float* dst, const float* src, const C16Plan& pl, float* bad0, float* bad1) {
     const int NB = pl.NB;
@@ -197,25 +198,34 @@ GNR_HD void to_pairs(const Ex& ex, float* dst, const float* src, const C16Plan& 
     int pos = 0;                                                                 // floats
     for (int b = 0; b < pl.nblk; ++b) {
         const int n = pl.kn[b], k0 = pl.k0[b];
-        ex.run(NB * 64 * n, [&](int t) {
+        ex.run(NB * 64 * 8, [&](int t) {
 #pragma clang fp contract(off)
-            const int i = t % n, lane = (t / n) & 63, nb = (t / n) >> 6;
-            const float w = src[frag_index(NB, k0 + i, nb, lane)];
-            const uint16_t h = f32_to_f16(w);
-            bool fin;
-            const float hf = f16_to_f32(h, fin);
-            if (!fin) { *bad0 = 1.f; *bad1 = 1.f; return; }
+            const int i = t & 7, lane = (t >> 3) & 63, nb = t >> 9;
+            uint16_t h = 0, m = 0;
+            if (i < n) {
+                const float w = src[frag_index(NB, k0 + i, nb, lane)];
+                const uint16_t hh = f32_to_f16(w);
+                bool fin;
+                const float hf = f16_to_f32(hh, fin);
+                if (fin) { h = hh; m = f32_to_f16((w - hf) * 2048.f); }
+                else { *bad0 = 1.f; *bad1 = 1.f; }
+            }
             uint16_t* base = o16 + 2 * pos;
             base[((nb * 2 + 0) * 64 + lane) * 8 + i] = h;
-            base[((nb * 2 + 1) * 64 + lane) * 8 + i] = f32_to_f16((w - hf) * 2048.f);
+            base[((nb * 2 + 1) * 64 + lane) * 8 + i] = m;
         });
         pos += pk::k32_floats(NB);
     }
     const int Jr = pl.nrest;
-    ex.run(Jr * NB * 64, [&](int t) {
-        const int lane = t & 63, nb = (t >> 6) % NB, jr = (t >> 6) / NB;
-        dst[pos + frag_index(NB, jr, nb, lane)] = src[frag_index(NB, pl.rest[jr], nb, lane)];
-    });
+    if (Jr > 0) {
+        ex.run(frag_floats(Jr, NB), [&](int t) {                                   // every float of the left-over fragment
+            int jr, nb, lane;
+            if (NB == 1) { jr = (t >> 8) * 4 + (t & 3); lane = (t >> 2) & 63; nb = 0; }
+            else if (NB == 3) { jr = t >> 8; lane = (t >> 2) & 63; nb = t & 3; }
+            else { nb = t % NB; lane = (t / NB) & 63; jr = (t / NB) >> 6; }
+            dst[pos + t] = (jr < Jr && nb < NB) ? src[frag_index(NB, pl.rest[jr], nb, lane)] : 0.f;
+        });
+    }
 }
 
 // C16 image, step 1: the CHAIN section's slots copied to their places (two slots grown, gnr_layout.h c16_off)

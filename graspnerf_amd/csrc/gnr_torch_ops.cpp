@@ -12,6 +12,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>      // the ROCm build of PyTorch presents HIP devices / streams under the "cuda" device type
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
+#include <torch/csrc/autograd/autograd_not_implemented_fallback.h>
 
 #include <tuple>
 #include <vector>
@@ -34,6 +35,15 @@ Tensor f32(const Tensor& t, const char* name) {
     return t.contiguous();
 }
 
+// every further argument lives on the scene's device and has the size the C ABI will read (the entry points take raw pointers:
+// a short or misplaced tensor would be an out-of-bounds device read, not an error)
+Tensor arg(const Tensor& t, const char* name, const Tensor& ref, int64_t numel) {
+    Tensor c = f32(t, name);
+    TORCH_CHECK(c.device() == ref.device(), "graspnerf ops: ", name, " is on ", c.device(), ", the scene on ", ref.device());
+    TORCH_CHECK(numel < 0 || c.numel() == numel, "graspnerf ops: ", name, " has ", c.numel(), " elements, expected ", numel);
+    return c;
+}
+
 struct Scene {
     Tensor imgs, img_feats, ray_feats, poses, Ks, depth_range;
     GnrScene s;
@@ -43,7 +53,9 @@ Scene make_scene(const Tensor& imgs, const Tensor& img_feats, const Tensor& ray_
                  const Tensor& depth_range, bool use_vis) {
     Scene sc{f32(imgs, "imgs"), f32(img_feats, "img_feats"), f32(ray_feats, "ray_feats"), f32(poses, "poses"), f32(Ks, "Ks"),
              f32(depth_range, "depth_range"), {}};
-    TORCH_CHECK(sc.imgs.dim() == 5 && sc.img_feats.dim() == 5 && sc.ray_feats.sizes() == sc.img_feats.sizes(), "graspnerf ops: imgs [B,V,3,H,W], feats [B,V,32,fh,fw]");
+    for (const Tensor* t : {&sc.img_feats, &sc.ray_feats, &sc.poses, &sc.Ks, &sc.depth_range})
+        TORCH_CHECK(t->device() == sc.imgs.device(), "graspnerf ops: every scene tensor must be on ", sc.imgs.device(), " (found ", t->device(), ")");
+    TORCH_CHECK(sc.imgs.dim() == 5 && sc.imgs.size(2) == 3 && sc.img_feats.dim() == 5 && sc.ray_feats.sizes() == sc.img_feats.sizes(), "graspnerf ops: imgs [B,V,3,H,W], feats [B,V,32,fh,fw]");
     const int B = (int)sc.imgs.size(0), V = (int)sc.imgs.size(1);
     TORCH_CHECK(sc.img_feats.size(0) == B && sc.img_feats.size(1) == V && sc.img_feats.size(2) == 32, "graspnerf ops: feature maps must be [B,V,32,fh,fw]");
     TORCH_CHECK(sc.poses.numel() == (int64_t)B * V * 12 && sc.Ks.numel() == (int64_t)B * V * 9 && sc.depth_range.numel() == (int64_t)B * V * 2, "graspnerf ops: poses [B,V,3,4], Ks [B,V,3,3], depth_range [B,V,2]");
@@ -58,8 +70,7 @@ Tensor sample_volume(const Tensor& imgs, const Tensor& img_feats, const Tensor& 
                      const Tensor& depth_range, const Tensor& bbox_min, const Tensor& weights, int64_t res, bool use_vis) {
     c10::DeviceGuard guard(imgs.device());
     Scene sc = make_scene(imgs, img_feats, ray_feats, poses, Ks, depth_range, use_vis);
-    const Tensor bb = f32(bbox_min, "bbox_min"), w = f32(weights, "weights");
-    TORCH_CHECK(bb.numel() == (int64_t)sc.s.B * 3, "graspnerf::sample_volume: bbox_min [B,3]");
+    const Tensor bb = arg(bbox_min, "bbox_min [B,3]", sc.imgs, (int64_t)sc.s.B * 3), w = arg(weights, "weights (packed level blob)", sc.imgs, gnr_packed_weights_floats());
     const size_t wsb = gnr_workspace_bytes(&sc.s, (int)res, 0, 0);
     Tensor ws = bytes(wsb, sc.imgs);
     void* st = cur_stream(sc.imgs);
@@ -91,12 +102,15 @@ std::vector<Tensor> render_rays(const Tensor& imgs, const Tensor& img_feats, con
                                 int64_t ray_batch_num, bool fine_depth_use_all, bool use_vis) {
     c10::DeviceGuard guard(imgs.device());
     Scene sc = make_scene(imgs, img_feats, ray_feats, poses, Ks, depth_range, use_vis);
-    const Tensor co = f32(coords, "coords"), qp = f32(que_pose, "que_pose"), qk = f32(que_K, "que_K"), qd = f32(que_depth_range, "que_depth_range");
-    const Tensor wc = f32(weights_coarse, "weights_coarse"), wf = f32(weights_fine, "weights_fine");
+    const Tensor co = arg(coords, "coords", sc.imgs, -1);
     TORCH_CHECK(co.dim() == 3 && co.size(0) == sc.s.B && co.size(2) == 2, "graspnerf::render_rays: coords [B,rn,2]");
     const int B = sc.s.B, rn = (int)co.size(1);
+    const Tensor qp = arg(que_pose, "que_pose [B,3,4]", sc.imgs, (int64_t)B * 12), qk = arg(que_K, "que_K [B,3,3]", sc.imgs, (int64_t)B * 9),
+                 qd = arg(que_depth_range, "que_depth_range [B,2]", sc.imgs, (int64_t)B * 2);
+    const Tensor wc = arg(weights_coarse, "weights_coarse (packed level blob)", sc.imgs, gnr_packed_weights_floats()),
+                 wf = arg(weights_fine, "weights_fine (packed level blob)", sc.imgs, gnr_packed_weights_floats());
     Tensor qi;
-    if (que_imgs.has_value() && que_imgs->defined()) qi = f32(*que_imgs, "que_imgs");
+    if (que_imgs.has_value() && que_imgs->defined()) qi = arg(*que_imgs, "que_imgs [B,3,H,W]", sc.imgs, (int64_t)B * 3 * sc.s.H * sc.s.W);
     GnrRays rays{rn, (int)dn, (int)fdn, (int)ray_mask_view_num, (int)ray_mask_point_num, fp(co), fp(qp), fp(qk), fp(qd),
                  qi.defined() ? fp(qi) : nullptr, nullptr, (int)ray_batch_num, fine_depth_use_all ? 1 : 0};
     const int fine_dn = fine_depth_use_all ? (int)(dn + fdn) : (int)fdn;
@@ -118,7 +132,7 @@ std::tuple<Tensor, Tensor, Tensor> sample_volume_train(const Tensor& imgs, const
                                                        int64_t res, bool use_vis) {
     c10::DeviceGuard guard(imgs.device());
     Scene sc = make_scene(imgs, img_feats, ray_feats, poses, Ks, depth_range, use_vis);
-    const Tensor bb = f32(bbox_min, "bbox_min"), w = f32(weights, "weights");
+    const Tensor bb = arg(bbox_min, "bbox_min [B,3]", sc.imgs, (int64_t)sc.s.B * 3), w = arg(weights, "weights (packed level blob)", sc.imgs, gnr_packed_weights_floats());
     const size_t wsb = gnr_workspace_bytes(&sc.s, (int)res, 0, 0), twb = gnr_sample_volume_train_workspace_bytes(&sc.s, (int)res);
     TORCH_CHECK(twb > 0, "graspnerf::sample_volume_train: bad volume resolution");
     Tensor ws = bytes(wsb, sc.imgs), tws = bytes(twb, sc.imgs);
@@ -136,9 +150,14 @@ std::tuple<Tensor, Tensor, Tensor> sample_volume_bwd(const Tensor& imgs, const T
                                                      const Tensor& canonical, int64_t res, bool use_vis) {
     c10::DeviceGuard guard(imgs.device());
     Scene sc = make_scene(imgs, img_feats, ray_feats, poses, Ks, depth_range, use_vis);
-    const Tensor dv = f32(dvol, "dvol"), w = f32(weights, "weights"), wb = f32(weights_bwd, "weights_bwd"), can = f32(canonical, "canonical");
-    TORCH_CHECK(ws.is_cuda() && tws.is_cuda() && ws.scalar_type() == at::kByte && tws.scalar_type() == at::kByte, "graspnerf::sample_volume_bwd: ws / tws are the byte tensors sample_volume_train returned");
     const int n = gnr_canonical_weights_floats() + (use_vis ? gnr_canonical_vis_floats() : 0);
+    const Tensor dv = arg(dvol, "dvol [B,1,R,R,R]", sc.imgs, (int64_t)sc.s.B * res * res * res), w = arg(weights, "weights (packed level blob)", sc.imgs, gnr_packed_weights_floats()),
+                 wb = arg(weights_bwd, "weights_bwd (gnr_pack_weights_bwd blob)", sc.imgs, gnr_packed_bwd_floats()),
+                 can = arg(canonical, "canonical (the level's canonical blob)", sc.imgs, gnr_canonical_weights_floats());
+    TORCH_CHECK(ws.is_cuda() && tws.is_cuda() && ws.scalar_type() == at::kByte && tws.scalar_type() == at::kByte && ws.is_contiguous() && tws.is_contiguous() &&
+                ws.device() == sc.imgs.device() && tws.device() == sc.imgs.device(), "graspnerf::sample_volume_bwd: ws / tws are the byte tensors sample_volume_train returned");
+    TORCH_CHECK((size_t)ws.numel() >= gnr_workspace_bytes(&sc.s, (int)res, 0, 0) && (size_t)tws.numel() >= gnr_sample_volume_train_workspace_bytes(&sc.s, (int)res),
+                "graspnerf::sample_volume_bwd: ws / tws are smaller than this scene and resolution need");
     Tensor dcan = at::zeros({n}, sc.imgs.options());
     Tensor dray = at::empty_like(sc.ray_feats), dimg = at::empty_like(sc.img_feats);
     ok(gnr_sample_volume_bwd(&sc.s, (int)res, fp(w), fp(wb), fp(can), fp(dv), dcan.data_ptr<float>(), dray.data_ptr<float>(), dimg.data_ptr<float>(),
@@ -167,4 +186,16 @@ TORCH_LIBRARY_IMPL(graspnerf, CUDA, m) {          // the ROCm build of PyTorch d
     m.impl("render_rays", &render_rays);
     m.impl("sample_volume_train", &sample_volume_train);
     m.impl("sample_volume_bwd", &sample_volume_bwd);
+}
+
+// Only the backend kernels above exist: an input that requires grad must not come back as an output that silently carries none.
+// The Autograd key gets PyTorch's "not implemented" kernel: the forward runs, the outputs are marked, and a backward through them
+// raises.  (Differentiating the path is the job of the autograd.Functions of graspnerf_amd/renderer.py, which pair
+// sample_volume_train with sample_volume_bwd and hand the canonical-blob gradient to the parameters; the packed `weights` blob an
+// operator sees is not a differentiable function of anything the dispatcher knows.)
+TORCH_LIBRARY_IMPL(graspnerf, Autograd, m) {
+    m.impl("sample_volume", torch::autograd::autogradNotImplementedFallback());
+    m.impl("render_rays", torch::autograd::autogradNotImplementedFallback());
+    m.impl("sample_volume_train", torch::autograd::autogradNotImplementedFallback());
+    m.impl("sample_volume_bwd", torch::autograd::autogradNotImplementedFallback());
 }

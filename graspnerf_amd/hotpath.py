@@ -166,9 +166,21 @@ class HotPath:
         return s, o
 
     def render(self, ref, que, cfg=None, fine_depth_in=None, debug=False, prepared=None):
-        """-> (coarse dict, fine dict[, fine_inds]) of device tensors with a leading batch dim."""
+        """-> (coarse dict, fine dict[, fine_inds]) of device tensors with a leading batch dim.  cfg use_hierarchical_sampling false
+        (renderer.py:153-162): the coarse pass only, fine dict = None."""
         cfg = cfg or {}
         dn, fdn = cfg.get('depth_sample_num', 40), cfg.get('fine_depth_sample_num', 40)
+        if not cfg.get('use_hierarchical_sampling', True):
+            if fine_depth_in is not None or debug:
+                raise _lib.GnrError('render(): fine depths / resampling indices need use_hierarchical_sampling')
+            B, rn = que['coords'].shape[:2]
+            scene, keep, ws = prepared or self.prepare(ref, 1, rn, dn)
+            rays, rkeep = self._rays(que, dn, fdn, cfg, scene.H, scene.W)
+            co_s, co = self._alloc_out(B, rn, dn, 'imgs' in que, False, rays.ray_batch_num)
+            _lib.check(self.L.gnr_render_rays_fwd(C.byref(scene), C.byref(rays), self.wc.data_ptr(), None, C.byref(co_s), None, None, None,
+                                                  ws.data_ptr(), ws.numel(), self._stream()), 'gnr_render_rays_fwd')
+            co['ray_mask'] = co['ray_mask'].bool()
+            return co, None
         if self.wf is None:
             raise _lib.GnrError('render() needs the fine-level weights')
         B, rn = que['coords'].shape[:2]
@@ -248,8 +260,8 @@ class HotPath:
         _lib.check(self.L.gnr_sample_volume_fwd_train(C.byref(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(), vol.data_ptr(),
                                                       ws.data_ptr(), ws.numel(), self._tws.data_ptr(), self._tws.numel(),
                                                       self._stream()), 'gnr_sample_volume_fwd_train')
-        self._train_ctx = (scene, keep, ws, res)
-        return vol
+        self._train_ctx = (scene, keep, ws, res, self._tws)     # the saved states travel with the context: a release_training_workspaces()
+        return vol                                               # (net.eval()) between this forward and its backward cannot take them away
 
     def train_ws_section(self, name, scene, res):
         """Float view of one section of the training workspace (tests): save1 save2 saveG dg16 dS2 dG dS1 dfeat64 dtail."""
@@ -262,7 +274,7 @@ class HotPath:
 
     def sample_volume_bwd(self, dvol, canonical_dev, stages=0x1f, want_feat_grads=True):
         """Backward of the last sample_volume_train: dvol [B,1,R,R,R] -> (d_canonical [36958], d_ray_feats, d_img_feats)."""
-        scene, keep, ws, res = self._train_ctx
+        scene, keep, ws, res, tws = self._train_ctx
         dvol = _f32(dvol, self.device)
         dcan = torch.zeros(self.L.gnr_canonical_weights_floats() + (self.L.gnr_canonical_vis_floats() if self.use_vis else 0), dtype=torch.float32, device=self.device)
         shp = (scene.B, scene.V, 32, scene.fh, scene.fw)
@@ -272,7 +284,7 @@ class HotPath:
                                                 canonical_dev.data_ptr(), dvol.data_ptr(), dcan.data_ptr(),
                                                 dray.data_ptr() if want_feat_grads else None,
                                                 dimg.data_ptr() if want_feat_grads else None, ws.data_ptr(), ws.numel(),
-                                                self._tws.data_ptr(), self._tws.numel(), stages, self._stream()),
+                                                tws.data_ptr(), tws.numel(), stages, self._stream()),
                    'gnr_sample_volume_bwd')
         return dcan, dray, dimg
 

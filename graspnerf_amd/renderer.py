@@ -268,16 +268,19 @@ class NeuralRayRenderer(nn.Module):
         c = self.cfg
         unsupported = [k for k, ok in (
             ('agg_net_type', c['agg_net_type'] == 'neus'), ('init_net_type', c['init_net_type'] == 'cost_volume'),
-            ('use_hierarchical_sampling', bool(c['use_hierarchical_sampling'])),
             # the reference evaluates the fine level with the COARSE decoder's compute_prob (renderer.py:70-72): mixed settings
             # either crash there (None * tensor) or silently ignore the fine branch
             ('dist_decoder_cfg.use_vis != fine_dist_decoder_cfg.use_vis',
+             not c['use_hierarchical_sampling'] or
              bool(c['dist_decoder_cfg'].get('use_vis', True)) == bool(c['fine_dist_decoder_cfg'].get('use_vis', True))),
             ('disable_view_dir', not c['disable_view_dir']),
             ('volume_type', list(c.get('volume_type', ['sdf'])) == ['sdf'])) if not ok]
         if unsupported:
             # Not configured by the reference's only yaml.  disable_view_dir cannot run in the reference either with
-            # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None).
+            # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None), and volume_type ['alpha'] raises in the
+            # reference's own call (renderer.py:190 -> network_rendering :100 "ValueError: too many values to unpack (expected 2)":
+            # the neus aggregation returns five values; recorded by tools/make_goldens.py --no-hier-only in
+            # tests/golden/golden_full_cfg1_nohier.npz 'volume_type_alpha'); 'image' reads prj_dict before it exists (:185).
             raise NotImplementedError(f'config options outside configs/nrvgn_sdf.yaml are not built: {unsupported}')
         if c['fine_depth_use_all']:
             # renderer.py:145-146: the fine pass renders the coarse and the resampled depths together.  The reference adds its
@@ -293,8 +296,11 @@ class NeuralRayRenderer(nn.Module):
         self.image_encoder = ResUNetLight(3, [1, 2, 6, 4], 32, inplanes=16)
         self.init_net = CostVolumeInitNet(c['init_net_cfg'])
         self.agg_net = _AggNetParams(c['agg_net_cfg'])
-        self.fine_dist_decoder = _DistDecoderParams(self.use_vis)
-        self.fine_agg_net = _AggNetParams(c['fine_agg_net_cfg'])
+        # renderer.py:56-58: the fine level's modules (and state-dict keys) exist only with hierarchical sampling
+        self.levels = ('coarse', 'fine') if c['use_hierarchical_sampling'] else ('coarse',)
+        if c['use_hierarchical_sampling']:
+            self.fine_dist_decoder = _DistDecoderParams(self.use_vis)
+            self.fine_agg_net = _AggNetParams(c['fine_agg_net_cfg'])
         self.use_sdf = True
         self._hot = None
 
@@ -318,9 +324,9 @@ class NeuralRayRenderer(nn.Module):
         ps = getattr(self, '_hot_params', None)
         if ps is None or self._hot is None:                  # (re)collected whenever the HotPath is rebuilt (_apply / load_state_dict)
             P = self._params()
-            ps = self._hot_params = [P[k] for lvl in ('coarse', 'fine') for k, _ in _w.level_keys(lvl)]
+            ps = self._hot_params = [P[k] for lvl in self.levels for k, _ in _w.level_keys(lvl)]
             if self.use_vis:
-                ps += [P[_w.LEVELS[lvl][0] + k] for lvl in ('coarse', 'fine') for k, _ in _w.VIS_KEYS]
+                ps += [P[_w.LEVELS[lvl][0] + k] for lvl in self.levels for k, _ in _w.VIS_KEYS]
         # (version, storage address): optimizer.step / copy_ / load_state_dict bump the version, `p.data = tensor` moves the
         # storage.  A write through `p.data.copy_()` / `p.data.mul_()` changes neither: call invalidate_packed() after such surgery.
         return tuple((p._version, p.data_ptr()) for p in ps)
@@ -329,36 +335,55 @@ class NeuralRayRenderer(nn.Module):
         """Forget the packed HIP copies of the hot-path weights: the next forward re-packs from the current parameter values.
         Needed only after in-place writes that bypass autograd's version counters (p.data.copy_, EMA swaps through .data)."""
         self._hot_ver = None
-        self._repack_pending = None
+        self._bwd_ver = None
         self.__dict__.pop('_param_dict', None)
 
+    def _vis_dev(self, sd, lvl):
+        """The vis_decoder's six tensors of a level (use_vis) as one flat device tensor, state-dict order."""
+        return torch.cat([sd[_w.LEVELS[lvl][0] + k].detach().reshape(-1).to(torch.float32) for k, _ in _w.VIS_KEYS])
+
+    def _repack_on_device(self, with_bwd):
+        """Packed copies of the CURRENT parameter values, built on the device (csrc/gnr_pack_dev.hip: the host packer's own
+        arithmetic, bit-identical blobs): the parameters are gathered into the level's canonical blob by one torch.cat and a
+        handful of stream-ordered kernels rewrite the packed blobs in place -- no device-to-host copy, no host-side pack, no
+        upload, and nothing the host waits for (the reference's parameters never leave the device either, trainer.py:146-158)."""
+        sd = self._params()
+        hot, L = self._hot, _lib.lib()
+        st = hot._stream()
+        can_dev = {lvl: _w.canonical_blob_device(sd, lvl, as_tensor=True) for lvl in self.levels}
+        vis = {lvl: self._vis_dev(sd, lvl) if self.use_vis else None for lvl in can_dev}
+        for lvl, blob in (('coarse', hot.wc), ('fine', hot.wf))[:len(self.levels)]:
+            _lib.check(L.gnr_pack_weights_device(can_dev[lvl].data_ptr(), blob.data_ptr(), st), 'gnr_pack_weights_device')
+            if vis[lvl] is not None:
+                _lib.check(L.gnr_pack_vis_decoder_device(vis[lvl].data_ptr(), blob.data_ptr(), st), 'gnr_pack_vis_decoder_device')
+        if with_bwd:
+            wb = getattr(hot, 'wb', None)
+            if wb is None or wb.get(self.levels[-1]) is None:
+                # first training forward: the backward blobs are created from host packs once (their structural zeros stay; the
+                # device packer rewrites the rest every step)
+                host = {lvl: t.cpu().numpy() for lvl, t in can_dev.items()}
+                hv = {lvl: None if vis[lvl] is None else vis[lvl].cpu().numpy() for lvl in vis}
+                hot.set_bwd_weights(*[_w.pack_bwd(host[lvl], hv[lvl]) for lvl in self.levels])
+            else:
+                for lvl in self.levels:
+                    _lib.check(L.gnr_pack_weights_bwd_device(can_dev[lvl].data_ptr(), wb[lvl].data_ptr(), st), 'gnr_pack_weights_bwd_device')
+                    if vis[lvl] is not None:
+                        _lib.check(L.gnr_pack_vis_decoder_bwd_device(vis[lvl].data_ptr(), wb[lvl].data_ptr(), st), 'gnr_pack_vis_decoder_bwd_device')
+            hot.can_dev = can_dev
+
     def hot(self):
-        """The HIP path with weights packed from the CURRENT parameter values: re-packed whenever a parameter was updated in
-        place since the last packing (an eval forward after optimizer.step() must not run on the previous weights)."""
+        """The HIP path with weights packed from the CURRENT parameter values: re-packed (on the device) whenever a parameter was
+        updated in place since the last packing (an eval forward after optimizer.step() must not run on the previous weights)."""
         ver = self._hot_versions()
         if self._hot is None:
             sd = self.state_dict()
             dev = next(self.parameters()).device
-            self._hot = HotPath(_w.pack_state_dict(sd, 'coarse'), _w.pack_state_dict(sd, 'fine'), device=dev)
+            self._hot = HotPath(*[_w.pack_state_dict(sd, lvl) for lvl in self.levels], device=dev)
             self._hot_ver = ver
         elif getattr(self, '_hot_ver', None) != ver:
-            sd = self._params()
-            if self.use_vis:                                 # (per-key host copies: inference-only configuration, rarely re-packed)
-                self._hot.wc.copy_(torch.from_numpy(_w.pack_state_dict(sd, 'coarse')))
-                self._hot.wf.copy_(torch.from_numpy(_w.pack_state_dict(sd, 'fine')))
-            else:
-                self._hot.wc.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'coarse'))))
-                self._hot.wf.copy_(torch.from_numpy(_w.pack(_w.canonical_blob_device(sd, 'fine'))))
+            self._repack_on_device(with_bwd=False)
             self._hot_ver = ver
         return self._hot
-
-    def _pinned(self, name, n):
-        """Persistent pinned staging buffers of the per-step weight re-pack (allocating pinned memory every step is a slow
-        path of the host allocator that can stall the queue)."""
-        bufs = self.__dict__.setdefault('_pin_bufs', {})
-        if name not in bufs or bufs[name].numel() != n:
-            bufs[name] = torch.empty(n, dtype=torch.float32, pin_memory=True)
-        return bufs[name]
 
     def _upload(self, name, host_tensor, dev):
         """Host tensor -> device through a persistent pinned staging buffer (one per name): `x.pin_memory()` every step
@@ -378,60 +403,24 @@ class NeuralRayRenderer(nn.Module):
         return out
 
     def repack_begin(self):
-        """First half of the per-step weight re-pack, to be called BEFORE the 2D backbones are queued: the canonical blobs of
-        both levels are gathered on the device and start their way to pinned host memory (stream-ordered, nothing waits).
-        hot_for_training() then finishes the job -- host-side packing + pinned, non-blocking uploads -- while the GPU works
-        on the backbones, instead of holding the GPU idle for it at the start of every step."""
-        sd = self._params()
-        up = getattr(self, '_repack_uploaded', None)
-        if up is not None:
-            up.synchronize()                                                # the staging buffers of the previous re-pack are free
-        can_dev = {lvl: _w.canonical_blob_device(sd, lvl, as_tensor=True) for lvl in ('coarse', 'fine')}
-        host = {lvl: self._pinned('can_' + lvl, t.numel()).copy_(t, non_blocking=True) for lvl, t in can_dev.items()}
-        ev = torch.cuda.Event()
-        ev.record()
-        self._repack_pending = (can_dev, host, ev, self._hot_versions())
+        """Kept for callers of the round-2..4 interface (the re-pack used to start its device-to-host copies here, ahead of the 2D
+        backbones, and finish on the host in hot_for_training()).  The packer runs on the device now: nothing to start early."""
+        return None
 
     def hot_for_training(self):
         """The HIP path with weights re-packed from the CURRENT parameter values (they move every optimiser step), plus
-        the transposed fragments of the backward twins."""
-        if getattr(self, '_repack_pending', None) is None or self._repack_pending[3] != self._hot_versions():
-            self.repack_begin()
-        can_dev, host, ev, ver = self._repack_pending
-        self._repack_pending = None
-        dev = next(self.parameters()).device
-        ev.synchronize()                                                    # the two 148 KB copies; queued ahead of the backbones
-        can = {lvl: t.numpy() for lvl, t in host.items()}
-
-        def up(name, a):                                                    # packed host array -> persistent pinned buffer
-            buf = self._pinned(name, a.size)
-            buf.numpy()[:] = a
-            return buf
-        vis = {'coarse': None, 'fine': None}
-        if self.use_vis:                                                    # non-default branch: its six tensors per level by per-key copies
-            sd = self._params()
-            vis = {lvl: _w.vis_blob(sd, lvl) for lvl in vis}
-
-        def fwd_pack(lvl):
-            out = _w.pack(can[lvl])
-            if vis[lvl] is not None:
-                _lib.check(_lib.lib().gnr_pack_vis_decoder(vis[lvl].ctypes.data_as(_lib.c_float_p), out.ctypes.data_as(_lib.c_float_p)), 'gnr_pack_vis_decoder')
-            return out
+        the transposed fragments of the backward twins -- all on the device, stream-ordered, without a host wait."""
+        ver = self._hot_versions()
         if self._hot is None:
-            self._hot = HotPath(fwd_pack('coarse'), fwd_pack('fine'), device=dev)
-        else:
-            self._hot.wc.copy_(up('wc', fwd_pack('coarse')), non_blocking=True)
-            self._hot.wf.copy_(up('wf', fwd_pack('fine')), non_blocking=True)
-        wb = getattr(self._hot, 'wb', None)
-        if wb is None or wb.get('fine') is None:
-            self._hot.set_bwd_weights(_w.pack_bwd(can['coarse'], vis['coarse']), _w.pack_bwd(can['fine'], vis['fine']))
-        else:
-            wb['coarse'].copy_(up('wbc', _w.pack_bwd(can['coarse'], vis['coarse'])), non_blocking=True)
-            wb['fine'].copy_(up('wbf', _w.pack_bwd(can['fine'], vis['fine'])), non_blocking=True)
-        self._repack_uploaded = torch.cuda.Event()
-        self._repack_uploaded.record()
-        self._hot.can_dev = can_dev
-        self._hot_ver = ver
+            sd = self.state_dict()
+            dev = next(self.parameters()).device
+            self._hot = HotPath(*[_w.pack_state_dict(sd, lvl) for lvl in self.levels], device=dev)
+            ver = self._hot_versions()
+            self._repack_on_device(with_bwd=True)            # creates the backward blobs (host pack, once) and can_dev
+        elif getattr(self, '_hot_ver', None) != ver or getattr(self._hot, 'wb', None) is None or self._hot.wb.get(self.levels[-1]) is None \
+                or getattr(self._hot, 'can_dev', None) is None or getattr(self, '_bwd_ver', None) != ver:
+            self._repack_on_device(with_bwd=True)
+        self._hot_ver = self._bwd_ver = ver
         return self._hot
 
     def _train_prep(self, ref_imgs_info, rn=0):
@@ -466,12 +455,15 @@ class NeuralRayRenderer(nn.Module):
     def _render_cfg(self):
         c = self.cfg
         return {'depth_sample_num': c['depth_sample_num'], 'fine_depth_sample_num': c['fine_depth_sample_num'],
+                'use_hierarchical_sampling': bool(c['use_hierarchical_sampling']),
                 'ray_mask_view_num': c['ray_mask_view_num'], 'ray_mask_point_num': c['ray_mask_point_num'],
                 'ray_batch_num': c['ray_batch_num'], 'fine_depth_use_all': bool(c['fine_depth_use_all'])}
 
     def _dn_max(self):
         """Most samples per ray of any render pass (workspace sizing)."""
         c = self.cfg
+        if not c['use_hierarchical_sampling']:
+            return c['depth_sample_num']
         fine = c['fine_depth_sample_num'] + (c['depth_sample_num'] if c['fine_depth_use_all'] else 0)
         return max(c['depth_sample_num'], fine)
 
@@ -546,8 +538,14 @@ class NeuralRayRenderer(nn.Module):
         chunk = self.cfg['ray_batch_num']
         parts = []
         for r0 in range(0, rn, chunk):
-            q = dict(que_b, coords=que_b['coords'][:, r0:r0 + chunk].contiguous(), fine_u=fine_u[:, r0:r0 + chunk].contiguous())
+            q = dict(que_b, coords=que_b['coords'][:, r0:r0 + chunk].contiguous())
+            if fine_u is not None:
+                q['fine_u'] = fine_u[:, r0:r0 + chunk].contiguous()
             n = q['coords'].shape[1]
+            if not self.cfg['use_hierarchical_sampling']:                   # renderer.py:153-162: the coarse pass's outputs only
+                coarse, ex = self._train_pass(hot, prep, q, None, 'coarse', False, ray_feats, img_feats, P)
+                parts.append(self._stacked(coarse, B, n))
+                continue
             coarse, ex = self._train_pass(hot, prep, q, None, 'coarse', True, ray_feats, img_feats, P)
             fine_depth = ex['fine_depth']
             if self.cfg['fine_depth_use_all']:                              # renderer.py:145-146: coarse and resampled depths together
@@ -569,12 +567,14 @@ class NeuralRayRenderer(nn.Module):
         hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref, que['coords'].shape[1])
         rn, chunk, fdn = que['coords'].shape[1], self.cfg['ray_batch_num'], self.cfg['fine_depth_sample_num']
         us = []
-        for r0 in range(0, rn, chunk):
-            us.append(torch.rand([1, min(chunk, rn - r0), fdn]))
-            for net in (self.agg_net, self.fine_agg_net):
+        hier = bool(self.cfg['use_hierarchical_sampling'])                  # without it the reference neither draws (sample_fine_depth is
+        for r0 in range(0, rn, chunk):                                      # not called) nor runs the fine aggregation net (its step stays)
+            if hier:
+                us.append(torch.rand([1, min(chunk, rn - r0), fdn]))
+            for net in ((self.agg_net, self.fine_agg_net) if hier else (self.agg_net,)):
                 net.train_step_bookkeeping()
         dev = ref['imgs'].device
-        fine_u = self._upload('fine_u1', torch.cat(us, 1), dev)
+        fine_u = self._upload('fine_u1', torch.cat(us, 1), dev) if hier else None
         bq = {'coords': que['coords'], 'pose': que['poses'], 'K': que['Ks'], 'depth_range': que['depth_range']}
         if 'imgs' in que:
             bq['imgs'] = que['imgs']
@@ -630,18 +630,21 @@ class NeuralRayRenderer(nn.Module):
             return self._render_autograd(que_imgs_info, ref_imgs_info, _prep)
         bref, prep = _prep or self._prepare(ref_imgs_info, rn)
         bque = self._batched_que(que_imgs_info)
+        hier = bool(self.cfg['use_hierarchical_sampling'])
         if is_train:
             # forward values only (no autograd through the HIP path).  The reference draws the
             # inverse-CDF samples per chunk with torch.rand on the CPU generator (render_ops.py:204-208): same
             # draws, same order, so a seeded run samples the same fine depths.
             fdn, chunk = self.cfg['fine_depth_sample_num'], self.cfg['ray_batch_num']
-            bque['fine_u'] = self.draw_fine_u(rn, fdn, chunk)
-            for net in (self.agg_net, self.fine_agg_net):          # aggregate_net.py:135-137 bookkeeping
+            if hier:
+                bque['fine_u'] = self.draw_fine_u(rn, fdn, chunk)
+            for net in ((self.agg_net, self.fine_agg_net) if hier else (self.agg_net,)):          # aggregate_net.py:135-137 bookkeeping
                 for _ in range((rn + chunk - 1) // chunk):
                     net.train_step_bookkeeping()
         co, fi = self.hot().render(bref, bque, self._render_cfg(), prepared=prep)
         out = self._out_dict(co, '', self.agg_net)
-        out.update(self._out_dict(fi, '_fine', self.fine_agg_net))
+        if hier:                                                            # renderer.py:157-161
+            out.update(self._out_dict(fi, '_fine', self.fine_agg_net))
         return out
 
     def render_by_depth(self, que_depth, que_imgs_info, ref_imgs_info, is_train, is_fine):   # renderer.py:110-138
@@ -671,19 +674,22 @@ class NeuralRayRenderer(nn.Module):
             # HIP forward + HIP backward behind an autograd.Function (csrc/gnr_bwd.inc)
             hot, bref, prep = _prep if _prep is not None and len(_prep) == 3 else self._train_prep(ref_imgs_info)
             xy = coords.to(torch.float32)[None]
-            mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'][None],
-                                         *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])[0]
-                      for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
-            return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
-                    'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]}
+            ms = [_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ref_imgs_info['ray_feats'][None],
+                                     *[P[_w.LEVELS[lvl][0] + 'mean_decoder.' + n] for n in _DM_PARAMS])[0] for lvl in self.levels]
+            out = {'depth_mean': ms[0][..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': ms[0][..., 1]}
+            if len(ms) > 1:                                                 # renderer.py:247-251,259-264: the fine means only with hierarchical sampling
+                out.update({'depth_mean_fine': ms[1][..., 0], 'depth_mean_fine_2': ms[1][..., 1]})
+            return out
         # the reference feeds (row, col) where (x, y) is expected; kept
         xy = coords.to(torch.float32)[None]
         bref, prep = _prep or self._prepare(ref_imgs_info)
         hot = self.hot()
         mc = hot.depth_mean(bref, xy, 'coarse', prepared=prep)[0]
-        mf = hot.depth_mean(bref, xy, 'fine', prepared=prep)[0]
-        return {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1],
-                'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]}
+        out = {'depth_mean': mc[..., 0], 'depth_coords': coords[None].repeat(rfn, 1, 1), 'depth_mean_2': mc[..., 1]}
+        if len(self.levels) > 1:
+            mf = hot.depth_mean(bref, xy, 'fine', prepared=prep)[0]
+            out.update({'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]})
+        return out
 
     def forward(self, data):                                                # renderer.py:268-291
         ref = dict(data['ref_imgs_info'])
@@ -728,10 +734,8 @@ class NeuralRayRenderer(nn.Module):
         h, w = refs[0]['imgs'].shape[-2:]
         rn, fdn, R = ques[0]['coords'].shape[1], c['fine_depth_sample_num'], c['volume_resolution']
         dev = refs[0]['imgs'].device
-        # Host-side order matters: the canonical weight blobs start their way to the host first (stream-ordered, ahead of
-        # everything); then the backbones are queued; while the GPU works on them the host packs the weights and uploads them
-        # (pinned, non-blocking) and runs the reference's CPU random draws, which reach the device in one pinned copy each.
-        self.repack_begin()
+        # The backbones are queued first; the weights are re-packed on the device behind them (hot_for_training: stream-ordered
+        # kernels, nothing waits), and the reference's CPU random draws reach the device in one pinned copy each.
         imgs = torch.cat([r['imgs'] for r in refs])
         img_feats = self.image_encoder(imgs)
         ray_feats = self.vis_encoder(self.init_net({'imgs': imgs}, None, True), img_feats)
@@ -739,13 +743,15 @@ class NeuralRayRenderer(nn.Module):
         hot = self.hot_for_training()
         want_depth = c.get('use_depth_loss', False) and 'true_depth' in refs[0]
         us, coords = [], []
+        hier = bool(c['use_hierarchical_sampling'])
         for _ in range(B):                                                  # the per-scene draw order of forward()
-            us.append(torch.rand([1, rn, fdn]))
-            for net in (self.agg_net, self.fine_agg_net):
+            if hier:
+                us.append(torch.rand([1, rn, fdn]))
+            for net in ((self.agg_net, self.fine_agg_net) if hier else (self.agg_net,)):
                 net.train_step_bookkeeping()
             if want_depth:
                 coords.append(self.gen_depth_loss_coords(h, w, dev, keep_on_host=True))
-        fine_u = self._upload('fine_u', torch.cat(us), dev)
+        fine_u = self._upload('fine_u', torch.cat(us), dev) if hier else None
         if want_depth:
             coords = torch.stack(coords)                                    # [B,8192,2]
             coords = coords if coords.is_cuda else self._upload('depth_coords', coords, dev)
@@ -763,10 +769,11 @@ class NeuralRayRenderer(nn.Module):
         st['volume'] = _SampleVolumeFn.apply(hot, bref, prep, R, ray_feats, img_feats, *[P[k] for k, _ in _w.level_keys('coarse', use_vis=self.use_vis)])
         if want_depth:
             xy = coords.to(torch.float32)
-            mc, mf = (_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[dec + 'mean_decoder.' + n] for n in _DM_PARAMS])
-                      for lvl, dec in (('coarse', 'dist_decoder.'), ('fine', 'fine_dist_decoder.')))
-            st.update({'depth_mean': mc[..., 0], 'depth_coords': coords[:, None].expand(B, V, *coords.shape[1:]), 'depth_mean_2': mc[..., 1],
-                       'depth_mean_fine': mf[..., 0], 'depth_mean_fine_2': mf[..., 1]})
+            ms = [_DepthMeanFn.apply(hot, bref, prep, xy, lvl, ray_feats, *[P[_w.LEVELS[lvl][0] + 'mean_decoder.' + n] for n in _DM_PARAMS])
+                  for lvl in self.levels]
+            st.update({'depth_mean': ms[0][..., 0], 'depth_coords': coords[:, None].expand(B, V, *coords.shape[1:]), 'depth_mean_2': ms[0][..., 1]})
+            if len(ms) > 1:
+                st.update({'depth_mean_fine': ms[1][..., 0], 'depth_mean_fine_2': ms[1][..., 1]})
         return st if stacked else self.unstack(st, B)
 
 

@@ -44,7 +44,7 @@ def exp_decay_lr(step, lr_init=1e-4, decay_step=100000, decay_rate=0.5, lr_min=1
 
 
 class Trainer:
-    def __init__(self, net, lr_cfg=None, batched=True, log_every=1):
+    def __init__(self, net, lr_cfg=None, batched=True, log_every=1, flat_exchange='auto'):
         """log_every: the loss terms leave the device every log_every-th step only (the reference writes its log every
         `train_log_step` = 20 steps, trainer.py:31,159; what it reads back EVERY step is the loss shown in its progress bar, :190).  With
         log_every = 1 every step() returns floats -- and ends in a device-to-host copy the host waits for, so the queue of the next step
@@ -54,34 +54,64 @@ class Trainer:
         self.batched = batched
         self.log_every = max(int(log_every), 1)
         self._pending = None
+        self.flat_exchange = flat_exchange
+        self._flat = self._views = None
         self.lr_cfg = lr_cfg or {}
         self.params = [p for p in net.parameters()]
         self.optimizer = torch.optim.Adam(self.params, lr=1e-3)            # lr_common_manager.py:9-13
         self.step_id = 0
 
+    def _mode_modules(self):
+        ms = self.__dict__.get('_mode_mods')
+        if ms is None:
+            names = ('nr_net', 'vgn_net')
+            ms = self.__dict__['_mode_mods'] = [getattr(self.net, n) for n in names if isinstance(getattr(self.net, n, None), torch.nn.Module)]
+            nr = getattr(self.net, 'nr_net', None)
+            for n in ('agg_net', 'fine_agg_net', 'image_encoder', 'init_net', 'vis_encoder'):
+                if isinstance(getattr(nr, n, None), torch.nn.Module):
+                    ms.append(getattr(nr, n))
+        return ms
+
+    def _flat_views(self):
+        """One persistent flat fp32 buffer for the gradient exchange (all parameters + one scene counter) and the per-parameter views
+        into it, made once: a step then moves the gradients in with ONE multi-tensor copy and out with one (no 346-way torch.cat,
+        no per-tensor reshape / split on the host every step)."""
+        if self._flat is None or self._flat.device != self.params[0].device:
+            n = sum(p.numel() for p in self.params)
+            self._flat = torch.zeros(n + 1, dtype=torch.float32, device=self.params[0].device)
+            self._views = [v.view(p.shape) for v, p in zip(torch.split(self._flat[:-1], [p.numel() for p in self.params]), self.params)]
+        return self._flat, self._views
+
     def _allreduce_grads(self, n_local):
-        """Sum of per-scene gradients over all ranks / global scene count, through one flat buffer: one concatenation,
-        one all-reduce, one multi-tensor copy back (parameters without a gradient on this rank count as zeros)."""
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        dev = self.params[0].device
+        """Sum of per-scene gradients over all ranks / global scene count, through one flat buffer: one multi-tensor copy in,
+        one all-reduce, one multi-tensor copy back (parameters without a gradient on this rank count as zeros).
+        flat_exchange: 'auto' = only when there is more than one rank; True = always (one rank: the collective is RCCL's
+        single-rank all-reduce -- how bench.py prices the N > 1 path of a step on one GPU)."""
+        ready = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if ready else 1
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         grads = [p.grad for p in self.params]
-        if world == 1:
+        if not (world > 1 or (self.flat_exchange is True and ready)):
             torch._foreach_div_(grads, float(max(n_local, 1)))
             return world
-        flat = torch.cat([g.reshape(-1) for g in grads] + [torch.full((1,), float(n_local), dtype=torch.float32, device=dev)])
+        flat, views = self._flat_views()
+        torch._foreach_copy_(views, grads)
+        flat[-1] = float(n_local)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat = flat[:-1] / flat[-1].clamp(min=1.0)
-        torch._foreach_copy_(grads, [v.reshape(g.shape) for v, g in zip(torch.split(flat, [g.numel() for g in grads]), grads)])
+        flat[:-1].div_(flat[-1].clamp(min=1.0))
+        torch._foreach_copy_(grads, views)
         return world
 
     def step(self, scenes):
         """scenes: list of `data` dicts (this rank's share of the global batch).  Gradients of the per-scene total
         losses are accumulated, all-reduced, averaged over the global scene count; one Adam update.
         -> dict of loss terms averaged over the local scenes, lr."""
-        if not self.net.training:                           # (train() walks every sub-module: not every step)
+        # (train() walks every sub-module: not every step.)  The root flag alone is not enough: `net.nr_net.eval()` for a render-only
+        # validation leaves the root in training mode, and the next steps would silently train with the renderer in eval mode (eval
+        # sampling, no NeuS step bookkeeping) -- every module whose behaviour depends on the mode is checked.
+        if not (self.net.training and all(m.training for m in self._mode_modules())):
             self.net.train()
         lr = exp_decay_lr(self.step_id, **self.lr_cfg)
         for g in self.optimizer.param_groups:

@@ -117,6 +117,17 @@ int gnr_pack_weights(const float* canonical_host, float* packed_host);
 int gnr_pack_vis_decoder(const float* vis_decoder_host, float* packed_host);
 int gnr_pack_vis_decoder_bwd(const float* vis_decoder_host, float* packed_bwd_host);
 int gnr_canonical_vis_floats(void);       /* 2145 */
+/* Device-side packers (csrc/gnr_pack_dev.hip): the same blobs from canonical blobs that are ALREADY ON THE DEVICE -- the training
+ * loop's parameters move every optimiser step and, as in the reference (train/trainer.py:146-158: nn.Module parameters, optimiser
+ * step on the device), never visit the host: no device-to-host copy, no host pack, no upload, no wait.  Stream-ordered kernels,
+ * nothing synchronises.  The arithmetic is the host packer's own source (csrc/gnr_pack_body.h) and the results are bit-identical
+ * to it.  The blobs are re-packed IN PLACE: `packed_dev` / `packed_bwd_dev` must once have been filled from a blob of
+ * gnr_pack_weights / gnr_pack_weights_bwd (any weights) -- the constant parts (structural zeros, the position table) are kept.
+ * gnr_pack_vis_decoder_device / _bwd_device: the use_vis branch, after the level's own re-pack, as on the host. */
+int gnr_pack_weights_device(const float* canonical_dev, float* packed_dev, void* stream);
+int gnr_pack_weights_bwd_device(const float* canonical_dev, float* packed_bwd_dev, void* stream);
+int gnr_pack_vis_decoder_device(const float* vis_decoder_dev, float* packed_dev, void* stream);
+int gnr_pack_vis_decoder_bwd_device(const float* vis_decoder_dev, float* packed_bwd_dev, void* stream);
 /* float offset of a named section of the packed blob (see csrc/gnr_layout.h), -1 if unknown */
 int gnr_layout_offset(const char* name);
 
@@ -164,7 +175,9 @@ int gnr_render_by_depth_fwd(const GnrScene* scene, const GnrRays* rays, const fl
 /* render (renderer.py:140-162, :201-220), eval mode: coarse pass on disparity-uniform
  * depths, inverse-CDF fine resampling (render_ops.py:172-229) + sort, fine pass.
  *   fine_depth_in : optional [B,rn,fdn]; when given it replaces the resampled depths
- *   fine_inds_out : optional [B,rn,fdn] int32 searchsorted indices of the resampling      */
+ *   fine_inds_out : optional [B,rn,fdn] int32 searchsorted indices of the resampling
+ *   fine == NULL  : cfg use_hierarchical_sampling false (renderer.py:153-162): the coarse pass only -- no resampling, no fine
+ *                   pass, packed_fine is not read (fine_depth_in / fine_inds_out must be NULL)                                  */
 int gnr_render_rays_fwd(const GnrScene* scene, const GnrRays* rays, const float* packed_coarse,
                         const float* packed_fine, GnrRenderOut* coarse, GnrRenderOut* fine,
                         const float* fine_depth_in, int* fine_inds_out, void* workspace,

@@ -264,3 +264,71 @@ def test_instance_norm_function_matches_autograd():
     up = torch.randn(y.shape, generator=g, dtype=torch.float64)
     got, want = torch.autograd.grad((y * up).sum(), (x, w, b)), torch.autograd.grad((ref * up).sum(), (x, w, b))
     assert float((y - ref).abs().max()) < 1e-12 and all(float((u - v).abs().max()) < 1e-10 for u, v in zip(got, want))
+
+
+def test_without_hierarchical_sampling_the_fine_level_does_not_exist():
+    """renderer.py:56-58: fine_dist_decoder / fine_agg_net (and their state-dict keys) are created only with use_hierarchical_sampling."""
+    import copy
+    from graspnerf_amd.renderer import GraspNeRF
+    cfg = copy.deepcopy(CFG)
+    cfg['use_hierarchical_sampling'] = False
+    net = GraspNeRF(cfg)
+    keys = list(net.state_dict())
+    assert not any(k.startswith('nr_net.fine_') for k in keys) and not hasattr(net.nr_net, 'fine_agg_net')
+    full = list(GraspNeRF(CFG).state_dict())
+    assert [k for k in full if not k.startswith('nr_net.fine_')] == keys
+    G = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_full_cfg1_nohier.npz'))
+    assert str(G['volume_type_alpha']).startswith('raises ValueError')        # why volume_type ['alpha'] stays refused here
+
+
+@pytest.mark.gpu
+def test_without_hierarchical_sampling_matches_reference():
+    """cfg use_hierarchical_sampling: false (the reference's base_cfg default, renderer.py:22,153-162): forward returns the coarse
+    pass only -- no '_fine' keys, no fine depth means -- in eval mode and in training mode (values; no torch.rand is drawn, only the
+    coarse aggregation net counts a step), against the imported reference (tools/make_goldens.py --no-hier-only); and a training
+    step runs through the coarse-only graph."""
+    import copy
+    from graspnerf_amd.renderer import GraspNeRF
+    G = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_full_cfg1_nohier.npz'))
+    cfg = copy.deepcopy(CFG)
+    cfg['use_hierarchical_sampling'] = False
+    net = GraspNeRF(cfg)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    full = synth_state_dict({k: tuple(v.shape) for k, v in GraspNeRF(CFG).state_dict().items()})      # the reference's values (same generator order)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(full[k])) for k in shapes})
+    net = net.cuda().eval()
+    torch.manual_seed(123)
+    with torch.no_grad():
+        out = net(_data('cuda'))
+    assert sorted(k for k in out if k != 'vgn_pred') == [str(k) for k in G['keys']]
+    tol = dict(rtol=1e-3, atol=3e-4)
+    np.testing.assert_allclose(out['volume'].cpu().numpy(), G['volume'], **tol)
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'pixel_colors_nr', 'pixel_colors_gt', 'sdf_gradient_error'):
+        np.testing.assert_allclose(out[k].cpu().numpy(), G['render.' + k], **tol)
+    assert np.array_equal(out['ray_mask'].cpu().numpy(), G['render.ray_mask'])
+    # training-mode values of the render, RNG stream and step counters as in the reference
+    nr = net.nr_net
+    nr.train()
+    d = _data('cuda')
+    with torch.no_grad():
+        ri = dict(d['ref_imgs_info'])
+        ri['img_feats'] = nr.image_encoder(ri['imgs'])
+        ri['ray_feats'] = nr.vis_encoder(nr.init_net(ri, None, True), ri['img_feats'])
+        torch.manual_seed(7)
+        before = torch.rand(1).item()
+        torch.manual_seed(7)
+        tr = nr.render(d['que_imgs_info'], ri, True)
+        assert torch.rand(1).item() == before and bool(G['train_rng_untouched'])
+    assert [nr.agg_net.step] == list(G['train_steps'])
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'pixel_colors_nr'):
+        np.testing.assert_allclose(tr[k].cpu().numpy(), G['train.' + k], **tol)
+    # and it trains: one autograd forward + backward through the coarse-only graph gives finite gradients on the coarse level
+    net.train()
+    data = dict(d)
+    data.pop('eval')
+    out = net(data)
+    assert 'sdf_values_fine' not in out and 'depth_mean_fine' not in out
+    (out['pixel_colors_nr'].sum() + out['volume'].sum() + out['depth_mean'].sum()).backward()
+    g = net.nr_net.agg_net.prob_embed[0].weight.grad if hasattr(net.nr_net.agg_net, 'prob_embed') else None
+    grads = [p.grad for n, p in net.nr_net.named_parameters() if n.startswith(('agg_net.', 'dist_decoder.')) and p.grad is not None]
+    assert grads and all(torch.isfinite(x).all() for x in grads) and any(float(x.abs().max()) > 0 for x in grads)

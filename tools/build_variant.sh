@@ -5,4 +5,4 @@ set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../graspnerf_amd/csrc"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -fno-slp-vectorize -o libgnr_$NAME.so \
-  gnr_kernels.hip gnr_head.hip gnr_post.hip gnr_img.hip gnr_pack.cpp gnr_host_rng.cpp "$@"
+  gnr_kernels.hip gnr_head.hip gnr_post.hip gnr_img.hip gnr_pack.cpp gnr_pack_dev.hip gnr_host_rng.cpp "$@"

@@ -401,6 +401,71 @@ def run_full_forward(renderer):
     print('full forward golden:', {k: v.shape for k, v in g.items()})
 
 
+def run_no_hier(renderer):
+    """cfg use_hierarchical_sampling: false (the reference's base_cfg default, renderer.py:22; render_impl :153-162 returns the coarse
+    pass's outputs only): GraspNeRF.forward in eval mode and NeuralRayRenderer.render in training mode (values), cfg1 shape.  Also
+    records what the reference does with volume_type ['alpha'] (renderer.py:189-191)."""
+    cfg = yaml.load(open(REF + '/src/nr/configs/nrvgn_sdf.yaml'), Loader=yaml.FullLoader)
+    for k, v in (('volume_resolution', 16), ('depth_sample_num', 16), ('fine_depth_sample_num', 16), ('use_hierarchical_sampling', False)):
+        cfg[k] = v
+    cfg['agg_net_cfg']['sample_num'] = 16
+    cfg['fine_agg_net_cfg']['sample_num'] = 16
+    import utils.field_utils as fu
+    fu.RESOLUTION, fu.VOXEL_SIZE = 16, fu.VOLUME_SIZE / 16
+    fu.HALF_VOXEL_SIZE = fu.VOXEL_SIZE / 2
+    renderer.TSDF_SAMPLE_POINTS = fu.generate_grid_points()
+    net = renderer.GraspNeRF(cfg)
+    net.eval()
+    sd = net.state_dict()
+    syn = synth_state_dict({k: tuple(v.shape) for k, v in sd.items()})
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
+    ref, que = make_scene(0, 'cfg1')
+    t = lambda a: torch.from_numpy(a.copy())
+    ref_info = {k: t(v) for k, v in ref.items() if k not in ('img_feats', 'ray_feats')}
+    que_info = {'coords': t(que['coords'])[None], 'poses': t(que['pose'])[None], 'Ks': t(que['K'])[None],
+                'depth_range': t(que['depth_range'])[None], 'imgs': t(que['imgs'])}
+    data = {'step': 0, 'eval': True, 'full_vol': True, 'ref_imgs_info': ref_info, 'que_imgs_info': que_info,
+            'src_imgs_info': dict(ref_info)}
+    torch.manual_seed(123)
+    with torch.no_grad():
+        out = net(data)
+    assert not any(k.endswith('_fine') and not k.startswith('depth_mean') for k in out), sorted(out)
+    g = {'volume': out['volume'].numpy(), 'keys': np.array(sorted(k for k in out if k != 'vgn_pred'))}
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'pixel_colors_nr', 'ray_mask', 'pixel_colors_gt', 'sdf_gradient_error'):
+        g['render.' + k] = out[k].numpy()
+    # training-mode values of the render (coarse pass only: no torch.rand is drawn, only the coarse aggregation net counts a step)
+    nr = net.nr_net
+    nr.train()
+    with torch.no_grad():
+        ri = dict(ref_info)
+        ri['img_feats'] = nr.image_encoder(ri['imgs'])
+        ri['ray_feats'] = nr.vis_encoder(nr.init_net(ri, None, True), ri['img_feats'])
+        torch.manual_seed(7)
+        before = torch.rand(1).item()
+        torch.manual_seed(7)
+        tr = nr.render(que_info, ri, True)
+        after = torch.rand(1).item()
+    g['train_rng_untouched'] = np.array(before == after)
+    assert not hasattr(nr, 'fine_agg_net') and not any(k.startswith('nr_net.fine_') for k in sd)      # renderer.py:56-58
+    g['train_steps'] = np.array([nr.agg_net.step])
+    for k in ('sdf_values', 'alpha_values', 'hit_prob_nr', 'render_depth', 'pixel_colors_nr'):
+        g['train.' + k] = tr[k].numpy()
+    # volume_type ['alpha'] (renderer.py:189-191): does the reference's own call run?
+    try:
+        cfg2 = dict(cfg, volume_type=['alpha'])
+        net2 = renderer.GraspNeRF(cfg2).eval()
+        net2.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
+        with torch.no_grad():
+            net2(data)
+        g['volume_type_alpha'] = np.array('runs')
+    except Exception as e:
+        import traceback
+        g['volume_type_alpha'] = np.array('raises ' + type(e).__name__ + ': ' + str(e)[:200] + ' @ ' + traceback.format_exc().strip().splitlines()[-3].strip()[:160])
+    print('volume_type alpha in the reference:', g['volume_type_alpha'])
+    np.savez_compressed(ROOT + '/tests/golden/golden_full_cfg1_nohier.npz', **g)
+    print('no-hier golden:', {k: getattr(v, 'shape', v) for k, v in g.items()})
+
+
 def run_train_step(renderer, scene_id=0, weight_seed=7, torch_seed=321, loss_seed=5, out_name='golden_train_step.npz', use_vis=False, use_all=False):
     """One training step of the reference (trainer.py:142-158): GraspNeRF.forward in train mode on a cfg1 scene with
     synthetic supervision (synth_loss_case targets), the configured losses (loss: [render, depth, sdf, vgn]), backward.
@@ -546,6 +611,8 @@ def main():
         return run_losses()
     if '--full-only' in sys.argv:
         return run_full_forward(renderer)
+    if '--no-hier-only' in sys.argv:
+        return run_no_hier(renderer)
     if '--ckpt-keys-only' in sys.argv:
         return run_ckpt_keys(renderer)
     if '--use-vis-only' in sys.argv:
