@@ -127,9 +127,60 @@ def recorded_pmc(batch):
                 'frac': round(4 * k['SQ_ACTIVE_INST_VALU'] / (cycles * simds), 3),
                 'note': 'share of the SIMDs\' cycles in which a vector instruction (incl. the MFMA issue slot) executes; what is left '
                         'is the matrix pipe alone (mfma_pipe_busy overlaps partly) and stalls on LDS / memory counters'}
+        # the other launches of a step / of a training step from the same stamped file: bytes at the L2's memory side (gfx950 read
+        # correction applied by tools/pmc_summary.py), L2 hit rate, instruction mix -- per launch, recomputable from profiles/<source>
+        def brief(name, scenes):
+            q = d['kernels'].get(name)
+            if not q:
+                return None
+            o = {'traffic': int(q['hbm_bytes_corrected']) if 'hbm_bytes_corrected' in q else None, 'scenes_per_launch': scenes}
+            if 'TCC_HIT_sum' in q:
+                o['l2_hit_rate'] = round(q['TCC_HIT_sum'] / max(q['TCC_HIT_sum'] + q['TCC_MISS_sum'], 1.0), 3)
+            if 'SQ_INSTS_VALU' in q:
+                o['mfma_per_launch'], o['valu_incl_mfma_per_launch'] = q['SQ_INSTS_MFMA'], q['SQ_INSTS_VALU']
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in q and 'GRBM_GUI_ACTIVE' in q:
+                o['mfma_pipe_busy'] = round(q['SQ_VALU_MFMA_BUSY_CYCLES'] / (q['GRBM_GUI_ACTIVE'] / 8 * simds), 3)
+            return o
+        counters['other_kernels'] = {n: brief(n, sc) for n, sc in (('k_chain<6, true, false, false, true>', 32), ('k_ray<true>', 32), ('k_ray<false>', 32),
+                                                                    ('k_repack_feats', 32))}
+        if d.get('bwd_source_sha16') == source_sha16('gnr_kernels.hip', 'gnr_bwd.inc'):
+            counters['backward_kernels'] = {n: brief(n, 8) for n in d['kernels'] if '_bwd' in n}
+        counters['pmc_age_commits'] = pmc_age_commits(d)
         return int(k['hbm_bytes_corrected']), counters, valu
     except (KeyError, ValueError, ZeroDivisionError, StopIteration):
         return None, None, None
+
+
+def pmc_age_commits(d):
+    """Commits between the tree the PMC file was collected on and this one (0 = same commit), from the commit count the file was
+    stamped with (`git_commit_count`, written here in the build container where the history exists); None where there is no .git
+    (the GPU boxes get a snapshot without it -- there `kernel_source_sha16` is what ties the counters to the running kernels)."""
+    import subprocess
+    try:
+        now = int(subprocess.check_output(['git', '-C', ROOT, 'rev-list', '--count', 'HEAD'], stderr=subprocess.DEVNULL, timeout=10).decode())
+        return now - int(d['git_commit_count'])
+    except Exception:
+        return None
+
+
+def recorded_arbiter():
+    """The fp64 arbiter at the benched shape (tests/test_range_guard.py::test_fp64_arbiter_benched_shape), from the newest committed
+    profiles/*parity_errors*.json that holds its rows: distance of the pair-form path from a float64 evaluation, relative to the fp32
+    CPU oracle's distance from it.  (The arbiter is the oracle: bench.py may run the oracle in its cpu_baseline leg only, so the
+    line quotes the recorded test run.)"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*parity_errors*.json')), reverse=True):
+        try:
+            rows = [r for r in json.load(open(f))['worst_per_check'] if 'benched shape' in r.get('what', '')]
+        except (OSError, ValueError, KeyError):
+            continue
+        if rows:
+            return {'source': os.path.relpath(f, ROOT), 'checks': len(rows),
+                    'rms_ratio_max': round(max(r['rms_ratio'] for r in rows), 3), 'p99_ratio_max': round(max(r['p99_ratio'] for r in rows), 3),
+                    'rms_ratio_volume': round(max(r['rms_ratio'] for r in rows if r['what'].endswith('volume')), 3),
+                    'note': '|HIP fp16-pair path - float64| / |fp32 CPU oracle - float64| over every voxel / sample of the benched shape '
+                            '(6 views, 40^3, 512 x (40+40)); test bounds: rms <= 1.5, p99 <= 2'}
+    return None
 
 
 # ---- parity gate -----------------------------------------------------------------------------------------------------
@@ -356,13 +407,14 @@ def train_leg(args, world, rank, dev, dist, sync):
     if rank == 0:
         _lib.timing_begin(only=dom)                    # the timed steps bracket this kernel only
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.train_steps + 1)]
-    host = []
+    host, host_cpu = [], []
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.train_steps):
-        h0 = time.perf_counter()
+        h0, c0 = time.perf_counter(), time.process_time()
         log = tr.step(scenes)
         host.append((time.perf_counter() - h0) * 1e3)
+        host_cpu.append((time.process_time() - c0) * 1e3)   # CPU time of the whole process (all threads) spent on the step
         marks[i + 1].record()                              # per-step spans on the stream (no synchronisation added)
     sync()
     log = tr.last_log()                                    # the terms of the last timed step (on a logging step step() returned them itself)
@@ -371,15 +423,15 @@ def train_leg(args, world, rank, dev, dist, sync):
     table = _lib.timing_end() if rank == 0 else {}
     K = args.train_steps
     # the same steps with the loss terms read back at the end of EVERY step (log_every = 1: what a per-step progress bar costs,
-    # trainer.py:190 of the reference): eight steps, reported next to the headline, not in it
+    # trainer.py:190 of the reference): the same number of steps, reported with the same prominence
     every = tr.log_every
     tr.log_every = 1
     sync()
     t1 = time.perf_counter()
-    for _ in range(8):
+    for _ in range(K):                                     # the same number of steps as the lazy-log figure
         tr.step(scenes)
     sync()
-    ms_log1 = max_over_ranks(time.perf_counter() - t1, dev) / 8 * 1e3
+    ms_log1 = max_over_ranks(time.perf_counter() - t1, dev) / K * 1e3
     tr.log_every = every
     # per-kernel table of the library: two further steps with every launch bracketed (outside the timed region: ~60 event
     # pairs per step would perturb it)
@@ -401,7 +453,11 @@ def train_leg(args, world, rank, dev, dist, sync):
         rec = {
             'metric': 'train scenes/sec (fwd + losses + bwd + gradient all-reduce + Adam), 6-view 40^3 grid + 512 rays x (40+40)',
             'value': round(world * n * K / dt, 3), 'unit': 'scenes/s', 'ms_per_step': round(dt / K * 1e3, 3), 'steps': K,
+            'value_with_per_step_readback': round(world * n / (ms_log1 * 1e-3), 3),
             'warmup': args.train_warmup, 'log_every': args.train_log_step, 'ms_per_step_with_log_every_1': round(ms_log1, 3),
+            'which_is_which': "value = the reference's LOGGING cadence (its log is written every train_log_step = 20 steps, trainer.py:31,159); "
+                              "value_with_per_step_readback = the reference's PROGRESS-BAR semantics (the loss is read back after every step, "
+                              "trainer.py:190), same number of steps; a comparison with a reference run that shows its progress bar should use the latter",
             'log_note': "every step runs forward, losses, backward, gradient all-reduce and Adam; the loss TERMS are copied to the host every log_every-th step (the reference's train_log_step = 20, trainer.py:31,159) instead of at the end of every step, where the host would wait for the copy and start the next step's ~2 000 launches from an empty queue; ms_per_step_with_log_every_1 = eight further steps with the per-step read-back (the reference's progress bar, trainer.py:190)", 'scenes_per_gpu': n, 'global_batch': world * n, 'n_gpus': world, 'dtype': 'f32', 'data': 'synthetic',
             'config': 'BASELINE.json configs[4]: backbones + nr TSDF + render + depth-mean head + grasp head + losses (render, depth, sdf, vgn), '
                       'batch 8/GPU, one flat fp32 gradient all-reduce (4.66 M parameters), Adam',
@@ -409,6 +465,11 @@ def train_leg(args, world, rank, dev, dist, sync):
             'ms_per_step_max': round(float(np.max(step_ms)), 3), 'max_over_median': round(float(np.max(step_ms) / np.median(step_ms)), 3),
             'stalled_steps': int(sum(x > 1.05 * float(np.median(step_ms)) for x in step_ms)),       # steps more than 5 % over the median, inside the timed region
             'host_ms_each_step': [round(x, 2) for x in host],
+            'host_ms_unblocked': round(float(np.min(host)), 2),
+            'host_cpu_ms_each_step': [round(x, 2) for x in host_cpu], 'host_cpu_ms_median': round(float(np.median(host_cpu)), 2),
+            'host_note': 'host_ms_each_step = wall time the host spends inside step(): it runs one to two steps ahead of the GPU and then blocks '
+                         'on a full queue, so the values alternate between its own queueing time (host_ms_unblocked) and waits for the GPU; '
+                         'host_cpu_ms_each_step = CPU time of the process (all threads) per step -- what the step needs from the host',
             'max_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 3),
             'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')},
             'split_ms_per_step': {'hip_path_kernels': round(path_ms, 3), 'hip_grasp_head_kernels': round(head_ms, 3),
@@ -448,7 +509,27 @@ def train_leg(args, world, rank, dev, dist, sync):
             rec['allreduce'] = ar
     del tr, net
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_train_2cpu:
+        rec['at_2_cpus'] = train_at_2_cpus(args, rec['ms_per_step'])
     return rec
+
+
+def train_at_2_cpus(args, ms_here):
+    """The same train step in a child process pinned to 2 CPUs (tools/train_step_bench.py --cpus 2: sched_setaffinity before torch
+    starts, pools sized for that share) = the host budget of one rank of an 8-rank node under the boxes' 16-CPU cgroup, followed by the
+    same steps with the N > 1 gradient exchange (persistent flat buffer, RCCL all-reduce on a one-rank group, copy back).  What a
+    1-GPU box can say about the 8-rank step: whether the host keeps up, and what the exchange costs next to the step."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'train_step_bench.py'), '--scenes', str(args.train_scenes), '--steps', str(args.train_steps),
+           '--warmup', str(args.train_warmup), '--cpus', '2', '--flat-exchange-steps', '8']
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=dict(os.environ, LOG_EVERY=str(args.train_log_step)))
+        d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+        return {'ms_per_step_at_2_cpus': round(d['ms_per_step'], 3), 'value': round(d['value'], 3), 'vs_this_process': round(d['ms_per_step'] / ms_here, 4),
+                'cpus_pinned': d['cpus_pinned'], 'torch_intra_op_threads': d['torch_intra_op_threads'], 'host_ms_each_step': d['host_ms_each_step'],
+                'with_flat_gradient_exchange': d['with_flat_gradient_exchange'], 'command': ' '.join(cmd[1:]).replace(ROOT + '/', '')}
+    except Exception as e:
+        return {'error': repr(e)[:300]}
 
 
 def allreduce_record(dist, world, n_params, dev):
@@ -531,6 +612,7 @@ def main():
     ap.add_argument('--no-backbones', action='store_true', help='skip the images -> grasps figure')
     ap.add_argument('--no-f32-build', action='store_true', help='skip timing the fp32-MFMA companion build next to the product')
     ap.add_argument('--train-scenes', type=int, default=8)
+    ap.add_argument('--no-train-2cpu', action='store_true', help='skip the train step of a child process pinned to 2 CPUs (the host budget of one rank of an 8-rank node)')
     ap.add_argument('--train-steps', type=int, default=16, help='timed steps of the train_step record (16: one stalled step moves the mean by 5 %, not 12)')
     ap.add_argument('--train-log-step', type=int, default=20, help="the loss terms leave the device every N-th step, the reference's train_log_step (trainer.py:31,159: 20); 1 = a device-to-host copy the host waits for at the end of EVERY step (what the reference's progress bar does, trainer.py:190)")
     ap.add_argument('--train-warmup', type=int, default=24, help='the caching allocators and MIOpen (solvers compiled on their first uses) settle over ~20 steps: profiles/r03_d, r03_f show stalled steps up to the 13th')
@@ -670,6 +752,7 @@ def main():
         fl_alg = chain_flops(B * res ** 3, c['V'], render=False)
         fl_exe = executed_mfma_flops(B * res ** 3, False)
         fl_ren = executed_mfma_flops(B * rn * dn, True)
+        fl_ren_alg = chain_flops(B * rn * dn, c['V'], render=True)
         achieved = fl_exe / (ms * 1e-3) / 1e12
         traffic, counters, valu = (None, None, None) if stub else recorded_pmc(B)
         out = {
@@ -681,6 +764,7 @@ def main():
                           'DESIGN.md 4.1b; as close to a float64 evaluation as the fp32 CPU oracle, tests/test_range_guard.py); operands beyond the '
                           'fp16 range make the launch fall back to the fp32-input MFMA (range_flags); f32_mfma_build is the same step with '
                           'every product on fp32 instructions',
+            'fp64_arbiter_at_benched_shape': None if stub else recorded_arbiter(),
             'parity_checked': parity is not None, 'parity': parity, 'range_flags': range_flags,
             'host_threads': {'torch_intra_op': host_threads, 'cpu_budget': cpu_budget(), 'cpus_visible': os.cpu_count()},
             'config': {'workload': f'{B} scenes/GPU/step, 6 views 288x512 (feature maps 72x128x32 x2), 40^3 TSDF volume + '
@@ -692,26 +776,34 @@ def main():
             # MAC), the 1..4-k-step remainders on the fp32-input MFMA: achieved = the MFMA FLOPs the kernel EXECUTES per launch
             # (MFMA_PER_TILE x tiles; PMC SQ_INSTS_MFMA agrees) / its HIP-event duration, peak = the dense f16 MFMA peak.
             # What binds it is VALU issue (`valu`): 12 vector instructions per MFMA (activations, operand splitting, queue moves).
-            'roofline': {'bound': 'mfma', 'binding_resource': 'valu_issue', 'achieved': round(achieved, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic,
-                         # the same launch priced by its ALGORITHMIC work: un-hoisted SURVEY 8d fp32 FLOPs (one per MAC, not the three
-                         # f16 partial products the kernel executes per MAC) over the same time and the same dense f16 peak
-                         'frac_algorithmic': round(fl_alg / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+            # achieved = ALGORITHMIC FLOPs per launch (un-hoisted: 2 x (6 x 27 736 + 6 528) = 345 888 per point x
+            # B x 40^3 points) / the HIP-event launch time, against the dense f16 MFMA peak the wide layers run under.
+            # frac_executed prices the matrix-core FLOPs the kernel actually EXECUTES (three f16 partial products per fp32 MAC,
+            # zero-padded K32 tails: 696 x 16 384 + 114 x 2 048 FLOP per 16-point tile) over the same time and peak.
+            'roofline': {'bound': 'mfma', 'binding_resource': 'valu_issue', 'achieved': round(fl_alg / (ms * 1e-3) / 1e12, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(fl_alg / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic,
+                         'flops_per_launch': fl_alg, 'flops_per_point': 2 * (c['V'] * MAC_VIEW_VOL + MAC_POINT_CHAIN), 'points_per_launch': B * res ** 3,
+                         'achieved_executed': round(achieved, 2), 'frac_executed': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
+                         'flops_per_launch_executed': fl_exe,
                          'kernel': 'k_chain<6,false> on the volume points', 'ms_per_launch': round(ms, 4),
                          'launches_timed': n_vol, 'ms_per_launch_standalone': round(ms_alone, 4),
-                         'flops_per_launch': fl_exe,
-                         'note': 'achieved = executed matrix-core FLOPs per launch (696 v_mfma_f32_16x16x32_f16 + 114 v_mfma_f32_16x16x4_f32 per '
-                                 '16-point tile; profiles/ PMC SQ_INSTS_MFMA per tile = 810) over the HIP-event launch time; peak = dense f16 MFMA.  '
-                                 'fp32 operands are carried as fp16 pairs and every fp32 MAC costs three f16 MACs, so the fp32-equivalent rate is '
-                                 'algorithmic_fp32_equiv (no fraction: it is not priced against a roof it does not run under).  The kernel is bound by '
-                                 'VALU issue, see valu',
+                         'note': 'frac = achieved / peak with achieved = flops_per_launch / ms_per_launch (algorithmic fp32 FLOPs, SURVEY 8d); '
+                                 'frac_executed = flops_per_launch_executed / ms_per_launch / peak (696 v_mfma_f32_16x16x32_f16 + 114 '
+                                 'v_mfma_f32_16x16x4_f32 per 16-point tile; counters.mfma_per_launch / (points_per_launch / 16) = 810 agrees).  '
+                                 'fp32 operands are carried as fp16 pairs and every fp32 MAC costs three f16 MACs plus a split on the VALU: the '
+                                 'kernel is bound by vector issue (valu), not by the matrix pipe (counters.mfma_pipe_busy); the fp32-instruction '
+                                 'peak of the part is 157.3 TFLOP/s (f32_mfma_build prices the all-fp32-instruction build against it)',
                          'valu': valu,
                          'algorithmic_fp32_equiv': {'tflops': round(fl_alg / (ms * 1e-3) / 1e12, 2), 'flops_per_launch': fl_alg,
                                                     'note': 'un-hoisted fp32 FLOPs 2*(6*27736+6528) per point (SURVEY.md 8d); the fp32-instruction peak of '
                                                             'the part is 157.3 TFLOP/s (f32_mfma_build.frac_of_fp32_mfma_peak is measured against it)'},
                          'render_launch': {'kernel': 'k_chain<6,true> on the ray points (2 launches per step)', 'ms_per_launch': round(ms_ren, 4),
-                                           'achieved': round(fl_ren / (ms_ren * 1e-3) / 1e12, 2),
-                                           'frac': round(fl_ren / (ms_ren * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'flops_per_launch': fl_ren}},
+                                           'achieved': round(fl_ren_alg / (ms_ren * 1e-3) / 1e12, 2),
+                                           'frac': round(fl_ren_alg / (ms_ren * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'flops_per_launch': fl_ren_alg,
+                                           'flops_per_point': 2 * (c['V'] * MAC_VIEW_RAY + MAC_POINT_CHAIN), 'points_per_launch': B * rn * dn,
+                                           'frac_executed': round(fl_ren / (ms_ren * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'flops_per_launch_executed': fl_ren,
+                                           'traffic': ((counters or {}).get('other_kernels', {}).get('k_chain<6, true, false, false, true>') or {}).get('traffic'),
+                                           'l2_hit_rate': ((counters or {}).get('other_kernels', {}).get('k_chain<6, true, false, false, true>') or {}).get('l2_hit_rate')}},
             'kernels_ms_per_step': {k: round(v[1] / 5, 4) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])},
         }
         # SURVEY.md §8d extras: the whole step against the HBM roof (26.0 MB compulsory bytes per scene, TSDF + render) and the

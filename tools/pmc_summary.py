@@ -37,7 +37,16 @@ def sha16(*names):
     return h.hexdigest()[:16]
 
 
+def commit_count():
+    import subprocess
+    try:
+        return int(subprocess.check_output(['git', '-C', os.path.dirname(CSRC), 'rev-list', '--count', 'HEAD'], stderr=subprocess.DEVNULL).decode())
+    except Exception:
+        return None          # no history on the GPU box: tools/stamp_pmc.py sets it once the file is back in the repo
+
+
 json.dump({
+    'git_commit_count': commit_count(),
     # bench.py reports these counters only while the stamps equal the sha256 of the kernel sources it runs (bench.py newest_pmc)
     'kernel_source_sha16': sha16('gnr_kernels.hip'), 'bwd_source_sha16': sha16('gnr_kernels.hip', 'gnr_bwd.inc'),
     'command': 'rocprofv3 --pmc <set> --output-format csv -- python tools/run_hot.py --iters 1   (forward kernels: B=32 scenes, 6 views, '
