@@ -212,7 +212,33 @@ constexpr int T_RGB0V = RGB0HT + frag_floats(4, 2);          // rgb_fc.0[:, 32] 
 // fourth decoder branch (use_vis), zero unless gnr_pack_vis_decoder_bwd filled it; k_view1_bwd<true> copies it behind its image
 constexpr int DECV2T = T_RGB0V + 16;                         // vis_decoder.2^T                                          8 x 2
 constexpr int DECV1T = DECV2T + 1024;                        // vis_decoder.0^T, rows in the gather layout               8 x 2
-constexpr int TOTAL = DECV1T + 1024;
+constexpr int F32_END = DECV1T + 1024;
+// fp16-pair images (layout of the C16 section: K32 blocks of (h, m) x NB x 64 lanes x 8 halfs) of the transposed fragments and of
+// prob_embed.2's forward fragment: the backward twins k_view2_bwd / k_view1_bwd run their forward recompute (from the forward
+// blob's C16 image) and their dX chains on the f16 matrix cores with fp32 operands as fp16 pairs, like k_chain (round 5).
+// Each of the two sections is one contiguous run the kernel copies into LDS; the bias / table copies keep them contiguous.
+constexpr int P2_BEGIN = F32_END;                            // second view loop (k_view2_bwd)
+constexpr int P2_PE2F = P2_BEGIN;                            // prob_embed.2 forward                                  1 x 2
+constexpr int P2_B_PE2 = P2_PE2F + pk::k32_floats(2);            // its bias (32)
+constexpr int P2_VISB1T = P2_B_PE2 + 32;                     //                                                       1 x 2
+constexpr int P2_VIS2T = P2_VISB1T + pk::k32_floats(2);
+constexpr int P2_VIS1T = P2_VIS2T + pk::k32_floats(2);
+constexpr int P2_BASE2T = P2_VIS1T + pk::k32_floats(2);          //                                                       1 x 4
+constexpr int P2_BASE1XT = P2_BASE2T + pk::k32_floats(4);        //                                                       2 x 3
+constexpr int P2_BASE1ET = P2_BASE1XT + 2 * pk::k32_floats(3);   //                                                       2 x 2
+constexpr int P2_END = P2_BASE1ET + 2 * pk::k32_floats(2);
+constexpr int P1_BEGIN = P2_END;                             // first view loop (k_view1_bwd)
+constexpr int P1_DEC2T = P1_BEGIN;                           // 3 x (1 x 2)
+constexpr int P1_DEC1T = P1_DEC2T + 3 * pk::k32_floats(2);
+constexpr int P1_PE2F = P1_DEC1T + 3 * pk::k32_floats(2);
+constexpr int P1_B_PE2 = P1_PE2F + pk::k32_floats(2);
+constexpr int P1_PE2T = P1_B_PE2 + 32;
+constexpr int P1_PE0T = P1_PE2T + pk::k32_floats(2);
+constexpr int P1_END = P1_PE0T + pk::k32_floats(2);
+constexpr int P_DECV2T = P1_END;                             // use_vis branch (zero unless gnr_pack_vis_decoder_bwd filled it)
+constexpr int P_DECV1T = P_DECV2T + pk::k32_floats(2);
+constexpr int TOTAL = P_DECV1T + pk::k32_floats(2);
+static_assert(P2_BEGIN % 4 == 0 && P1_BEGIN % 4 == 0 && P_DECV2T % 4 == 0, "pair blocks are read as 16-byte vectors");
 }  // namespace pkb
 
 }  // namespace gnr

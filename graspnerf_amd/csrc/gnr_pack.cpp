@@ -58,6 +58,7 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
     if (!c || !p) return GNR_ERR_ARG;
     std::memset(p, 0, sizeof(float) * gnr::pkb::TOTAL);
     gnr::packer::pack_backward(gnr::packer::HostExec(), c, p);
+    gnr::packer::pack_backward_pairs(gnr::packer::HostExec(), p);
     return GNR_OK;
 }
 
@@ -66,6 +67,7 @@ extern "C" int gnr_pack_weights_bwd(const float* c, float* p) {
 extern "C" int gnr_pack_vis_decoder_bwd(const float* v, float* p) {
     if (!v || !p) return GNR_ERR_ARG;
     gnr::packer::pack_vis_backward(gnr::packer::HostExec(), v, p);
+    gnr::packer::pack_vis_backward_pairs(gnr::packer::HostExec(), p);
     return GNR_OK;
 }
 

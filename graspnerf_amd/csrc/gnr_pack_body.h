@@ -472,6 +472,41 @@ GNR_HD void pack_backward(const Ex& ex, const float* c, float* p) {
     ex.run(16, [&](int t) { p[pkb::T_RGB0V + t] = c[can::RGB0_W + t * 37 + 32]; });
 }
 
+// fp16-pair images of the backward blob (pkb::P2_BEGIN ..): second phase of the backward pack, reads the fp32 fragments
+// pack_backward wrote (on the device: its own launch)
+GNR_HD inline C16Plan pair_plan(int J, int NB) {
+    C16Plan pl{0, J, NB, J / 8, {0, 8, 16, 24, 32}, {8, 8, 8, 8, 8}, 0, {0, 0}};
+    return pl;
+}
+template <class Ex>
+GNR_HD void pack_backward_pairs(const Ex& ex, float* p) {
+    float* bad = p + pkb::P2_B_PE2 + 31;           // (a transposed weight beyond the fp16 range is a forward weight beyond it: the forward
+    (void)bad;                                     //  blob's flag already sends every launch to the fp32 kernels; nothing to record here)
+    float sink0 = 0.f, sink1 = 0.f;
+    auto pairs = [&](int dst, int src, int J, int NB) { to_pairs(ex, p + dst, p + src, pair_plan(J, NB), &sink0, &sink1); };
+    pairs(pkb::P2_PE2F, pkb::PE2F, 8, 2);
+    ex.run(32, [&](int t) { p[pkb::P2_B_PE2 + t] = p[pkb::B_PE2 + t]; p[pkb::P1_B_PE2 + t] = p[pkb::V1_B_PE2 + t]; });
+    pairs(pkb::P2_VISB1T, pkb::VISB1T, 8, 2);
+    pairs(pkb::P2_VIS2T, pkb::VIS2T, 8, 2);
+    pairs(pkb::P2_VIS1T, pkb::VIS1T, 8, 2);
+    pairs(pkb::P2_BASE2T, pkb::BASE2T, 8, 4);
+    pairs(pkb::P2_BASE1XT, pkb::BASE1XT, 16, 3);
+    pairs(pkb::P2_BASE1ET, pkb::BASE1ET, 16, 2);
+    for (int br = 0; br < 3; ++br) {
+        pairs(pkb::P1_DEC2T + br * pk::k32_floats(2), pkb::DEC2T + br * 1024, 8, 2);
+        pairs(pkb::P1_DEC1T + br * pk::k32_floats(2), pkb::DEC1T + br * 1024, 8, 2);
+    }
+    pairs(pkb::P1_PE2F, pkb::V1_PE2F, 8, 2);
+    pairs(pkb::P1_PE2T, pkb::PE2T, 8, 2);
+    pairs(pkb::P1_PE0T, pkb::PE0T, 8, 2);
+}
+template <class Ex>
+GNR_HD void pack_vis_backward_pairs(const Ex& ex, float* p) {
+    float sink0 = 0.f, sink1 = 0.f;
+    to_pairs(ex, p + pkb::P_DECV2T, p + pkb::DECV2T, pair_plan(8, 2), &sink0, &sink1);
+    to_pairs(ex, p + pkb::P_DECV1T, p + pkb::DECV1T, pair_plan(8, 2), &sink0, &sink1);
+}
+
 // The fourth decoder branch's transposed fragments (use_vis training) into a blob of pack_backward; output rows of
 // vis_decoder.0^T land in the gather layout like DEC1T.
 template <class Ex>

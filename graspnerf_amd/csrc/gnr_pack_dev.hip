@@ -23,6 +23,8 @@ __global__ __launch_bounds__(256) void k_pack_c16_copy(float* p) { packer::c16_c
 __global__ __launch_bounds__(256) void k_pack_c16_pairs(float* p) { packer::c16_pairs(dev_exec(), p); }
 __global__ __launch_bounds__(256) void k_pack_backward(const float* __restrict__ c, float* __restrict__ p) { packer::pack_backward(dev_exec(), c, p); }
 __global__ __launch_bounds__(256) void k_pack_vis_backward(const float* __restrict__ v, float* __restrict__ p) { packer::pack_vis_backward(dev_exec(), v, p); }
+__global__ __launch_bounds__(256) void k_pack_backward_pairs(float* p) { packer::pack_backward_pairs(dev_exec(), p); }
+__global__ __launch_bounds__(256) void k_pack_vis_backward_pairs(float* p) { packer::pack_vis_backward_pairs(dev_exec(), p); }
 
 constexpr int PACK_BLOCKS = 64, PACK_THREADS = 256;       // 16 384 threads: the largest fragment (HOIST, 9 216 entries) in one sweep
 int c16_image(float* p, hipStream_t st) {
@@ -50,11 +52,13 @@ extern "C" int gnr_pack_vis_decoder_device(const float* vis_decoder_dev, float* 
 extern "C" int gnr_pack_weights_bwd_device(const float* canonical_dev, float* packed_bwd_dev, void* stream) {
     if (!canonical_dev || !packed_bwd_dev) return GNR_ERR_ARG;
     hipLaunchKernelGGL(gnr::k_pack_backward, dim3(gnr::PACK_BLOCKS), dim3(gnr::PACK_THREADS), 0, (hipStream_t)stream, canonical_dev, packed_bwd_dev);
+    hipLaunchKernelGGL(gnr::k_pack_backward_pairs, dim3(gnr::PACK_BLOCKS), dim3(gnr::PACK_THREADS), 0, (hipStream_t)stream, packed_bwd_dev);
     return hipGetLastError() == hipSuccess ? GNR_OK : GNR_ERR_HIP;
 }
 
 extern "C" int gnr_pack_vis_decoder_bwd_device(const float* vis_decoder_dev, float* packed_bwd_dev, void* stream) {
     if (!vis_decoder_dev || !packed_bwd_dev) return GNR_ERR_ARG;
     hipLaunchKernelGGL(gnr::k_pack_vis_backward, dim3(gnr::PACK_BLOCKS), dim3(gnr::PACK_THREADS), 0, (hipStream_t)stream, vis_decoder_dev, packed_bwd_dev);
+    hipLaunchKernelGGL(gnr::k_pack_vis_backward_pairs, dim3(gnr::PACK_BLOCKS), dim3(gnr::PACK_THREADS), 0, (hipStream_t)stream, packed_bwd_dev);
     return hipGetLastError() == hipSuccess ? GNR_OK : GNR_ERR_HIP;
 }

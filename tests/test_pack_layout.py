@@ -255,7 +255,11 @@ def _bwd_offsets():
                    ('BASE1XT', ff(16, 3)), ('BASE1ET', ff(16, 2)), ('HOISTT_A', ff(16, 4)), ('HOISTT_B', ff(16, 4)),
                    ('HOISTT_C', ff(16, 1)), ('DEC2T', 3072), ('DEC1T', 3072), ('V1_PE2F', 1024), ('V1_B_PE2', 32), ('PE2T', 1024),
                    ('PE0T', 1024), ('T_PE0HV', 64), ('NR0T', ff(4, 2)), ('RDF2T', ff(9, 1)), ('RGB2T', ff(4, 1)),
-                   ('RGB0HT', ff(4, 2)), ('T_RGB0V', 16), ('DECV2T', 1024), ('DECV1T', 1024)]
+                   ('RGB0HT', ff(4, 2)), ('T_RGB0V', 16), ('DECV2T', 1024), ('DECV1T', 1024),
+                   # fp16-pair images of the fragments the backward twins multiply on the f16 matrix cores (pkb::P2_*, P1_*, P_DECV*)
+                   ('P2_PE2F', 1024), ('P2_B_PE2', 32), ('P2_VISB1T', 1024), ('P2_VIS2T', 1024), ('P2_VIS1T', 1024), ('P2_BASE2T', 2048),
+                   ('P2_BASE1XT', 2 * 1536), ('P2_BASE1ET', 2048), ('P1_DEC2T', 3072), ('P1_DEC1T', 3072), ('P1_PE2F', 1024),
+                   ('P1_B_PE2', 32), ('P1_PE2T', 1024), ('P1_PE0T', 1024), ('P_DECV2T', 1024), ('P_DECV1T', 1024)]
     for name, n in order:
         BWD_OFF[name] = o
         o += n
@@ -269,10 +273,16 @@ def test_bwd_fragments_compute_transposed_products(weights_np):
     rng = np.random.default_rng(0)
     vis = rng.standard_normal(_lib.lib().gnr_canonical_vis_floats()).astype(np.float32)       # use_vis: the fourth decoder branch
     assert vis.size == 2145
-    assert np.array_equal(weights.pack_bwd(can)[-2048:], np.zeros(2048, np.float32))          # absent: its sections stay zero
-    pb = weights.pack_bwd(can, vis)
-    assert np.array_equal(pb[:-2048], weights.pack_bwd(can)[:-2048])
     O = _bwd_offsets()
+    plain = weights.pack_bwd(can)
+    vis_secs = [(O['DECV2T'], 2048), (O['P_DECV2T'], 2048)]                                   # fp32 fragments and their pair images
+    for o, n in vis_secs:
+        assert np.array_equal(plain[o:o + n], np.zeros(n, np.float32))                        # absent: its sections stay zero
+    pb = weights.pack_bwd(can, vis)
+    keep = np.ones(pb.size, bool)
+    for o, n in vis_secs:
+        keep[o:o + n] = False
+    assert np.array_equal(pb[keep], plain[keep])
     W = lambda k: weights_np['agg_net.agg_impl.' + k]
     gather = lambda nb, i: 8 * (i // 4) + 4 * nb + (i % 4)
     natO = lambda nb, i: 16 * nb + i
@@ -538,3 +548,33 @@ def test_gradient_blob_key_order_with_and_without_the_vis_decoder():
         assert parts[dec + 'vis_decoder.0.weight'].shape == (32, 32) and parts[dec + 'vis_decoder.0.weight'][0, 0] == n
         assert parts[dec + 'vis_decoder.4.bias'].reshape(-1)[0] == n + nv - 1
         assert sum(int(np.prod(s)) if len(s) else 1 for _, s in base) == n
+
+
+def test_bwd_pair_images_encode_their_fp32_fragments(weights_np):
+    """The pair images of the backward blob (what k_view2_bwd / k_view1_bwd stage into LDS for their dX chains and for prob_embed.2's
+    forward): block b, output block nb of a J x NB fragment holds, per lane, 8 halfs h and 8 halfs m with h + m 2^-11 = the fp32
+    fragment's k-steps 8b .. 8b+7 to an fp32 ulp or two (exactly for most values); the bias copies are copies."""
+    can = weights.canonical_blob(weights_np, 'coarse')
+    vis = np.random.default_rng(0).standard_normal(2145).astype(np.float32)
+    pb = weights.pack_bwd(can, vis)
+    O = _bwd_offsets()
+    fi = lambda NB, j, nb, lane: ((j // 4) * 64 + lane) * 4 + (j % 4) if NB == 1 else ((j * 64 + lane) * 4 + nb if NB == 3 else (j * 64 + lane) * NB + nb)
+    cases = [('P2_PE2F', 'PE2F', 8, 2), ('P2_VISB1T', 'VISB1T', 8, 2), ('P2_VIS2T', 'VIS2T', 8, 2), ('P2_VIS1T', 'VIS1T', 8, 2),
+             ('P2_BASE2T', 'BASE2T', 8, 4), ('P2_BASE1XT', 'BASE1XT', 16, 3), ('P2_BASE1ET', 'BASE1ET', 16, 2),
+             ('P1_PE2F', 'V1_PE2F', 8, 2), ('P1_PE2T', 'PE2T', 8, 2), ('P1_PE0T', 'PE0T', 8, 2), ('P_DECV2T', 'DECV2T', 8, 2), ('P_DECV1T', 'DECV1T', 8, 2)] + \
+            [('P1_DEC2T', 'DEC2T', 8, 2, br) for br in range(3)] + [('P1_DEC1T', 'DEC1T', 8, 2, br) for br in range(3)]
+    lane = np.arange(64)
+    for c in cases:
+        dst, src, J, NB = c[:4]
+        br = c[4] if len(c) > 4 else 0
+        d0, s0 = O[dst] + br * 1024, O[src] + br * 1024
+        halfs = pb[d0:d0 + (J // 8) * NB * 512].view(np.float16)
+        for b in range(J // 8):
+            for nb in range(NB):
+                for i in range(8):
+                    h = halfs[(((b * NB + nb) * 2 + 0) * 64 + lane) * 8 + i].astype(np.float64)
+                    m = halfs[(((b * NB + nb) * 2 + 1) * 64 + lane) * 8 + i].astype(np.float64)
+                    w = pb[s0 + np.array([fi(NB, 8 * b + i, nb, l) for l in lane])].astype(np.float64)
+                    assert np.all(np.abs(h + m / 2048.0 - w) <= 2.0 ** -22 * np.abs(w) + 2.0 ** -35), (dst, b, nb, i)      # one to two fp32 ulps; below 6e-5 the halves are fp16 subnormals: 3e-11 absolute
+    assert np.array_equal(pb[O['P2_B_PE2']:O['P2_B_PE2'] + 32], pb[O['B_PE2']:O['B_PE2'] + 32])
+    assert np.array_equal(pb[O['P1_B_PE2']:O['P1_B_PE2'] + 32], pb[O['V1_B_PE2']:O['V1_B_PE2'] + 32])
