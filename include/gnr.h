@@ -288,6 +288,9 @@ int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, i
  *                         gnr_depth_mean_bwd_workspace_bytes(scene) for the partial parameter gradients and the
  *                         channel-last feature gradient (required, also with d_ray_feats == NULL).            */
 int gnr_debug_poison_partials(int on);
+/* Measurement / test switch: the backward of the first view loop as k_view1_bwd (one wavefront per tile, 0) or as k_view1_bwd_pw
+ * (a compute wavefront and its partner per tile, 1: the default).  Same outputs either way; returns the old setting. */
+int gnr_debug_view1_partner(int on);
 int gnr_packed_bwd_floats(void);
 int gnr_pack_weights_bwd(const float* canonical_host, float* packed_bwd_host);
 size_t gnr_depth_mean_bwd_workspace_bytes(const GnrScene* scene);
