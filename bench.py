@@ -92,7 +92,7 @@ def recorded_bwd_traffic(scenes):
     if d is None:
         return None, None
     try:
-        k = d['kernels'].get('k_view1_bwd<false>') or d['kernels']['k_view1_bwd']      # (a template since the use_vis twin; older files: plain)
+        k = d['kernels'].get('k_view1_bwd_pw') or d['kernels'].get('k_view1_bwd<false>') or d['kernels']['k_view1_bwd']      # (round 5: the partner-wavefront kernel; before: the template / the plain kernel)
         return (int(k['hbm_bytes_corrected']), src) if scenes == 8 else (None, None)
     except KeyError:
         return None, None
@@ -478,7 +478,7 @@ def train_leg(args, world, rank, dev, dist, sync):
                                           'everything_else = 2D backbones, grasp head under autograd (MIOpen), losses, optimizer, '
                                           'all-reduce and host gaps'},
             'hip_kernels_ms_per_step': per_step,
-            'roofline': {'bound': 'mfma', 'kernel': 'k_view1_bwd on the volume points (gnr_sample_volume_bwd)', 'achieved': round(ach, 3),
+            'roofline': {'bound': 'mfma', 'kernel': 'k_view1_bwd_pw (first view loop backward, compute + partner wavefronts) on the volume points (gnr_sample_volume_bwd)', 'achieved': round(ach, 3),
                          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'ms_per_launch': round(ms, 4),
                          'launches_timed': cnt, 'flops_per_launch': fl, 'traffic': recorded_bwd_traffic(n)[0],
                          'traffic_source': recorded_bwd_traffic(n)[1],

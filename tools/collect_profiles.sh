@@ -20,12 +20,6 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU S
   N=$(echo $SET | tr ' ' '_')
   rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/$TAG/pmc/bwd_$N -o p -- python $R/tools/time_volume_bwd.py --scenes 8 > $R/gpurun_out/$TAG/pmc_bwd_$N.log 2>&1
 done
-# the render launch with the rays in pixel-Morton order (gnr_debug_ray_order, a measured negative): its L2 counters next to the default's
-for SET in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-  N=$(echo $SET | tr ' ' '_')
-  rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/$TAG/pmc_order/$N -o p -- python $R/tools/run_hot.py --iters 1 --distinct --ray-order > $R/gpurun_out/$TAG/pmc_order_$N.log 2>&1
-  rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/$TAG/pmc_caller/$N -o p -- python $R/tools/run_hot.py --iters 1 --distinct > $R/gpurun_out/$TAG/pmc_caller_$N.log 2>&1
-done
 [ $MODE = all ] && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace_train -o t -- python $R/tools/train_step_bench.py --steps 3 --warmup 3 > $R/gpurun_out/$TAG/train_under_rocprof.json 2> $R/gpurun_out/$TAG/trace_train.log
 cd $R
 if [ $MODE = pmc ]; then
@@ -39,8 +33,6 @@ python tools/prof_summary.py $DB "$TAG: rocprofv3 --kernel-trace --stats -- pyth
 DB=$(find gpurun_out/$TAG/trace_train -name "*.db" | head -1)
 python tools/prof_summary.py $DB "$TAG: rocprofv3 --kernel-trace --stats -- python tools/train_step_bench.py --steps 3 --warmup 3 (8 scenes per step, 1x MI355X); kernels that started in the last 330 ms of the trace = the steady-state steps" --last-ms 330 > gpurun_out/$TAG/train_step_kernel_stats.txt
 python tools/pmc_summary.py gpurun_out/$TAG/pmc gpurun_out/$TAG/pmc_counters.json > gpurun_out/$TAG/pmc_summary.log
-python tools/pmc_summary.py gpurun_out/$TAG/pmc_order gpurun_out/$TAG/pmc_ray_order_morton.json > /dev/null
-python tools/pmc_summary.py gpurun_out/$TAG/pmc_caller gpurun_out/$TAG/pmc_ray_order_caller.json > /dev/null
 # the counters the bench line replays must be the ones just collected: put them where bench.py looks (profiles/, newest by name)
 cp gpurun_out/$TAG/pmc_counters.json profiles/${TAG}_pmc_counters.json
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
@@ -49,4 +41,4 @@ python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 head -14 gpurun_out/$TAG/bench_kernel_stats.txt
 head -30 gpurun_out/$TAG/train_step_kernel_stats.txt | cut -c1-130
 tail -1 gpurun_out/$TAG/bench.json | cut -c1-300
-rm -rf gpurun_out/$TAG/trace gpurun_out/$TAG/pmc gpurun_out/$TAG/pmc_order gpurun_out/$TAG/pmc_caller gpurun_out/$TAG/trace_train
+rm -rf gpurun_out/$TAG/trace gpurun_out/$TAG/pmc gpurun_out/$TAG/trace_train
