@@ -98,9 +98,10 @@ class Trainer:
             return world
         flat, views = self._flat_views()
         torch._foreach_copy_(views, grads)
-        flat[-1] = float(n_local)
+        flat[-1:].fill_(float(n_local))                     # (a kernel launch; `flat[-1] = x` is a pageable host-to-device copy the HOST waits for:
+                                                            #  measured, tools/dbg/allreduce_blocking.py -- it cost the step its run-ahead, 3 - 4.6 ms)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat[:-1].div_(flat[-1].clamp(min=1.0))
+        flat[:-1].div_(flat[-1:].clamp(min=1.0))           # (a one-element tensor, broadcast on the device)
         torch._foreach_copy_(grads, views)
         return world
 
