@@ -312,3 +312,57 @@ def test_render_chain_twin_matches_autograd(V, rn, dn, weights_np):
     assert n >= 40
     _close(dray[0], tref['ray_feats'].grad, 'd ray_feats', rel=1e-3)
     _close(dimg[0], tref['img_feats'].grad, 'd img_feats', rel=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('V,res,B', [(6, 8, 2), (3, 5, 1)])
+def test_partner_wavefront_kernels_agree_with_the_single_wavefront_kernels(V, res, B, weights_np):
+    """Round 5: the two view loops' backward runs as k_view{1,2}_bwd_pw (a compute wavefront and its partner per tile, two per SIMD);
+    the single-wavefront kernels of rounds 1-4 stay in the library (use_vis levels take k_view1_bwd<true>) behind
+    gnr_debug_view1_partner.  Same sums in another order: parameter gradients (per tensor) and feature-map gradients equal to 2e-5
+    of their scale -- on the volume points and on a render pass, with small (1e-4) and large (1e3) upstream gradients."""
+    from graspnerf_amd import _lib
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    from graspnerf_amd.synth import CONFIGS
+    L = _lib.lib()
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    can = {lvl: weights.canonical_blob(weights_np, lvl) for lvl in ('coarse', 'fine')}
+    hp.set_bwd_weights(weights.pack_bwd(can['coarse']), weights.pack_bwd(can['fine']))
+    rn, dn = 21, 16
+    scenes = [make_scene(70 + i, dict(CONFIGS['cfg1'], V=V, rn=rn)) for i in range(B)]
+    bref, bque = batch_scenes(scenes)
+    rng = np.random.default_rng(V + res)
+    dvol = torch.from_numpy(rng.standard_normal((B, 1, res, res, res)).astype(np.float32)).cuda() * 1e-4     # small gradients: the power-of-two normalisation at work
+    depth = torch.sort(torch.from_numpy(rng.uniform(0.25, 0.75, (B, rn, dn)).astype(np.float32)), -1)[0].cuda()
+    ds = torch.from_numpy(rng.standard_normal((B, rn * dn, 65)).astype(np.float32)).cuda() * 1e3            # and large ones
+    dc = torch.from_numpy(rng.standard_normal((B, rn * dn, 3)).astype(np.float32)).cuda() * 1e3
+    cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+    bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
+    out = {}
+    old = L.gnr_debug_view1_partner(1)
+    try:
+        for mode in (1, 0):
+            L.gnr_debug_view1_partner(mode)
+            hp.sample_volume_train(bref, res)
+            vol_g = hp.sample_volume_bwd(dvol, torch.from_numpy(can['coarse']).cuda())
+            prep = hp.prepare(bref, 1, rn, dn)
+            _, _, _, ctx = hp.render_chain_train(bq, depth, 'fine', cfg, prep)
+            ren_g = hp.render_chain_bwd(ctx, ds, dc)
+            torch.cuda.synchronize()
+            out[mode] = [t.clone() for t in vol_g] + [t.clone() for t in ren_g]
+    finally:
+        L.gnr_debug_view1_partner(old & 1 if old in (0, 1) else 1)
+    names = ['volume d_canonical', 'volume d_ray_feats', 'volume d_img_feats', 'render d_canonical', 'render d_ray_feats', 'render d_img_feats']
+    for name, a, b in zip(names, out[1], out[0]):
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0, name
+        tol = 2e-5           # another summation order of fp32 partial sums (sums with cancellation: a bias of 7e-7 moved by 2e-12)
+        # per parameter tensor for the blobs (their scales differ by orders of magnitude), whole tensor for the feature maps
+        if 'canonical' in name:
+            lvl = 'coarse' if name.startswith('volume') else 'fine'
+            ga, gb = weights.split_canonical(a[:36958], lvl), weights.split_canonical(b[:36958], lvl)
+            for k in ga:
+                sc = float(gb[k].abs().max())
+                if sc > 0 and not k.endswith('rgb_fc.4.bias'):         # (a bias in front of a softmax over views: exactly zero, both sides hold rounding noise)
+                    assert float((ga[k] - gb[k]).abs().max()) <= tol * sc + 1e-30, (name, k, float((ga[k] - gb[k]).abs().max()), sc)
+        else:
+            assert float((a - b).abs().max()) <= tol * float(b.abs().max()), name

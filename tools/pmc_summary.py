@@ -48,7 +48,7 @@ def commit_count():
 json.dump({
     'git_commit_count': commit_count(),
     # bench.py reports these counters only while the stamps equal the sha256 of the kernel sources it runs (bench.py newest_pmc)
-    'kernel_source_sha16': sha16('gnr_kernels.hip'), 'bwd_source_sha16': sha16('gnr_kernels.hip', 'gnr_bwd.inc'),
+    'kernel_source_sha16': sha16('gnr_kernels.hip'), 'bwd_source_sha16': sha16('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc'),
     'command': 'rocprofv3 --pmc <set> --output-format csv -- python tools/run_hot.py --iters 1   (forward kernels: B=32 scenes, 6 views, '
                '40^3 + 512 rays) and -- python tools/time_volume_bwd.py --scenes 8 (k_*_bwd kernels of sample_volume: 8 scenes); '
                'one run per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU SQ_INSTS_MFMA | '
