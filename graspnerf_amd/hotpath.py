@@ -103,6 +103,11 @@ class HotPath:
         _lib.check(self.L.gnr_range_status(C.byref(scene), ws.data_ptr(), ws.numel(), C.byref(flags), self._stream()), 'gnr_range_status')
         return int(flags.value)
 
+    def feature_grad_mode(self, fixed_point):
+        """Process-wide: feature-map gradients through 64-bit fixed-point adds (bit-reproducible) instead of float atomics
+        (include/gnr.h gnr_feature_grad_mode; -> previous setting).  range_status() bit 3 tells a clamped contribution."""
+        return bool(self.L.gnr_feature_grad_mode(1 if fixed_point else 0))
+
     def force_fp32_chain(self, on):
         """Process-wide test / measurement switch: every chain launch on the fp32-input MFMA (-> previous setting)."""
         return bool(self.L.gnr_force_fp32_chain(1 if on else 0))

@@ -44,14 +44,20 @@ def exp_decay_lr(step, lr_init=1e-4, decay_step=100000, decay_rate=0.5, lr_min=1
 
 
 class Trainer:
-    def __init__(self, net, lr_cfg=None, batched=True, log_every=1, flat_exchange='auto'):
-        """log_every: the loss terms leave the device every log_every-th step only (the reference writes its log every
+    def __init__(self, net, lr_cfg=None, batched=True, log_every=1, flat_exchange='auto', reproducible_feature_grads=False):
+        """reproducible_feature_grads: the path's feature-map gradients (the gradients it hands the 2D backbones) through 64-bit
+        fixed-point adds instead of float atomics (include/gnr.h gnr_feature_grad_mode): with it every gradient the HIP path produces is
+        the same bits from run to run, as on the reference's CPU path; process-wide, ~0.7 % of the step.
+        log_every: the loss terms leave the device every log_every-th step only (the reference writes its log every
         `train_log_step` = 20 steps, trainer.py:31,159; what it reads back EVERY step is the loss shown in its progress bar, :190).  With
         log_every = 1 every step() returns floats -- and ends in a device-to-host copy the host waits for, so the queue of the next step
         starts empty: the GPU idles while the host launches its first kernels, every step.  In between step() returns only `lr`; the terms
         of the latest step stay on the device until last_log() asks for them."""
         self.net = net
         self.batched = batched
+        if reproducible_feature_grads:
+            from . import _lib
+            _lib.lib().gnr_feature_grad_mode(1)
         self.log_every = max(int(log_every), 1)
         self._pending = None
         self.flat_exchange = flat_exchange

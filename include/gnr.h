@@ -146,7 +146,8 @@ int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, 
  * in-range scenes pay ~5 us per chain launch, and no call synchronises with the host.
  * gnr_range_status reads the watch word of the last gnr_prepare on this workspace (synchronises `stream`):
  *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range;
- *   bit 2: a weight beyond the fp16 range (gnr_pack_weights marks such a blob instead of refusing it).
+ *   bit 2: a weight beyond the fp16 range (gnr_pack_weights marks such a blob instead of refusing it);
+ *   bit 3: (backward, gnr_feature_grad_mode(1) only) a feature-map gradient contribution was clamped to the fixed-point range.
  * Bits 0 and 2 hold for every launch on the prepared scene (the pair kernel then returns at once and the twin computes the launch);
  * bit 1 is watched per launch slot (volume, coarse pass, fine pass, the training forwards), so a scene whose coarse pass tripped it
  * does not pay the recomputation on its volume or fine pass; the status word is the OR over the slots.
@@ -273,8 +274,14 @@ int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, i
  * wavefronts statically, every wavefront stores its partial sums into its own slot of a partial buffer inside the
  * caller-owned scratch / training workspace, and one reduction kernel per entry point adds the slots in slot order (in
  * double) into d_canonical / dtail.  Two calls on the same inputs return the same bits (the reference's CPU backward is
- * deterministic as well: ibrnet.py:497-504 + autograd).  Only the feature-map gradients (d_ray_feats, d_img_feats: a
- * bilinear scatter, like ATen's grid_sampler backward on a GPU) are accumulated with float atomics.
+ * deterministic as well: ibrnet.py:497-504 + autograd).  The feature-map gradients (d_ray_feats, d_img_feats: a bilinear
+ * scatter, like ATen's grid_sampler backward on a GPU) are accumulated with float atomics by default: their low bits depend on
+ * the arrival order.  gnr_feature_grad_mode(1) makes them BIT-REPRODUCIBLE too: every contribution is rounded once to a multiple
+ * of a launch-wide power-of-two quantum (2^-28 of the launch's largest upstream gradient, found by an order-independent maximum)
+ * and added as a 64-bit integer (integer adds commute); a contribution more than 2^14 times the upstream maximum is clamped and
+ * raises bit 3 of gnr_range_status.  Costs twice the atomic traffic of the float path.  Process-wide; returns the old mode.
+ * Every entry point that produces feature-map gradients honours it (gnr_depth_mean_bwd, gnr_sample_volume_bwd,
+ * gnr_render_chain_bwd); their workspaces are sized for either mode.
  * gnr_debug_poison_partials(1) fills the partial buffers with NaN patterns before the kernels run (tests: an entry no
  * wavefront stores would show in the reduced gradient); returns the old setting.
  * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
@@ -288,6 +295,7 @@ int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, i
  *                         gnr_depth_mean_bwd_workspace_bytes(scene) for the partial parameter gradients and the
  *                         channel-last feature gradient (required, also with d_ray_feats == NULL).            */
 int gnr_debug_poison_partials(int on);
+int gnr_feature_grad_mode(int mode);       /* 0: float atomics (default); 1: 64-bit fixed point, bit-reproducible */
 /* Measurement / test switch: the backward of the first view loop as k_view1_bwd (one wavefront per tile, 0) or as k_view1_bwd_pw
  * (a compute wavefront and its partner per tile, 1: the default).  Same outputs either way; returns the old setting. */
 int gnr_debug_view1_partner(int on);

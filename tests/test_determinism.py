@@ -2,8 +2,9 @@
 fixed-order reduction in double, no float atomics): two calls on the same inputs return the same BITS, like the
 reference's CPU backward (ibrnet.py:497-504 + autograd, trainer.py:146-158), and every entry of every partial slot is
 stored by exactly one wavefront (the poisoned run would show a missing store as NaN in the reduced gradient).
-Only the feature-map gradients (a bilinear scatter with float atomics, like ATen's grid_sampler backward on a GPU) may
-differ between runs, within rounding."""
+The feature-map gradients are a bilinear scatter: with float atomics (the default, like ATen's grid_sampler backward on a GPU) they
+may differ between runs within rounding; with gnr_feature_grad_mode(1) (64-bit fixed-point adds, include/gnr.h) they are equal
+bit for bit as well, and equal to the float path's within its own run-to-run spread.  Every test runs in both modes."""
 import numpy as np
 import pytest
 import torch
@@ -27,6 +28,36 @@ def _feat_close(a, b):
     assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9
 
 
+@pytest.fixture(params=['float_atomics', 'fixed_point'])
+def feat_same(request):
+    """Sets the feature-gradient mode; yields the comparison two runs' feature-map gradients must pass."""
+    L = _lib.lib()
+    prev = L.gnr_feature_grad_mode(1 if request.param == 'fixed_point' else 0)
+
+    def same(a, b):
+        if request.param == 'fixed_point':
+            assert torch.equal(a, b)
+        else:
+            _feat_close(a, b)
+    same.fixed = request.param == 'fixed_point'
+    yield same
+    L.gnr_feature_grad_mode(prev)
+
+
+def _float_mode(fn):
+    """fn() with the float-atomic scatter (reference values for the fixed-point runs)."""
+    L = _lib.lib()
+    prev = L.gnr_feature_grad_mode(0)
+    try:
+        return fn()
+    finally:
+        L.gnr_feature_grad_mode(prev)
+
+
+def _not_clamped(hp, prep=None):
+    assert hp.range_status(prep) & 8 == 0, 'a feature-gradient contribution left the fixed-point range'
+
+
 @pytest.fixture()
 def poison():
     """Runs the test body with the partial buffers poisoned (NaN patterns) before every backward kernel."""
@@ -46,7 +77,7 @@ def _volume_case(hp, V, res, B, H=96, W=128):
 
 
 @pytest.mark.parametrize('V,res,B,H,W', [(3, 16, 2, 96, 128), (6, 40, 2, 288, 512)])
-def test_sample_volume_bwd_is_bit_reproducible(V, res, B, H, W, weights_np, poison):
+def test_sample_volume_bwd_is_bit_reproducible(V, res, B, H, W, weights_np, poison, feat_same):
     """All five stages, the second case at the benchmark's scene size (6 views 288x512, 40^3: every CU's four wavefronts hold
     tiles): parameter gradients equal bit for bit, no entry of a slot left unstored."""
     hp = _hot(weights_np)
@@ -57,11 +88,17 @@ def test_sample_volume_bwd_is_bit_reproducible(V, res, B, H, W, weights_np, pois
     assert float(runs[0][0].abs().max()) > 0
     for r in runs[1:]:
         assert torch.equal(r[0], runs[0][0])
-        _feat_close(r[1], runs[0][1]); _feat_close(r[2], runs[0][2])
+        feat_same(r[1], runs[0][1]); feat_same(r[2], runs[0][2])
+    if feat_same.fixed:                                            # the same values as the float path, to that path's own spread
+        ref = _float_mode(lambda: hp.sample_volume_bwd(dvol, hp.can_dev['coarse']))
+        assert torch.equal(ref[0], runs[0][0])
+        _feat_close(runs[0][1], ref[1]); _feat_close(runs[0][2], ref[2])
+        assert float(runs[0][1].abs().max()) > 0 and float(runs[0][2].abs().max()) > 0
+        _not_clamped(hp)
 
 
 @pytest.mark.parametrize('V,rn,dn', [(3, 33, 16), (6, 512, 40)])
-def test_render_pass_bwd_is_bit_reproducible(V, rn, dn, weights_np, poison):
+def test_render_pass_bwd_is_bit_reproducible(V, rn, dn, weights_np, poison, feat_same):
     """One training render pass backwards: per-view chain (k_red2 / k_view2<true> / k_hoist / k_view1), geometry_fc on dual numbers,
     the per-ray tail with its second-order path and the compositing -- every parameter gradient equal bit for bit."""
     from graspnerf_amd.hotpath import batch_scenes
@@ -98,10 +135,16 @@ def test_render_pass_bwd_is_bit_reproducible(V, rn, dn, weights_np, poison):
         assert bool(torch.isfinite(v).all()), k
         assert float(v.abs().max()) > 0, k
         assert torch.equal(p1[k], v) and torch.equal(p2[k], v), k
-    _feat_close(f1[0], f0[0]); _feat_close(f1[1], f0[1])
+    feat_same(f1[0], f0[0]); feat_same(f1[1], f0[1]); feat_same(f2[0], f0[0]); feat_same(f2[1], f0[1])
+    if feat_same.fixed:
+        pr, fr = _float_mode(once)
+        assert torch.equal(pr['dcan'], p0['dcan'])
+        _feat_close(f0[0], fr[0]); _feat_close(f0[1], fr[1])
+        assert float(f0[0].abs().max()) > 0 and float(f0[1].abs().max()) > 0
+        _not_clamped(hp, prep)
 
 
-def test_depth_mean_bwd_is_bit_reproducible(weights_np, poison):
+def test_depth_mean_bwd_is_bit_reproducible(weights_np, poison, feat_same):
     from graspnerf_amd.hotpath import batch_scenes
     hp = _hot(weights_np)
     bref, _ = batch_scenes([make_scene(s, 'cfg2') for s in (0, 1)])
@@ -115,17 +158,44 @@ def test_depth_mean_bwd_is_bit_reproducible(weights_np, poison):
     assert bool(torch.isfinite(runs[0][0]).all()) and float(runs[0][0].abs().max()) > 0
     for r in runs[1:]:
         assert torch.equal(r[0], runs[0][0])
-        _feat_close(r[1], runs[0][1])
+        feat_same(r[1], runs[0][1])
+    if feat_same.fixed:
+        ref = _float_mode(lambda: hp.depth_mean_bwd(bref, coords, dmean, 'coarse', prepared=prep))
+        _feat_close(runs[0][1], ref[1])
+        assert float(runs[0][1].abs().max()) > 0
+        _not_clamped(hp, prep)
+        zero = hp.depth_mean_bwd(bref, coords, np.zeros_like(dmean), 'coarse', prepared=prep)      # no upstream gradient: quantum falls back, nothing added
+        assert float(zero[1].abs().max()) == 0.0 and bool(torch.isfinite(zero[0]).all())
 
 
-def test_train_step_path_gradients_are_bit_reproducible():
+def test_fixed_point_feature_gradients_over_forty_orders_of_magnitude(weights_np, feat_same):
+    """The quantum follows the launch's largest upstream gradient: upstream gradients scaled by 1e-20 ... 1e+18 give feature-map
+    gradients that scale with them (a fixed quantum would return zeros at one end and clamp at the other)."""
+    if not feat_same.fixed:
+        pytest.skip('fixed-point mode only')
+    from graspnerf_amd.hotpath import batch_scenes
+    hp = _hot(weights_np)
+    bref, _ = batch_scenes([make_scene(s, 'cfg1') for s in (0, 1)])
+    rng = np.random.default_rng(9)
+    pn = 2048
+    coords = np.stack([rng.uniform(-1, 128, (2, pn)), rng.uniform(-1, 96, (2, pn))], -1).astype(np.float32)
+    dmean = rng.standard_normal((2, 3, pn, 2)).astype(np.float32)
+    prep = hp.prepare(bref, 1)
+    base = hp.depth_mean_bwd(bref, coords, dmean, 'coarse', prepared=prep)[1].double()
+    for k in (1e-20, 1e-6, 1e+9, 1e+18):
+        g = hp.depth_mean_bwd(bref, coords, (dmean.astype(np.float64) * k).astype(np.float32), 'coarse', prepared=prep)[1].double()
+        assert float((g / k - base).abs().max()) <= 1e-6 * float(base.abs().max()), k
+    _not_clamped(hp, prep)
+
+
+def test_train_step_path_gradients_are_bit_reproducible(feat_same):
     """A training step of BASELINE configs[4]'s kind (render, volume, depth-mean head, grasp head, losses; two scenes stacked)
     run twice from the same state, the same RNG stream and the same feature maps: every output of the forward and the gradient
     of every parameter of the volumetric path (dist decoders, aggregation nets: 122 tensors) come out bit-identical -- their
     upstream gradients pass through the losses and the grasp head, deterministic kernels as well.  The 2D feature extractors
     are held fixed here (their outputs are recorded once and replayed): MIOpen's convolutions are outside this library and not
-    bit-reproducible from call to call on this stack; the feature-map gradients the path hands them (a bilinear scatter with
-    float atomics) are compared to rounding only."""
+    bit-reproducible from call to call on this stack; the feature-map gradients the path hands them are compared to rounding in
+    the float-atomic mode and bit for bit in the fixed-point mode (sums over the volume, coarse, fine and depth-mean backward)."""
     from test_train_step import build, scene_data
     from graspnerf_amd.trainer import train_losses_stacked
     from graspnerf_amd import losses
@@ -170,4 +240,4 @@ def test_train_step_path_gradients_are_bit_reproducible():
     assert not bad, (len(bad), bad[:6], [float((grads[0][k] - grads[1][k]).abs().max()) for k in bad[:6]])
     assert len(feat[0]) >= 2
     for k in feat[0]:
-        _feat_close(feat[1][k], feat[0][k])
+        feat_same(feat[1][k], feat[0][k])

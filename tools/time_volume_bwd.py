@@ -10,12 +10,14 @@ from graspnerf_amd.synth import make_scene
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--scenes', type=int, default=8)
+ap.add_argument('--fixed-point-feature-grads', action='store_true', help='gnr_feature_grad_mode(1): 64-bit fixed-point scatter')
 a = ap.parse_args()
 wnp = dict(np.load(os.path.join(ROOT, 'tests/golden/weights_seed0.npz')))
 hp = HotPath(weights.pack_state_dict(wnp, 'coarse'), weights.pack_state_dict(wnp, 'fine'))
 can = weights.canonical_blob(wnp, 'coarse')
 hp.set_bwd_weights(weights.pack_bwd(can))
 can_dev = torch.from_numpy(can).cuda()
+hp.feature_grad_mode(a.fixed_point_feature_grads)
 one = make_scene(0, 'cfg2', with_query_image=False)
 bref, _ = batch_scenes([one] * a.scenes)
 bref = {k: torch.from_numpy(v).cuda() for k, v in bref.items()}

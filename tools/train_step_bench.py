@@ -18,6 +18,7 @@ ap.add_argument('--coords-rng', default='cpu', choices=['cpu', 'device'], help="
 ap.add_argument('--sync-debug', action='store_true')
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark: let MIOpen search its convolution solvers')
 ap.add_argument('--profile', default=None, help='write torch.profiler tables of one extra step to this file')
+ap.add_argument('--reproducible-feature-grads', action='store_true', help='feature-map gradients through 64-bit fixed-point adds (gnr_feature_grad_mode(1))')
 ap.add_argument('--cpus', type=int, default=0, help='pin the process to its first N allowed CPUs before torch is imported (0: leave the affinity alone)')
 ap.add_argument('--flat-exchange-steps', type=int, default=0, help='after the timed steps: this many further steps with the N > 1 gradient exchange (flat buffer + RCCL all-reduce on a one-rank group)')
 a = ap.parse_args()
@@ -65,7 +66,7 @@ net = GraspNeRF(CFG)
 syn = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
 net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.items()})
 net = net.to(dev)
-tr = Trainer(net, log_every=int(os.environ.get('LOG_EVERY', 20)))   # the reference's train_log_step (trainer.py:31)
+tr = Trainer(net, log_every=int(os.environ.get('LOG_EVERY', 20)), reproducible_feature_grads=a.reproducible_feature_grads)   # the reference's train_log_step (trainer.py:31)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 scenes = []
 for i in range(a.scenes):
@@ -129,7 +130,7 @@ if rank == 0:
     print(json.dumps({'metric': 'train scenes/sec (fwd+loss+bwd+allreduce+Adam), 6-view 40^3 grid + 512 rays', 'value': world * a.scenes * a.steps / dt,
                       'unit': 'scenes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
                       'scenes_per_gpu': a.scenes, 'depth_coords_rng': a.coords_rng, 'miopen_find': bool(a.miopen_find),
-                      'cpus_pinned': a.cpus or None, 'cpu_budget': cpu_budget(), 'torch_intra_op_threads': host_threads, 'log_every': tr.log_every,
+                      'reproducible_feature_grads': bool(a.reproducible_feature_grads), 'cpus_pinned': a.cpus or None, 'cpu_budget': cpu_budget(), 'torch_intra_op_threads': host_threads, 'log_every': tr.log_every,
                       'host_ms_each_step': [round(x, 2) for x in host], 'host_ms_median': round(float(np.median(host)), 3),
                       'with_flat_gradient_exchange': flat,
                       'max_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30,
