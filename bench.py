@@ -72,10 +72,12 @@ def source_sha16(*names):
 
 
 def newest_pmc(stamp_key, *sources):
-    """The newest committed profiles/r*_pmc_counters.json (tools/collect_profiles.sh), or None when its stamp `stamp_key`
-    (written by tools/pmc_summary.py) is not the sha256 of the CURRENT kernel sources: counters of another build are not
-    reported."""
+    """The counters collected in this run (live_pmc) when there are any; else the newest committed profiles/r*_pmc_counters.json
+    (tools/collect_profiles.sh), or None when its stamp `stamp_key` (written by tools/pmc_summary.py) is not the sha256 of the
+    CURRENT kernel sources: counters of another build are not reported."""
     import glob
+    if _LIVE_PMC['doc'] is not None:
+        return _LIVE_PMC['doc'], 'measured in this run (rocprofv3 --pmc child passes, roofline.counters.live)'
     try:
         newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_counters.json')))[-1]
         d = json.load(open(newest))
@@ -92,7 +94,8 @@ def recorded_bwd_traffic(scenes):
     if d is None:
         return None, None
     try:
-        k = d['kernels'].get('k_view1_bwd_pw') or d['kernels'].get('k_view1_bwd<false>') or d['kernels']['k_view1_bwd']      # (round 5: the partner-wavefront kernel; before: the template / the plain kernel)
+        ks = d['kernels']                                  # (round 5: the partner-wavefront kernel, a template since the fixed-point mode; before: the single-wavefront kernel)
+        k = ks.get('k_view1_bwd_pw<false>') or ks.get('k_view1_bwd_pw') or ks.get('k_view1_bwd<false>') or ks['k_view1_bwd']
         return (int(k['hbm_bytes_corrected']), src) if scenes == 8 else (None, None)
     except KeyError:
         return None, None
@@ -149,6 +152,59 @@ def recorded_pmc(batch):
         return int(k['hbm_bytes_corrected']), counters, valu
     except (KeyError, ValueError, ZeroDivisionError, StopIteration):
         return None, None, None
+
+
+_LIVE_PMC = {'doc': None, 'info': None}
+
+
+def live_pmc(cap_s=240.0):
+    """The PMC counters of this build measured IN THIS RUN.  rocprofv3 cannot attach to this process, so child runs of the same
+    workloads are profiled -- tools/run_hot.py --iters 1 (the B = 32 forward step) and tools/time_volume_bwd.py --scenes 8 (the
+    sample_volume backward) -- one counter set per run and nothing else enabled (`rocprofv3 --pmc <set> --output-format csv`: the
+    separate passes MI355X_MICROARCH.md's HBM section prescribes; the same sets and the same aggregation as
+    tools/collect_profiles.sh -> tools/pmc_summary.py, gfx950 read correction included).  Fills _LIVE_PMC: doc = a document of
+    the form kept under profiles/*_pmc_counters.json (or None), info = what was done / why not."""
+    import importlib.util, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        _LIVE_PMC['info'] = {'error': 'rocprofv3 not on PATH'}
+        return
+    sp = importlib.util.spec_from_file_location('pmc_summary', os.path.join(ROOT, 'tools', 'pmc_summary.py'))
+    pm = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(pm)
+    t0 = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix='gnr_pmc_', dir='/tmp')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE')
+           and not k.startswith(('TORCHELASTIC', 'MASTER_'))}
+    env['TMPDIR'] = '/tmp'
+    done, failed = [], []
+    try:
+        jobs = [('', st, ['tools/run_hot.py', '--iters', '1']) for st in pm.FWD_SETS] + \
+               [('bwd_', st, ['tools/time_volume_bwd.py', '--scenes', '8']) for st in pm.BWD_SETS]
+        for prefix, st, cmd in jobs:
+            left = cap_s - (time.perf_counter() - t0)
+            if left < 15:
+                failed.append(prefix + st + ': time cap')
+                continue
+            try:
+                subprocess.run([exe, '--pmc', *st.split(), '--output-format', 'csv', '-d', os.path.join(tmp, prefix + st.replace(' ', '_')), '-o', 'p', '--',
+                                sys.executable, os.path.join(ROOT, cmd[0]), *cmd[1:]], cwd='/tmp', env=env, timeout=min(left, 90.0),
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+                done.append(prefix + st)
+            except Exception as e:                           # a failed pass only drops its counters
+                failed.append(prefix + st + ': ' + type(e).__name__)
+        res = pm.aggregate(tmp)
+        if res:
+            doc = pm.document(res)
+            doc['git_commit_count'] = None
+            _LIVE_PMC['doc'] = doc
+        _LIVE_PMC['info'] = {'passes': len(done), 'failed': failed or None, 'seconds': round(time.perf_counter() - t0, 1),
+                             'command': 'rocprofv3 --pmc <set> --output-format csv -- python tools/run_hot.py --iters 1 | tools/time_volume_bwd.py --scenes 8 '
+                                        '(one child run per counter set, after the timed forward steps of this run)'}
+    except Exception as e:                                   # the counters are an extra: a box without a working profiler reports the recorded ones
+        _LIVE_PMC['info'] = {'error': repr(e)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_age_commits(d):
@@ -334,7 +390,7 @@ def f32_mfma_build_leg(value):
         env.pop(k)                                          # the child is a plain single-process run, also under torch.distributed.run
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', '60', '--warmup', '10', '--no-train', '--no-backbones',
-                            '--no-cpu-baseline', '--no-f32-build'], env=env, capture_output=True, text=True, timeout=300)
+                            '--no-cpu-baseline', '--no-f32-build', '--no-live-pmc'], env=env, capture_output=True, text=True, timeout=300)
         d = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:                                  # noqa: BLE001  (a failed companion run must not lose the product's line)
         return {'skipped': f'{type(e).__name__}: {e}'[:200]}
@@ -610,6 +666,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the configs[4] train-step sub-record')
     ap.add_argument('--no-backbones', action='store_true', help='skip the images -> grasps figure')
+    ap.add_argument('--no-live-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (N = 1)')
     ap.add_argument('--no-f32-build', action='store_true', help='skip timing the fp32-MFMA companion build next to the product')
     ap.add_argument('--train-scenes', type=int, default=8)
     ap.add_argument('--no-train-2cpu', action='store_true', help='skip the train step of a child process pinned to 2 CPUs (the host budget of one rank of an 8-rank node)')
@@ -754,7 +811,11 @@ def main():
         fl_ren = executed_mfma_flops(B * rn * dn, True)
         fl_ren_alg = chain_flops(B * rn * dn, c['V'], render=True)
         achieved = fl_exe / (ms * 1e-3) / 1e12
+        if world == 1 and not args.no_live_pmc and not stub:
+            live_pmc()                                   # counters of THIS run when the box has the profiler (else the recorded, sha-stamped ones)
         traffic, counters, valu = (None, None, None) if stub else recorded_pmc(B)
+        if counters is not None:
+            counters['live'] = _LIVE_PMC['info']
         out = {
             'metric': METRIC, 'value': round(world * B * args.steps / dt, 3), 'unit': 'scenes/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),

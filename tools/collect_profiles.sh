@@ -11,7 +11,7 @@ MODE=${2:-all}      # all | pmc (only the counter passes + the stamped json: eno
 R=$PWD
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-[ $MODE = all ] && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace -o t -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-backbones --no-f32-build > $R/gpurun_out/$TAG/bench_under_rocprof.json 2> $R/gpurun_out/$TAG/trace.log
+[ $MODE = all ] && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace -o t -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-backbones --no-f32-build --no-live-pmc > $R/gpurun_out/$TAG/bench_under_rocprof.json 2> $R/gpurun_out/$TAG/trace.log
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   N=$(echo $SET | tr ' ' '_')
   rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/$TAG/pmc/$N -o p -- python $R/tools/run_hot.py --iters 1 > $R/gpurun_out/$TAG/pmc_$N.log 2>&1
