@@ -169,6 +169,9 @@ def live_pmc(cap_s=240.0):
     if exe is None:
         _LIVE_PMC['info'] = {'error': 'rocprofv3 not on PATH'}
         return
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprofiler' in os.environ.get('LD_PRELOAD', ''):
+        _LIVE_PMC['info'] = {'skipped': 'this process is itself running under a profiler: no nested counter passes'}
+        return
     sp = importlib.util.spec_from_file_location('pmc_summary', os.path.join(ROOT, 'tools', 'pmc_summary.py'))
     pm = importlib.util.module_from_spec(sp)
     sp.loader.exec_module(pm)
