@@ -118,6 +118,7 @@ constexpr int CHAIN_END = T_VIS + 8;
 static_assert(CHAIN_END % 4 == 0, "CHAIN section must be float4 copyable");
 static_assert(CHAIN_END * 4 <= 160 * 1024, "CHAIN section must fit the 160 KiB LDS");
 
+constexpr int k32_floats(int NB) { return NB * 512; }     // one K32 pair block (C16 section below)
 // RAY section (k_ray): plain row-major matrices, read with wave-uniform (scalar) loads
 constexpr int R_WQ = CHAIN_END, R_WK = R_WQ + 256, R_WV = R_WK + 256, R_WFC = R_WV + 256;
 constexpr int R_LNW = R_WFC + 256, R_LNB = R_LNW + 16;
@@ -146,12 +147,19 @@ constexpr int R_OUTB = R_OUTVJP + 16;       // folded bias: out_fc.1 . out_fc.0.
 // follows).  ray_dir_fc.2 (4 k-steps, per view) stays fp32: padded as well it costs more than it saves (measured).
 // Which k-steps form the blocks of which layer: gnr_pack.cpp `c16_plan` and the call sites in k_chain.  The fp32 CHAIN
 // section stays in the blob: k_depth_mean and the backward twins read their forward fragments from it.
-constexpr int k32_floats(int NB) { return NB * 512; }     // one K32 pair block
+// (k32_floats: defined above, in front of the RAY section)
 constexpr int C16_GROW_HOIST = 5 * k32_floats(4) - frag_floats(36, 4);      // 36 k-steps -> 4 blocks + a padded one
 constexpr int C16_GROW_GEO1 = 3 * k32_floats(4) - frag_floats(23, 4);       // 23 k-steps -> 2 blocks + a padded one
 // offset inside the C16 image of what sits at offset `o` of the CHAIN section
 constexpr int c16_off(int o) { return o + (o > HOIST ? C16_GROW_HOIST : 0) + (o > GEO1 ? C16_GROW_GEO1 : 0); }
-constexpr int C16 = R_OUTB + 4;
+// RM section (round 5): the two layers of geometry_fc's backward inside k_ray<true> (the in-forward VJP, ibrnet.py:497-504) as fp16-pair
+// K32 blocks for the f16 matrix cores -- 16 samples are the 16 columns of an MFMA; read by k_ray straight from global memory (the
+// kernel's LDS belongs to the attention).  Element e of lane group g of block b <-> input k = 32 b + 8 g + e (RM_GEOB: the D layout
+// of RM_GEOA's output, hidden unit 16 (2b + e/4) + 4g + e%4); output block nb, row i <-> output 16 nb + i.
+constexpr int RM_GEOA = R_OUTB + 4;                 // du = geometry_fc.2^T dc              K = 16 (lane groups 0, 1), NB = 4
+constexpr int RM_GEOB = RM_GEOA + k32_floats(4);    // de = geometry_fc.0[:, 65:86]^T da    K = 64 (two blocks), NB = 2 (rows 21.. zero)
+constexpr int RM_END = RM_GEOB + 2 * k32_floats(2);
+constexpr int C16 = RM_END;
 constexpr int C16_END = c16_off(CHAIN_END);
 static_assert(C16_END % 4 == 0 && C16_END * 4 <= 160 * 1024, "the C16 image must fit the 160 KiB LDS");
 constexpr int TOTAL = C16 + C16_END;

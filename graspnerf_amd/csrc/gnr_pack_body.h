@@ -278,6 +278,28 @@ struct Base0Folded {
     }
 };
 
+// fp16-pair K32 blocks straight from a weight accessor (the RM section: no fp32 fragment in between): block kb, output block nb,
+// lane, element i  <-  w = wf(psi(nb, lane & 15), phi(8 kb + i, lane >> 4)), zero where either index is -1
+template <class Ex, class WF, class Phi, class Psi>
+GNR_HD void pack_pairs(const Ex& ex, float* dst, WF wf, int KB, int NB, Phi phi, Psi psi) {
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(dst);
+    ex.run(KB * NB * 64 * 8, [&](int t) {
+#pragma clang fp contract(off)
+        const int i = t & 7, lane = (t >> 3) & 63, nb = (t >> 9) % NB, kb = (t >> 9) / NB;
+        const int o = psi(nb, lane & 15), k = phi(8 * kb + i, lane >> 4);
+        uint16_t h = 0, m = 0;
+        if (o >= 0 && k >= 0) {
+            const float w = (float)wf(o, k);
+            const uint16_t hh = f32_to_f16(w);
+            bool fin;
+            const float hf = f16_to_f32(hh, fin);
+            if (fin) { h = hh; m = f32_to_f16((w - hf) * 2048.f); }
+        }
+        o16[(((kb * NB + nb) * 2 + 0) * 64 + lane) * 8 + i] = h;
+        o16[(((kb * NB + nb) * 2 + 1) * 64 + lane) * 8 + i] = m;
+    });
+}
+
 // ---- forward blob: CHAIN + RAY sections from the canonical blob (everything except the position table R_PE and the C16 image)
 template <class Ex>
 GNR_HD void pack_forward(const Ex& ex, const float* c, float* p) {
@@ -407,6 +429,11 @@ GNR_HD void pack_forward(const Ex& ex, const float* c, float* p) {
         for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT1_W + f] * (double)c[can::OUT0_B + f];
         p[pk::R_OUTB] = (float)acc;
     });
+    // --- RM section: geometry_fc's backward in k_ray<true> as pair blocks (gnr_layout.h)
+    auto k16 = [](int j, int g) { return (j < 8 && g < 2) ? 8 * g + j : -1; };                  // 16 inputs in lane groups 0, 1 of one block
+    auto khid = [](int j, int g) { const int b = j >> 3, e = j & 7; return 16 * (2 * b + (e >> 2)) + 4 * g + (e & 3); };   // D layout of RM_GEOA's output
+    pack_pairs(ex, p + pk::RM_GEOA, MatT{c + can::GEO2_W, 64}, 1, 4, k16, natO);                // (o = h, k = c): geometry_fc.2.weight[c][h]
+    pack_pairs(ex, p + pk::RM_GEOB, MatT{c + can::GEO0_W + 65, 86}, 2, 2, khid, [](int nb, int i) { const int e = 16 * nb + i; return e < 21 ? e : -1; });
 }
 
 // The optional fourth decoder branch of a level (dist_decoder_cfg.use_vis: true, dist_decoder.py:89-97,103-104,133-134) into an
