@@ -1685,7 +1685,106 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
                 dV[4 * h] = dV4[h].x; dV[4 * h + 1] = dV4[h].y; dV[4 * h + 2] = dV4[h].z; dV[4 * h + 3] = dV4[h].w;
             }
         }
-        // dT = dy (residual) + Wq^T dQ + Wk^T dK + Wv^T dV ; dc = dT * ELU'(c) with ELU' = g>0 ? 1 : g+1
+        // dT = dy (residual) + Wq^T dQ + Wk^T dK + Wv^T dV ; dc = dT * ELU'(c) with ELU' = g>0 ? 1 : g+1 ;
+        // geometry_fc backward (two layers, 16 -> 64 -> the 21 embed columns; only the embed columns matter)
+        float de[21];
+#if GNR_RAY_GEO_MFMA
+        // The three layers on the f16 matrix cores, 16 samples as the columns of an MFMA (fp16-pair fragments: the RM section of the blob,
+        // read from global memory / L2).  [dQ | dK | dV | dy] crosses from "lane = sample" to the B-operand layout through a 32-float
+        // row per sample in the attention scratch (dead once every lane has left the column pass), in two halves; from there on the
+        // chain stays in registers: the D layout of each layer is the B layout the next one was packed for (dT -> ELU' -> dc -> du ->
+        // ELU' -> da -> de), and de comes back through the same row.
+        {
+            static_assert(OVL, "the transfer rows re-use the overlaid attention scratch");
+            const int lane = threadIdx.x & 63, mr = lane & 15, mg = lane >> 4;
+            const unsigned magic = (65536u + (unsigned)S - 1u) / (unsigned)S;      // T / S for T < 256 as (T * magic) >> 16
+            constexpr int GS = 36;                            // row stride (floats): 16-byte aligned, rows of a group on different banks
+            float* Gr = sc + i * GS;
+            // column mr of group q4 is the sample of thread T = 64 wave + 16 q4 + mr
+            auto col = [&](int q4, int& rayT, int& iT, float*& row) -> bool {
+                const int T = ((int)threadIdx.x & ~63) + 16 * q4 + mr;
+                int rlT = (int)(((unsigned)T * magic) >> 16);
+                const int sl = T - rlT * S;
+                const bool okT = rlT < rpb && blockIdx.x * rpb + rlT < a.nrays && sl < dn;
+                rlT = min(rlT, rpb - 1);
+                iT = min(sl, dn - 1);
+                rayT = min((int)(blockIdx.x * rpb) + rlT, a.nrays - 1);
+                row = sm + (size_t)rlT * a.ray_stride + iT * GS;
+                return okT;
+            };
+            auto row_block = [&](const float* row) -> P8 {    // inputs 8 mg .. 8 mg + 7 of the row's 32
+                const f4 a0 = reinterpret_cast<const f4*>(row + 8 * mg)[0], a1 = reinterpret_cast<const f4*>(row + 8 * mg)[1];
+                const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                return split8<0>(x);
+            };
+            auto put_row = [&](const float (&lo)[16], const float (&hi)[16]) {
+                if (act) {                                    // (lanes out of range shadow another lane's row: no stores)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        reinterpret_cast<f4*>(Gr)[c] = (f4){lo[4 * c], lo[4 * c + 1], lo[4 * c + 2], lo[4 * c + 3]};
+                        reinterpret_cast<f4*>(Gr + 16)[c] = (f4){hi[4 * c], hi[4 * c + 1], hi[4 * c + 2], hi[4 * c + 3]};
+                    }
+                }
+            };
+            __syncthreads();                                  // Q / dO / statistics are free
+            f4 dT[4];
+            put_row(dQ, dK);
+            wave_sync();
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                int rayT, iT; float* row;
+                (void)col(q4, rayT, iT, row);
+                const P8 xp = row_block(row);
+                f4 acc[1] = {(f4){0.f, 0.f, 0.f, 0.f}};
+                mm16<1, 1, false>(W + pk::RM_DC, lane, &xp, acc);
+                dT[q4] = acc[0];
+            }
+            wave_sync();
+            put_row(dV, dy);
+            wave_sync();
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                int rayT, iT; float* row;
+                const bool okT = col(q4, rayT, iT, row);
+                const float* recT = a.rec + ((size_t)rayT * dn + iT) * REC + 4 * mg;
+                {
+                    const P8 xp = row_block(row);
+                    f4 acc[1] = {dT[q4]};
+                    mm16<1, 1, false>(W + pk::RM_DC + pk::k32_floats(1), lane, &xp, acc);     // dT: channel 4 mg + t of column mr
+                    dT[q4] = acc[0];
+                }
+                const f4 gq = *reinterpret_cast<const f4*>(recT);                             // geometry_fc's output of that sample
+                const float dc4[4] = {dT[q4].x * (gq.x > 0.f ? 1.f : gq.x + 1.f), dT[q4].y * (gq.y > 0.f ? 1.f : gq.y + 1.f),
+                                      dT[q4].z * (gq.z > 0.f ? 1.f : gq.z + 1.f), dT[q4].w * (gq.w > 0.f ? 1.f : gq.w + 1.f)};
+                const P8 xp = split8z<0, 4>(dc4);
+                f4 du[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) du[nb] = (f4){0.f, 0.f, 0.f, 0.f};
+                mm16<1, 4, false>(W + pk::RM_GEOA, lane, &xp, du);              // du[nb][t]: hidden unit 16 nb + 4 mg + t of column mr
+                float da[16];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const f4 u = *reinterpret_cast<const f4*>(recT + 16 + 16 * nb);           // geometry_fc's hidden layer of that sample
+                    da[4 * nb] = du[nb].x * (u.x > 0.f ? 1.f : u.x + 1.f); da[4 * nb + 1] = du[nb].y * (u.y > 0.f ? 1.f : u.y + 1.f);
+                    da[4 * nb + 2] = du[nb].z * (u.z > 0.f ? 1.f : u.z + 1.f); da[4 * nb + 3] = du[nb].w * (u.w > 0.f ? 1.f : u.w + 1.f);
+                }
+                const P8 yp[2] = {split8<0>(da), split8<8>(da)};
+                f4 d2[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+                mm16<2, 2, false>(W + pk::RM_GEOB, lane, yp, d2);               // d2[nb][t]: embed column 16 nb + 4 mg + t
+                if (okT) {
+                    *reinterpret_cast<f4*>(row + 4 * mg) = d2[0];
+                    if (mg < 2) *reinterpret_cast<f4*>(row + 16 + 4 * mg) = d2[1];
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const f4 v = reinterpret_cast<const f4*>(Gr)[c];
+                de[4 * c] = v.x; de[4 * c + 1] = v.y; de[4 * c + 2] = v.z; de[4 * c + 3] = v.w;
+            }
+            de[20] = Gr[20];
+        }
+#else
         float g16b[16];                                   // geometry_fc's output again (re-read: 16 registers less across the sweeps)
         {
             const f4* r4 = reinterpret_cast<const f4*>(rec);
@@ -1707,72 +1806,6 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
             }
             dc[c] = s * (g16b[c] > 0.f ? 1.f : g16b[c] + 1.f);
         }
-        // geometry_fc backward (two layers, 16 -> 64 -> the 21 embed columns); only the embed columns matter
-        float de[21];
-#if GNR_RAY_GEO_MFMA
-        // On the f16 matrix cores, 16 samples as the columns of an MFMA (fp16-pair fragments: the RM section of the blob, read from
-        // global memory).  dc crosses from "lane = sample" to the B-operand layout through a 32-float row per sample in the attention
-        // scratch (dead once every lane has left the column pass), du -> ELU' -> da stays in registers (the D layout of the first layer
-        // is the B layout the second one was packed for), de comes back through the same row.
-        {
-            static_assert(OVL, "the transfer rows re-use the overlaid attention scratch");
-            const int lane = threadIdx.x & 63, mr = lane & 15, mg = lane >> 4;
-            const unsigned magic = (65536u + (unsigned)S - 1u) / (unsigned)S;      // T / S for T < 256 as (T * magic) >> 16
-            __syncthreads();                                  // Q / dO / statistics are free
-            constexpr int GS = 36;                            // row stride (floats): 16-byte aligned, rows of a group on different banks
-            float* Gr = sc + i * GS;
-            if (act) {                                        // (lanes out of range shadow another lane's row: no stores)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) reinterpret_cast<f4*>(Gr)[c] = (f4){dc[4 * c], dc[4 * c + 1], dc[4 * c + 2], dc[4 * c + 3]};
-            }
-            wave_sync();
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                // column mr of group q4 is the sample of thread T = 64 wave + 16 q4 + mr
-                const int T = ((int)threadIdx.x & ~63) + 16 * q4 + mr;
-                int rlT = (int)(((unsigned)T * magic) >> 16);
-                const int sl = T - rlT * S;
-                const bool okT = rlT < rpb && blockIdx.x * rpb + rlT < a.nrays && sl < dn;
-                rlT = min(rlT, rpb - 1);
-                const int iT = min(sl, dn - 1);
-                const int rayT = min((int)(blockIdx.x * rpb) + rlT, a.nrays - 1);
-                float* row = sm + (size_t)rlT * a.ray_stride + iT * GS;
-                const float* uT = a.rec + ((size_t)rayT * dn + iT) * REC + 16 + 4 * mg;       // geometry_fc's hidden layer of that sample
-                P8 xp;
-                {
-                    const f4 a0 = reinterpret_cast<const f4*>(row + 8 * (mg & 1))[0], a1 = reinterpret_cast<const f4*>(row + 8 * (mg & 1))[1];
-                    const float z = mg < 2 ? 1.f : 0.f;      // K = 16: lane groups 2, 3 carry no inputs (their fragment slots are zero)
-                    const float x[8] = {a0.x * z, a0.y * z, a0.z * z, a0.w * z, a1.x * z, a1.y * z, a1.z * z, a1.w * z};
-                    xp = split8<0>(x);
-                }
-                f4 du[4];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) du[nb] = (f4){0.f, 0.f, 0.f, 0.f};
-                mm16<1, 4, false>(W + pk::RM_GEOA, lane, &xp, du);              // du[nb][t]: hidden unit 16 nb + 4 mg + t of column mr
-                float da[16];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const f4 u = *reinterpret_cast<const f4*>(uT + 16 * nb);
-                    da[4 * nb] = du[nb].x * (u.x > 0.f ? 1.f : u.x + 1.f); da[4 * nb + 1] = du[nb].y * (u.y > 0.f ? 1.f : u.y + 1.f);
-                    da[4 * nb + 2] = du[nb].z * (u.z > 0.f ? 1.f : u.z + 1.f); da[4 * nb + 3] = du[nb].w * (u.w > 0.f ? 1.f : u.w + 1.f);
-                }
-                const P8 yp[2] = {split8<0>(da), split8<8>(da)};
-                f4 d2[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
-                mm16<2, 2, false>(W + pk::RM_GEOB, lane, yp, d2);               // d2[nb][t]: embed column 16 nb + 4 mg + t
-                if (okT) {
-                    *reinterpret_cast<f4*>(row + 4 * mg) = d2[0];
-                    if (mg < 2) *reinterpret_cast<f4*>(row + 16 + 4 * mg) = d2[1];
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const f4 v = reinterpret_cast<const f4*>(Gr)[c];
-                de[4 * c] = v.x; de[4 * c + 1] = v.y; de[4 * c + 2] = v.z; de[4 * c + 3] = v.w;
-            }
-            de[20] = Gr[20];
-        }
-#else
 #pragma unroll
         for (int e = 0; e < 21; ++e) de[e] = 0.f;
 #pragma unroll 2

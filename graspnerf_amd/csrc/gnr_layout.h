@@ -152,11 +152,13 @@ constexpr int C16_GROW_HOIST = 5 * k32_floats(4) - frag_floats(36, 4);      // 3
 constexpr int C16_GROW_GEO1 = 3 * k32_floats(4) - frag_floats(23, 4);       // 23 k-steps -> 2 blocks + a padded one
 // offset inside the C16 image of what sits at offset `o` of the CHAIN section
 constexpr int c16_off(int o) { return o + (o > HOIST ? C16_GROW_HOIST : 0) + (o > GEO1 ? C16_GROW_GEO1 : 0); }
-// RM section (round 5): the two layers of geometry_fc's backward inside k_ray<true> (the in-forward VJP, ibrnet.py:497-504) as fp16-pair
+// RM section (round 5): the tail of the in-forward VJP inside k_ray<true> (ibrnet.py:497-504: the transposed q / k / v projections +
+// residual, then the two layers of geometry_fc's backward) as fp16-pair
 // K32 blocks for the f16 matrix cores -- 16 samples are the 16 columns of an MFMA; read by k_ray straight from global memory (the
 // kernel's LDS belongs to the attention).  Element e of lane group g of block b <-> input k = 32 b + 8 g + e (RM_GEOB: the D layout
 // of RM_GEOA's output, hidden unit 16 (2b + e/4) + 4g + e%4); output block nb, row i <-> output 16 nb + i.
-constexpr int RM_GEOA = R_OUTB + 4;                 // du = geometry_fc.2^T dc              K = 16 (lane groups 0, 1), NB = 4
+constexpr int RM_DC = R_OUTB + 4;                   // dT = [Wq^T Wk^T Wv^T I] [dQ; dK; dV; dy]    K = 64 (two blocks), NB = 1
+constexpr int RM_GEOA = RM_DC + 2 * k32_floats(1);  // du = geometry_fc.2^T dc              K = 16: input 4 g + e in elements e < 4 of lane group g (RM_DC's D layout), NB = 4
 constexpr int RM_GEOB = RM_GEOA + k32_floats(4);    // de = geometry_fc.0[:, 65:86]^T da    K = 64 (two blocks), NB = 2 (rows 21.. zero)
 constexpr int RM_END = RM_GEOB + 2 * k32_floats(2);
 constexpr int C16 = RM_END;

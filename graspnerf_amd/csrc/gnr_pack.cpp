@@ -40,7 +40,7 @@ extern "C" int gnr_layout_offset(const char* name) {
         {"R_WQ", R_WQ}, {"R_WK", R_WK}, {"R_WV", R_WV}, {"R_WFC", R_WFC}, {"R_LNW", R_LNW}, {"R_LNB", R_LNB},
         {"R_OUT0W", R_OUT0W}, {"R_OUT0B", R_OUT0B}, {"R_OUT1W", R_OUT1W}, {"R_OUT1B", R_OUT1B},
         {"R_GEO2W", R_GEO2W}, {"R_GEO1E", R_GEO1E}, {"R_VARIANCE", R_VARIANCE}, {"R_PE", R_PE}, {"R_WQT", R_WQT},
-        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"R_OUTB", R_OUTB}, {"RM_GEOA", RM_GEOA}, {"RM_GEOB", RM_GEOB}, {"RM_END", RM_END}, {"C16", C16}, {"C16_END", C16_END}, {"TOTAL", TOTAL}};
+        {"R_WKT", R_WKT}, {"R_WVT", R_WVT}, {"R_WFCT", R_WFCT}, {"R_GEO2WT", R_GEO2WT}, {"R_OUTVJP", R_OUTVJP}, {"R_OUTB", R_OUTB}, {"RM_DC", RM_DC}, {"RM_GEOA", RM_GEOA}, {"RM_GEOB", RM_GEOB}, {"RM_END", RM_END}, {"C16", C16}, {"C16_END", C16_END}, {"TOTAL", TOTAL}};
     if (!std::strncmp(name, "C16.", 4)) {                     // where a CHAIN-section name sits in the blob's C16 image
         for (const E& e : tab)
             if (!std::strcmp(e.n, name + 4) && e.o <= CHAIN_END) return C16 + c16_off(e.o);

@@ -429,10 +429,13 @@ GNR_HD void pack_forward(const Ex& ex, const float* c, float* p) {
         for (int f = 0; f < 16; ++f) acc += (double)c[can::OUT1_W + f] * (double)c[can::OUT0_B + f];
         p[pk::R_OUTB] = (float)acc;
     });
-    // --- RM section: geometry_fc's backward in k_ray<true> as pair blocks (gnr_layout.h)
-    auto k16 = [](int j, int g) { return (j < 8 && g < 2) ? 8 * g + j : -1; };                  // 16 inputs in lane groups 0, 1 of one block
+    // --- RM section: the tail of k_ray<true>'s in-forward VJP as pair blocks (gnr_layout.h)
+    auto k64 = [](int j, int g) { return 32 * (j >> 3) + 8 * g + (j & 7); };                     // input 32 b + 8 g + e of [dQ | dK | dV | dy]
+    auto k16d = [](int j, int g) { return j < 4 ? 4 * g + j : -1; };                             // the D layout of RM_DC's output as RM_GEOA's B operand
     auto khid = [](int j, int g) { const int b = j >> 3, e = j & 7; return 16 * (2 * b + (e >> 2)) + 4 * g + (e & 3); };   // D layout of RM_GEOA's output
-    pack_pairs(ex, p + pk::RM_GEOA, MatT{c + can::GEO2_W, 64}, 1, 4, k16, natO);                // (o = h, k = c): geometry_fc.2.weight[c][h]
+    const float* wqkv = c + can::WQ;                                                             // [Wq; Wk; Wv] rows 0..47 (contiguous in the blob)
+    pack_pairs(ex, p + pk::RM_DC, [wqkv](int o, int k) { return k < 48 ? wqkv[k * 16 + o] : (k - 48 == o ? 1.f : 0.f); }, 2, 1, k64, natO);
+    pack_pairs(ex, p + pk::RM_GEOA, MatT{c + can::GEO2_W, 64}, 1, 4, k16d, natO);               // (o = h, k = c): geometry_fc.2.weight[c][h]
     pack_pairs(ex, p + pk::RM_GEOB, MatT{c + can::GEO0_W + 65, 86}, 2, 2, khid, [](int nb, int i) { const int e = 16 * nb + i; return e < 21 ? e : -1; });
 }
 
