@@ -1,10 +1,12 @@
-"""A/B of k_ray's per-sample dense layers: f16-pair MFMAs (docs/experiments/r05_ray_mfma.patch applied: `git apply` it, build.sh;
-GNR_RAY_MFMA=1 is its default) against the fp32 FMA form of the product (libgnr_rayf.so = tools/build_variant.sh rayf -DGNR_RAY_MFMA=0
-in the patched tree, or simply the unpatched library).  Result: profiles/r05_m_ray_mfma_ab.json (not adopted).  One library per process (GNR_LIB); the same B = 32 forward step;
-per-kernel ms (HIP events on the launch stream); --save writes the outputs, --compare reads the other build's and prints the
-largest differences.
+"""A/B of k_ray's per-sample dense layers on the f16 matrix cores against their fp32 FMA form.  One library per process (GNR_LIB);
+the same B = 32 forward step; per-kernel ms (HIP events on the launch stream); --save writes the outputs, --compare reads the other
+build's and prints the largest differences.
+  * adopted (the product): the tail of k_ray<true>'s in-forward VJP as a register-resident MFMA chain (GNR_RAY_GEO_MFMA=1);
+    the fp32 form:  tools/build_variant.sh rayf -DGNR_RAY_GEO_MFMA=0
+  * not adopted: the forward dense layers (q / k / v projections, fc): docs/experiments/r05_ray_mfma.patch on commit 0243025
     GNR_LIB=libgnr_rayf.so python tools/ab_ray_mfma.py --save gpurun_out/ray_f.npz
-    python tools/ab_ray_mfma.py --compare gpurun_out/ray_f.npz"""
+    python tools/ab_ray_mfma.py --compare gpurun_out/ray_f.npz
+Results: profiles/r05_m_ray_mfma_ab.json."""
 import argparse, json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
