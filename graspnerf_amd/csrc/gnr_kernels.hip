@@ -2041,6 +2041,8 @@ __global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restri
 #if GNR_PROTO_P1
 #include "gnr_chain_p1.inc"
 #endif
+#define GNR_HD __host__ __device__
+#include "gnr_pack_body.h"      // (k_pack_geo_dual: the packer's pair-block builder on the device)
 #include "gnr_bwd.inc"
 #include "gnr_capi.inc"
 #if GNR_PROTO_P1

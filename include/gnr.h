@@ -299,6 +299,9 @@ int gnr_feature_grad_mode(int mode);       /* 0: float atomics (default); 1: 64-
 /* Measurement / test switch: the backward of the first view loop as k_view1_bwd (one wavefront per tile, 0) or as k_view1_bwd_pw
  * (a compute wavefront and its partner per tile, 1: the default).  Same outputs either way; returns the old setting. */
 int gnr_debug_view1_partner(int on);
+/* Measurement / test switch: the per-point half of gnr_geo_dual_bwd on the f16 matrix cores (1: the default) or as fp32 FMAs with one
+ * lane per point (0).  Same outputs to rounding; returns the old setting. */
+int gnr_debug_geo_dual_matrix_cores(int on);
 int gnr_packed_bwd_floats(void);
 int gnr_pack_weights_bwd(const float* canonical_host, float* packed_bwd_host);
 size_t gnr_depth_mean_bwd_workspace_bytes(const GnrScene* scene);
