@@ -90,7 +90,7 @@ def newest_pmc(stamp_key, *sources):
 
 def recorded_bwd_traffic(scenes):
     """HBM-side bytes per launch of k_view1_bwd (volume points, 8 scenes) from the recorded PMC passes, or None."""
-    d, src = newest_pmc('bwd_source_sha16', 'gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc')
+    d, src = newest_pmc('bwd_source_sha16', 'gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc')
     if d is None:
         return None, None
     try:
@@ -146,7 +146,7 @@ def recorded_pmc(batch):
             return o
         counters['other_kernels'] = {n: brief(n, sc) for n, sc in (('k_chain<6, true, false, false, true>', 32), ('k_ray<true>', 32), ('k_ray<false>', 32),
                                                                     ('k_repack_feats', 32))}
-        if d.get('bwd_source_sha16') == source_sha16('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc'):
+        if d.get('bwd_source_sha16') == source_sha16('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc'):
             counters['backward_kernels'] = {n: brief(n, 8) for n in d['kernels'] if '_bwd' in n}
         counters['pmc_age_commits'] = pmc_age_commits(d)
         return int(k['hbm_bytes_corrected']), counters, valu

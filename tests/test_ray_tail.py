@@ -200,6 +200,42 @@ def test_geometry_dual_kernels(P_, level, weights_np):
         assert _rel(got[k], want[k]) < 1e-3, k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('scale_x,scale_adj', [(1.0, 1e-6), (3e4, 1e3), (1.0, 1e-20)])
+def test_geo_dual_bwd_on_the_matrix_cores_agrees_with_the_fp32_kernel(scale_x, scale_adj, weights_np):
+    """gnr_geo_dual_bwd's per-point half as a chained fp16-pair MFMA (k_geo_dual_bwd_pts_mm, the default) against the fp32 FMA kernel
+    (gnr_debug_geo_dual_matrix_cores(0)): d stats and geometry_fc's gradients equal to 2e-5 of their scale (1e-2 where statistics of
+    3e4 drive exp() -- both kernels are then 1e-3 off a float64 evaluation), for training-step magnitudes, for statistics near the fp16
+    limit with large adjoints and for adjoints of 1e-20 (every operand block is normalised before it is split); a ragged point count."""
+    from graspnerf_amd.hotpath import HotPath
+    from graspnerf_amd import _lib
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    canon = torch.from_numpy(weights.canonical_blob(weights_np, 'fine')).cuda()
+    rng = np.random.default_rng(11)
+    Pn = 4 * 512 * 40 + 13
+    stats = (rng.standard_normal((Pn, 66)) * scale_x).astype(np.float32)
+    stats[:, 32:64] = np.abs(stats[:, 32:64]); stats[:, 64] = rng.uniform(0, 1, Pn); stats[:, 65] = 6
+    pts = rng.uniform(-0.5, 0.5, (Pn, 3)).astype(np.float32)
+    gamma = (rng.standard_normal((Pn, 3)) * scale_adj).astype(np.float32)
+    gbar = (rng.standard_normal((Pn, 16)) * scale_adj).astype(np.float32)
+    gdbar = (rng.standard_normal((Pn, 16)) * scale_adj * 0.1).astype(np.float32)
+    L = _lib.lib()
+    prev = L.gnr_debug_geo_dual_matrix_cores(1)
+    try:
+        got = [x.double() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
+        L.gnr_debug_geo_dual_matrix_cores(0)
+        want = [x.double() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
+    finally:
+        L.gnr_debug_geo_dual_matrix_cores(prev)
+    torch.cuda.synchronize()
+    tol = 2e-5 if scale_x == 1.0 else 1e-2
+    for g, w, name in zip(got, want, ('d stats', 'd geometry_fc')):
+        assert bool(torch.isfinite(g).all()), name
+        assert float(w.abs().max()) > 0, name
+        assert float((g - w).abs().max()) <= tol * float(w.abs().max()), name
+    assert float(got[0][:, 65].abs().max()) == 0.0                     # n_valid has no gradient
+
+
 def test_positive_cumprod_backward_equals_autograd():
     """reference_autograd._CumprodPositive: torch.cumprod's values, and its gradient for strictly positive factors, without the
     `(x == 0).any()` host read of the stock backward."""

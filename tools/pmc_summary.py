@@ -38,7 +38,7 @@ def aggregate(src):
 
 import hashlib
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'graspnerf_amd', 'csrc')
-BWD_SOURCES = ('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc')
+BWD_SOURCES = ('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc')
 
 
 def sha16(*names):
