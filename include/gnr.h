@@ -370,8 +370,9 @@ int gnr_ray_tail_grad_floats(void);
  * (overwritten) and the gradients of geometry_fc.{0,2}.{weight,bias} ACCUMULATED into d_canonical (state-dict order).   */
 int gnr_geo_dual_fwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, float* g, float* gd,
                      int P, void* stream);
-/* bwd runs as two kernels (one lane per point; then the weight-gradient outer products over the points on the matrix cores) with the
- * per-point adjoints between them (288 floats per point) and the partial weight gradients in caller-owned scratch of
+/* bwd runs as two kernels (the per-point reverse pass -- 16 points as the columns of a chained fp16-pair MFMA, its fragments packed per
+ * call from canonical_dev -- then the weight-gradient outer products over the points on the matrix cores) with the per-point adjoints
+ * between them (288 floats per point), the fragment image (64 KB) and the partial weight gradients in caller-owned scratch of
  * gnr_geo_dual_bwd_workspace_bytes(P) bytes. */
 size_t gnr_geo_dual_bwd_workspace_bytes(int P);
 int gnr_geo_dual_bwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, const float* gbar,
