@@ -1600,12 +1600,15 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
             for (int c = 0; c < 16; ++c) s = fmaf(dy[c], W[pk::R_WFCT + f * 16 + c], s);
             dO[f] = s;
         }
-        // row pass: rs_h = sum_j P dA ;  dQ = (sum_j P dA k_j - rs sum_j P k_j) / 2
-        float dQ[16], rsv[4] = {0.f, 0.f, 0.f, 0.f};
-        {
-            f4 A1[4], B1[4];
+        // row pass: dQ = sum_j P_ij (dA_ij - rs_i) k_j / 2 with dA_ij = dO_i . v_j and rs_i = sum_j P_ij dA_ij = dO_i . o_i (the attention's
+        // own output: no sweep needed for it, and none for sum_j P k_j)
+        float dQ[16], rsv[4];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) { A1[h] = (f4){0.f, 0.f, 0.f, 0.f}; B1[h] = (f4){0.f, 0.f, 0.f, 0.f}; }
+        for (int h = 0; h < 4; ++h) rsv[h] = dO[4 * h] * o[4 * h] + dO[4 * h + 1] * o[4 * h + 1] + dO[4 * h + 2] * o[4 * h + 2] + dO[4 * h + 3] * o[4 * h + 3];
+        {
+            f4 A1[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) A1[h] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll UB
             for (int j = 0; j < dn; ++j) {
                 float sj[4];
@@ -1616,16 +1619,13 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
                     const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
                     const float pj = __builtin_amdgcn_exp2f(sj[h] - amax[h]) * ainv[h];
                     const float dA = dO[4 * h] * vj.x + dO[4 * h + 1] * vj.y + dO[4 * h + 2] * vj.z + dO[4 * h + 3] * vj.w;
-                    const float pd = pj * dA;
-                    rsv[h] += pd;
-                    A1[h] += pd * kj;
-                    B1[h] += pj * kj;
+                    A1[h] += (pj * (dA - rsv[h])) * kj;
                 }
             }
             const float sc2 = rowok ? 0.5f : 0.f;       // masked query rows: d logits = 0
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const f4 d4 = (A1[h] - rsv[h] * B1[h]) * sc2;
+                const f4 d4 = A1[h] * sc2;
                 dQ[4 * h] = d4.x; dQ[4 * h + 1] = d4.y; dQ[4 * h + 2] = d4.z; dQ[4 * h + 3] = d4.w;
             }
         }
