@@ -1340,6 +1340,8 @@ struct RayArgs {
     // inverse-CDF resampling (coarse pass only; nullable)
     float* fine_depth; int* fine_inds; int fdn;
     const float* fine_u;     // [nrays][fdn] caller-drawn samples (is_train) or null (eval midpoints)
+    unsigned* range_word;    // RENDER, MM: bit 1 is set when the matrix-core tail produced a non-finite value (an operand or a weight beyond the fp16 range)
+    const unsigned* only_if; // RENDER, !MM (the fp32 twin launch): run only if bit 1 of this word is set; null: always
     const int* ray_perm;     // RENDER, nullable: rec / desc are in Morton order of the rays (k_ray_order); slot s of scene b holds ray
                              // ray_perm[b][s]; every other array (inputs depth / colours / fine_u, all outputs) is in the caller's order
 };
@@ -1403,8 +1405,13 @@ DEV void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <bool RENDER>
+// MM (RENDER only): the VJP's dense tail on the f16 matrix cores (the product); false: as fp32 FMAs -- the instantiation launched right
+// behind every MM launch, which returns at once unless that launch's range watch tripped (RayArgs::only_if) and otherwise recomputes it
+template <bool RENDER, bool MM = (GNR_RAY_GEO_MFMA != 0)>
 __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayArgs a) {
+    if constexpr (RENDER && !MM) {
+        if (a.only_if && (__builtin_nontemporal_load(a.only_if) & 2u) == 0u) return;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int dn = a.dn, S = a.slots, rpb = a.rays_per_block;
     // thread -> (ray in block, slot).  Threads beyond the last ray of the block / launch shadow the last valid
@@ -1688,7 +1695,48 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
         // dT = dy (residual) + Wq^T dQ + Wk^T dK + Wv^T dV ; dc = dT * ELU'(c) with ELU' = g>0 ? 1 : g+1 ;
         // geometry_fc backward (two layers, 16 -> 64 -> the 21 embed columns; only the embed columns matter)
         float de[21];
-#if GNR_RAY_GEO_MFMA
+        // the same tail as fp32 FMAs, one lane per sample (MM = false: the range fallback of the matrix-core form, launched as its twin)
+        auto tail_fp32 = [&]() {
+            float g16b[16];                                   // geometry_fc's output again (re-read: 16 registers less across the sweeps)
+            {
+                const f4* r4 = reinterpret_cast<const f4*>(rec);
+    #pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f4 x = __builtin_nontemporal_load(r4 + q4);
+                    g16b[4 * q4] = x.x; g16b[4 * q4 + 1] = x.y; g16b[4 * q4 + 2] = x.z; g16b[4 * q4 + 3] = x.w;
+                }
+            }
+            float dc[16];
+    #pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float s = dy[c];
+    #pragma unroll
+                for (int f = 0; f < 16; ++f) {
+                    s = fmaf(W[pk::R_WQT + c * 16 + f], dQ[f], s);
+                    s = fmaf(W[pk::R_WKT + c * 16 + f], dK[f], s);
+                    s = fmaf(W[pk::R_WVT + c * 16 + f], dV[f], s);
+                }
+                dc[c] = s * (g16b[c] > 0.f ? 1.f : g16b[c] + 1.f);
+            }
+    #pragma unroll
+            for (int e = 0; e < 21; ++e) de[e] = 0.f;
+    #pragma unroll 2
+            for (int h4 = 0; h4 < 16; ++h4) {
+                const f4 u4 = reinterpret_cast<const f4*>(rec + 16)[h4];
+    #pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    const int h = 4 * h4 + hh;
+                    float du = 0.f;
+    #pragma unroll
+                    for (int c = 0; c < 16; ++c) du = fmaf(W[pk::R_GEO2WT + h * 16 + c], dc[c], du);
+                    const float uh = u4[hh];
+                    const float da = du * (uh > 0.f ? 1.f : uh + 1.f);
+    #pragma unroll
+                    for (int e = 0; e < 21; ++e) de[e] = fmaf(W[pk::R_GEO1E + h * 24 + e], da, de[e]);
+                }
+            }
+        };
+        if constexpr (MM) {
         // The three layers on the f16 matrix cores, 16 samples as the columns of an MFMA (fp16-pair fragments: the RM section of the blob,
         // read from global memory / L2).  [dQ | dK | dV | dy] crosses from "lane = sample" to the B-operand layout through a 32-float
         // row per sample in the attention scratch (dead once every lane has left the column pass), in two halves; from there on the
@@ -1783,47 +1831,18 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
                 de[4 * c] = v.x; de[4 * c + 1] = v.y; de[4 * c + 2] = v.z; de[4 * c + 3] = v.w;
             }
             de[20] = Gr[20];
+            // Range guard.  The high half of a pair is an fp16: an operand of 65 520 or more, or a weight without a pair (the packer stores
+            // +-inf for it), makes the outputs of its sample non-finite (w inf = inf, 0 inf = NaN).  The launch's watch word then makes the
+            // fp32 instantiation behind this launch recompute it: that form has no such limit (the reference computes in fp32,
+            // ibrnet.py:497-504).
+            float chk = 0.f;
+#pragma unroll
+            for (int e = 0; e < 21; ++e) chk += de[e];
+            if (__ballot(act && !(fabsf(chk) < 3.0e38f)) != 0ull && lane == 0 && a.range_word) atomicOr(a.range_word, 2u);
         }
-#else
-        float g16b[16];                                   // geometry_fc's output again (re-read: 16 registers less across the sweeps)
-        {
-            const f4* r4 = reinterpret_cast<const f4*>(rec);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f4 x = __builtin_nontemporal_load(r4 + q4);
-                g16b[4 * q4] = x.x; g16b[4 * q4 + 1] = x.y; g16b[4 * q4 + 2] = x.z; g16b[4 * q4 + 3] = x.w;
-            }
+        } else {
+            tail_fp32();
         }
-        float dc[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float s = dy[c];
-#pragma unroll
-            for (int f = 0; f < 16; ++f) {
-                s = fmaf(W[pk::R_WQT + c * 16 + f], dQ[f], s);
-                s = fmaf(W[pk::R_WKT + c * 16 + f], dK[f], s);
-                s = fmaf(W[pk::R_WVT + c * 16 + f], dV[f], s);
-            }
-            dc[c] = s * (g16b[c] > 0.f ? 1.f : g16b[c] + 1.f);
-        }
-#pragma unroll
-        for (int e = 0; e < 21; ++e) de[e] = 0.f;
-#pragma unroll 2
-        for (int h4 = 0; h4 < 16; ++h4) {
-            const f4 u4 = reinterpret_cast<const f4*>(rec + 16)[h4];
-#pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
-                const int h = 4 * h4 + hh;
-                float du = 0.f;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) du = fmaf(W[pk::R_GEO2WT + h * 16 + c], dc[c], du);
-                const float uh = u4[hh];
-                const float da = du * (uh > 0.f ? 1.f : uh + 1.f);
-#pragma unroll
-                for (int e = 0; e < 21; ++e) de[e] = fmaf(W[pk::R_GEO1E + h * 24 + e], da, de[e]);
-            }
-        }
-#endif
         const float* dsc = a.desc + pt * DESC_FLOATS;
         const f4 ds0 = reinterpret_cast<const f4*>(dsc)[0], ds1 = reinterpret_cast<const f4*>(dsc)[1];
         const float pp[3] = {ds0.x, ds0.y, ds0.z}, qd[3] = {ds0.w, ds1.x, ds1.y};

@@ -294,6 +294,8 @@ GNR_HD void pack_pairs(const Ex& ex, float* dst, WF wf, int KB, int NB, Phi phi,
             bool fin;
             const float hf = f16_to_f32(hh, fin);
             if (fin) { h = hh; m = f32_to_f16((w - hf) * 2048.f); }
+            else h = hh;                                         // no pair (|w| >= 65 520 or not finite): +-inf / NaN in the high half -- the consumer's outputs
+                                                                 // turn non-finite and its range guard recomputes them in fp32 (k_ray<true>)
         }
         o16[(((kb * NB + nb) * 2 + 0) * 64 + lane) * 8 + i] = h;
         o16[(((kb * NB + nb) * 2 + 1) * 64 + lane) * 8 + i] = m;

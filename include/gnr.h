@@ -145,7 +145,9 @@ int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, 
  * immediately unless the watch tripped and otherwise recomputes the launch: out-of-range scenes get the fp32 kernel's values,
  * in-range scenes pay ~5 us per chain launch, and no call synchronises with the host.
  * gnr_range_status reads the watch word of the last gnr_prepare on this workspace (synchronises `stream`):
- *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range;
+ *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range (k_chain), or a
+ *   non-finite value in the matrix-core tail of the per-ray kernel (an operand or a per-ray weight beyond the fp16 range: that launch and the
+ *   later per-ray launches on the prepared scene are recomputed by their fp32 instantiation);
  *   bit 2: a weight beyond the fp16 range (gnr_pack_weights marks such a blob instead of refusing it);
  *   bit 3: (backward, gnr_feature_grad_mode(1) only) a feature-map gradient contribution was clamped to the fixed-point range.
  * Bits 0 and 2 hold for every launch on the prepared scene (the pair kernel then returns at once and the twin computes the launch);

@@ -138,6 +138,39 @@ def test_a_weight_without_an_fp16_pair_runs_on_the_fp32_twin(weights_np):
     _check_fallback(hp, w, ref, que, 4, 'mean_decoder.0 weight = 1e5')
 
 
+@pytest.mark.parametrize('key,ij', [('agg_impl.geometry_fc.2.weight', (3, 5)), ('agg_impl.ray_attention.w_ks.weight', (2, 9)),
+                                    ('agg_impl.geometry_fc.0.weight', (7, 70))])
+def test_a_k_ray_weight_without_an_fp16_pair_runs_on_the_fp32_twin(key, ij, weights_np):
+    """The dense tail of k_ray<true>'s in-forward VJP multiplies on the f16 matrix cores ([Wq;Wk;Wv]^T, geometry_fc.2^T, geometry_fc.0^T:
+    csrc/gnr_kernels.hip).  A weight of 1e5 has no fp16 pair: the packer stores inf for it, the tail's outputs turn non-finite, the
+    launch's watch word (bit 1 of gnr_range_status) makes the fp32 instantiation behind the launch recompute it -- the SDF gradient is the
+    fp32 one (oracle autograd to 1e-3), everything is finite."""
+    from graspnerf_amd.hotpath import batch_scenes
+    w = dict(weights_np)
+    w['agg_net.' + key] = w['agg_net.' + key].copy()
+    w['agg_net.' + key][ij] = 1e5
+    hp = _hp(w)
+    ref, que = make_scene(0, 'cfg1')
+    bref, bque = batch_scenes([(ref, que)])
+    dn = 16
+    depth = O.sample_depth(torch.from_numpy(que['depth_range']), que['coords'].shape[0], dn)
+    prep = hp.prepare(bref, 1, que['coords'].shape[0], dn)
+    o = hp.render_by_depth(bref, bque, depth[None], 'coarse', debug=True, prepared=prep)
+    flags = hp.range_status(prep)
+    assert flags & 2, flags
+    dbg = {}
+    Wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    O.render_by_depth(Wt, O.to_torch(ref), O.to_torch(que), depth, 'dist_decoder.', 'agg_net.', O.DEFAULT_RENDER_CFG, debug=dbg)
+    got, want = o['sdf_gradient'].cpu().numpy()[0].astype(np.float64), dbg['grad'].numpy().astype(np.float64)
+    assert np.isfinite(got).all() and all(np.isfinite(v.float().cpu().numpy()).all() for v in o.values())
+    assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), (np.abs(got - want).max(), np.abs(want).max())
+    # and an in-range scene on the same workspace afterwards: a new prepare clears the watch
+    hp2 = _hp(weights_np)
+    prep2 = hp2.prepare(bref, 1, que['coords'].shape[0], dn)
+    hp2.render_by_depth(bref, bque, depth[None], 'coarse', debug=True, prepared=prep2)
+    assert hp2.range_status(prep2) == 0
+
+
 @pytest.mark.parametrize('regime', ['x1', 'features x30', 'features x1e-3', 'decoder+geometry weights x3'])
 def test_fp64_arbiter(regime, weights_np):
     """|HIP - fp64| against |fp32 oracle - fp64| on the volume (16^3) and the coarse sdf / alpha of 64 rays.  The HIP path uses

@@ -243,6 +243,36 @@ def test_geo_dual_bwd_on_the_matrix_cores_agrees_with_the_fp32_kernel(scale_x, s
     assert float(got[0][:, 65].abs().max()) == 0.0                     # n_valid has no gradient
 
 
+@pytest.mark.gpu
+def test_geo_dual_bwd_weight_without_an_fp16_pair_falls_back_to_the_fp32_kernel(weights_np):
+    """A geometry_fc weight of 1e5 has no fp16 pair: k_pack_geo_dual stores inf for it, the matrix-core kernel's outputs turn non-finite, its
+    range word makes the fp32 kernel launched behind it recompute the call: the outputs are that kernel's, bit for bit."""
+    from graspnerf_amd.hotpath import HotPath
+    from graspnerf_amd import _lib
+    w = dict(weights_np)
+    k = 'fine_agg_net.agg_impl.geometry_fc.2.weight'
+    w[k] = w[k].copy(); w[k][5, 11] = 1e5
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    canon = torch.from_numpy(weights.canonical_blob(w, 'fine')).cuda()
+    rng = np.random.default_rng(2)
+    Pn = 5000
+    stats = rng.standard_normal((Pn, 66)).astype(np.float32); stats[:, 32:64] = np.abs(stats[:, 32:64]); stats[:, 65] = 6
+    pts = rng.uniform(-0.5, 0.5, (Pn, 3)).astype(np.float32)
+    gamma, gbar, gdbar = (rng.standard_normal(sh).astype(np.float32) * 1e-3 for sh in ((Pn, 3), (Pn, 16), (Pn, 16)))
+    L = _lib.lib()
+    prev = L.gnr_debug_geo_dual_matrix_cores(1)
+    try:
+        got = [x.clone() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
+        L.gnr_debug_geo_dual_matrix_cores(0)
+        want = [x.clone() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
+    finally:
+        L.gnr_debug_geo_dual_matrix_cores(prev)
+    torch.cuda.synchronize()
+    for g, x in zip(got, want):
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+        assert torch.equal(g, x)
+
+
 def test_positive_cumprod_backward_equals_autograd():
     """reference_autograd._CumprodPositive: torch.cumprod's values, and its gradient for strictly positive factors, without the
     `(x == 0).any()` host read of the stock backward."""
