@@ -578,3 +578,52 @@ def test_bwd_pair_images_encode_their_fp32_fragments(weights_np):
                     assert np.all(np.abs(h + m / 2048.0 - w) <= 2.0 ** -22 * np.abs(w) + 2.0 ** -35), (dst, b, nb, i)      # one to two fp32 ulps; below 6e-5 the halves are fp16 subnormals: 3e-11 absolute
     assert np.array_equal(pb[O['P2_B_PE2']:O['P2_B_PE2'] + 32], pb[O['B_PE2']:O['B_PE2'] + 32])
     assert np.array_equal(pb[O['P1_B_PE2']:O['P1_B_PE2'] + 32], pb[O['V1_B_PE2']:O['V1_B_PE2'] + 32])
+
+
+def test_rm_section_encodes_the_vjp_tail_of_k_ray(weights_np):
+    """The RM section of the forward blob (gnr_layout.h): fp16-pair K32 blocks of the three layers k_ray<true> runs on the matrix cores.
+    Block b, output block nb, lane (r = lane & 15, g = lane >> 4), element e holds h + m 2^-11 = the weight of output 16 nb + r and
+      RM_DC:   input 32 b + 8 g + e of [dQ | dK | dV | dy]: [Wq; Wk; Wv][k][o] for k < 48, the identity behind (the residual),
+      RM_GEOA: input 4 g + e (e < 4; the D layout of RM_DC's output): geometry_fc.2.weight[c][h],
+      RM_GEOB: hidden unit 16 (2 b + e / 4) + 4 g + e % 4 (the D layout of RM_GEOA's output): geometry_fc.0.weight[h][65 + o], o < 21;
+    a weight without an fp16 pair (1e5) is stored as inf in the high half (k_ray's range guard then recomputes in fp32)."""
+    w = dict(weights_np)
+    k2 = 'agg_net.agg_impl.geometry_fc.2.weight'
+    w[k2] = w[k2].copy(); w[k2][3, 5] = 1e5
+    p = weights.pack_state_dict(w, 'coarse')
+    att = 'agg_net.agg_impl.ray_attention.'
+    Wqkv = np.concatenate([w[att + 'w_qs.weight'], w[att + 'w_ks.weight'], w[att + 'w_vs.weight']], 0).astype(np.float64)     # [48][16]
+    G2 = w[k2].astype(np.float64)                                                   # [16][64]
+    G0 = w['agg_net.agg_impl.geometry_fc.0.weight'].astype(np.float64)             # [64][86]
+
+    def decode(name, KB, NB):
+        halfs = p[off(name):off(name) + KB * NB * 512].view(np.float16).astype(np.float64)
+        out = np.zeros((KB, NB, 64, 8))
+        for b in range(KB):
+            for nb in range(NB):
+                for half, sc in ((0, 1.0), (1, 1.0 / 2048.0)):
+                    blk = halfs[((b * NB + nb) * 2 + half) * 512:((b * NB + nb) * 2 + half + 1) * 512].reshape(64, 8)
+                    out[b, nb] += blk * sc
+        return out
+
+    dc, ga, gb = decode('RM_DC', 2, 1), decode('RM_GEOA', 1, 4), decode('RM_GEOB', 2, 2)
+    tol = lambda x: 2.0 ** -22 * np.abs(x) + 2.0 ** -35
+    for lane in range(64):
+        r, g = lane & 15, lane >> 4
+        for e in range(8):
+            for b in range(2):
+                k = 32 * b + 8 * g + e
+                want = Wqkv[k, r] if k < 48 else (1.0 if k - 48 == r else 0.0)
+                assert abs(dc[b, 0, lane, e] - want) <= tol(want), ('RM_DC', b, lane, e)
+                for nb in range(2):
+                    h, o = 16 * (2 * b + e // 4) + 4 * g + e % 4, 16 * nb + r
+                    want = G0[h, 65 + o] if o < 21 else 0.0
+                    assert abs(gb[b, nb, lane, e] - want) <= tol(want), ('RM_GEOB', b, nb, lane, e)
+            for nb in range(4):
+                h, c = 16 * nb + r, 4 * g + e
+                if e >= 4:
+                    assert ga[0, nb, lane, e] == 0.0
+                elif (c, h) == (3, 5):
+                    assert np.isinf(ga[0, nb, lane, e]) and ga[0, nb, lane, e] > 0          # no fp16 pair
+                else:
+                    assert abs(ga[0, nb, lane, e] - G2[c, h]) <= tol(G2[c, h]), ('RM_GEOA', nb, lane, e)
