@@ -88,6 +88,8 @@ def lib():
     L.gnr_force_fp32_chain.restype = C.c_int
     L.gnr_debug_ray_order.argtypes = [C.c_int]
     L.gnr_debug_ray_order.restype = C.c_int
+    L.gnr_debug_scatter_bins.argtypes = [C.c_int]
+    L.gnr_debug_scatter_bins.restype = C.c_int
     L.gnr_sample_volume_fwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_sample_volume_fwd.restype = C.c_int
@@ -229,7 +231,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
             'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_debug_conv3d_first_gen', 'gnr_conv3d_tap_mask_words', 'gnr_conv3d_tap_mask', 'gnr_conv3d_same_masked', 'gnr_conv3d_same_bwd_weight_masked', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
-            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_debug_poison_partials', 'gnr_feature_grad_mode', 'gnr_debug_view1_partner', 'gnr_debug_geo_dual_matrix_cores', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
+            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_debug_poison_partials', 'gnr_feature_grad_mode', 'gnr_debug_view1_partner', 'gnr_debug_scatter_bins', 'gnr_debug_geo_dual_matrix_cores', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
             'gnr_img_last_error', 'gnr_instnorm_act', 'gnr_instnorm_act_bwd', 'gnr_reflect_pad2d', 'gnr_reflect_pad2d_bwd', 'gnr_upsample2x_bilinear']
 
 

@@ -2063,7 +2063,9 @@ __global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restri
 #define GNR_HD __host__ __device__
 #include "gnr_pack_body.h"      // (k_pack_geo_dual: the packer's pair-block builder on the device)
 #include "gnr_bwd.inc"
+#ifndef GNR_DEV_NO_CAPI         // tools/isa_one.sh: the kernels alone + one explicit instantiation (register / spill checks in seconds)
 #include "gnr_capi.inc"
+#endif
 #if GNR_PROTO_P1
 #include "gnr_chain_p1_capi.inc"
 #endif

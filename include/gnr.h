@@ -301,6 +301,9 @@ int gnr_feature_grad_mode(int mode);       /* 0: float atomics (default); 1: 64-
 /* Measurement / test switch: the backward of the first view loop as k_view1_bwd (one wavefront per tile, 0) or as k_view1_bwd_pw
  * (a compute wavefront and its partner per tile, 1: the default).  Same outputs either way; returns the old setting. */
 int gnr_debug_view1_partner(int on);
+/* Measurement / test switch: the feature-map gradient of k_view1_bwd_pw as the binned scatter (1: the default; csrc/gnr_bwd_scatter.inc:
+ * rows parked in HBM, summed per feature-map pixel before anything is added atomically) or as direct float atomics (0). */
+int gnr_debug_scatter_bins(int on);
 /* Measurement / test switch: the per-point half of gnr_geo_dual_bwd on the f16 matrix cores (1: the default) or as fp32 FMAs with one
  * lane per point (0).  Same outputs to rounding; returns the old setting. */
 int gnr_debug_geo_dual_matrix_cores(int on);
