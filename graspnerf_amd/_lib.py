@@ -15,7 +15,13 @@ c_float_p = C.POINTER(C.c_float)
 class GnrScene(C.Structure):
     _fields_ = [('B', C.c_int), ('V', C.c_int), ('H', C.c_int), ('W', C.c_int), ('fh', C.c_int), ('fw', C.c_int),
                 ('imgs', C.c_void_p), ('img_feats', C.c_void_p), ('ray_feats', C.c_void_p),
-                ('poses', C.c_void_p), ('Ks', C.c_void_p), ('depth_range', C.c_void_p), ('use_vis', C.c_int)]
+                ('poses', C.c_void_p), ('Ks', C.c_void_p), ('depth_range', C.c_void_p), ('use_vis', C.c_int), ('options', C.c_uint)]
+
+
+# per-call options (GnrScene.options; the `options` argument of gnr_ray_tail_dual_bwd / gnr_geo_dual_bwd): include/gnr.h GNR_OPT_*
+OPTIONS = {'fp32_chain': 0x001, 'feature_grad_fixed': 0x002, 'view1_one_wavefront': 0x004, 'view2_one_wavefront': 0x008,
+           'ray_order_morton': 0x010, 'poison_partials': 0x020, 'direct_scatter': 0x040, 'geo_dual_fp32': 0x080, 'test_lose_partner': 0x100}
+GNR_STATUS_LOST_PARTNER = 16
 
 
 class GnrRays(C.Structure):
@@ -84,12 +90,8 @@ def lib():
     L.gnr_prepare.restype = C.c_int
     L.gnr_range_status.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_size_t, C.POINTER(C.c_uint), C.c_void_p]
     L.gnr_range_status.restype = C.c_int
-    L.gnr_force_fp32_chain.argtypes = [C.c_int]
-    L.gnr_force_fp32_chain.restype = C.c_int
-    L.gnr_debug_ray_order.argtypes = [C.c_int]
-    L.gnr_debug_ray_order.restype = C.c_int
-    L.gnr_debug_scatter_bins.argtypes = [C.c_int]
-    L.gnr_debug_scatter_bins.restype = C.c_int
+    L.gnr_status_words_offset.argtypes = [C.POINTER(GnrScene)]
+    L.gnr_status_words_offset.restype = C.c_size_t
     L.gnr_sample_volume_fwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_sample_volume_fwd.restype = C.c_int
@@ -125,8 +127,6 @@ def lib():
     L.gnr_conv3d_same_workspace_bytes.restype = C.c_size_t
     L.gnr_conv3d_same.argtypes = [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_conv3d_same.restype = C.c_int
-    L.gnr_debug_conv3d_first_gen.argtypes = [C.c_int]
-    L.gnr_debug_conv3d_first_gen.restype = C.c_int
     L.gnr_conv3d_tap_mask_words.argtypes = [C.c_int] * 2
     L.gnr_conv3d_tap_mask_words.restype = C.c_size_t
     L.gnr_conv3d_tap_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -173,21 +173,15 @@ def lib():
     L.gnr_host_randperm_prefix.restype = C.c_int
     L.gnr_geo_dual_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
     L.gnr_geo_dual_fwd.restype = C.c_int
-    L.gnr_geo_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_geo_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]
     L.gnr_geo_dual_bwd_workspace_bytes.argtypes = [C.c_int]
     L.gnr_geo_dual_bwd_workspace_bytes.restype = C.c_size_t
     L.gnr_geo_dual_bwd.restype = C.c_int
     L.gnr_composite_bwd.restype = C.c_int
     L.gnr_render_tail_fwd_train.restype = C.c_int
     L.gnr_ray_tail_grad_floats.restype = C.c_int
-    L.gnr_ray_tail_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gnr_ray_tail_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]
     L.gnr_ray_tail_dual_bwd_workspace_bytes.restype = C.c_size_t
-    L.gnr_debug_poison_partials.argtypes = [C.c_int]
-    L.gnr_debug_poison_partials.restype = C.c_int
-    L.gnr_debug_geo_dual_matrix_cores.argtypes = [C.c_int]
-    L.gnr_debug_geo_dual_matrix_cores.restype = C.c_int
-    L.gnr_feature_grad_mode.argtypes = [C.c_int]
-    L.gnr_feature_grad_mode.restype = C.c_int
     L.gnr_ray_tail_dual_bwd.restype = C.c_int
     L.gnr_grasp_select_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.gnr_grasp_select_workspace_bytes.restype = C.c_size_t
@@ -223,15 +217,15 @@ def lib():
 
 
 EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_pack_vis_decoder', 'gnr_pack_vis_decoder_bwd', 'gnr_canonical_vis_floats', 'gnr_pack_weights_device', 'gnr_pack_weights_bwd_device', 'gnr_pack_vis_decoder_device', 'gnr_pack_vis_decoder_bwd_device', 'gnr_layout_offset', 'gnr_workspace_bytes',
-            'gnr_prepare', 'gnr_range_status', 'gnr_force_fp32_chain', 'gnr_debug_ray_order', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
+            'gnr_prepare', 'gnr_range_status', 'gnr_status_words_offset', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
             'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_timing_begin', 'gnr_timing_begin_only', 'gnr_timing_end', 'gnr_grasp_select_workspace_bytes',
             'gnr_grasp_select_fwd', 'gnr_post_last_error', 'gnr_packed_bwd_floats', 'gnr_pack_weights_bwd',
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
-            'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_debug_conv3d_first_gen', 'gnr_conv3d_tap_mask_words', 'gnr_conv3d_tap_mask', 'gnr_conv3d_same_masked', 'gnr_conv3d_same_bwd_weight_masked', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
-            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_debug_poison_partials', 'gnr_feature_grad_mode', 'gnr_debug_view1_partner', 'gnr_debug_scatter_bins', 'gnr_debug_geo_dual_matrix_cores', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
+            'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_tap_mask_words', 'gnr_conv3d_tap_mask', 'gnr_conv3d_same_masked', 'gnr_conv3d_same_bwd_weight_masked', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
+            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
             'gnr_img_last_error', 'gnr_instnorm_act', 'gnr_instnorm_act_bwd', 'gnr_reflect_pad2d', 'gnr_reflect_pad2d_bwd', 'gnr_upsample2x_bilinear']
 
 

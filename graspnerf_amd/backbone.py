@@ -362,6 +362,9 @@ def _fold_route(x, w):
 
 
 STRIDE2_AS_S2D = True               # the same for the encoder's stride-2 layers
+CONV3D_FIRST_GEN = False            # tests: the K = 3 convolutions of this module through the first-generation kernels (GNR_CONV3D_FIRST_GEN:
+                                    # a per-call flag of the C ABI, include/gnr.h -- this switch lives on the Python side, the library keeps none)
+GNR_CONV3D_FIRST_GEN = 0x100
 
 
 def _s2d_route(x, w):
@@ -465,7 +468,7 @@ def _hip_conv3d_same(x, w, b, mode, mask=None):
     ws = _CONV_WS[key]
     y = torch.empty(B, cin if mode else cout, D, H, W, dtype=torch.float32, device=x.device)
     rc = L.gnr_conv3d_same_masked(x.data_ptr(), w.data_ptr(), b.contiguous().data_ptr() if (b is not None and not mode) else None, y.data_ptr(),
-                                  B, cin, cout, D, H, W, k, mode, mask.data_ptr() if mask is not None else None, ws.data_ptr(), ws.numel(),
+                                  B, cin, cout, D, H, W, k, mode | (GNR_CONV3D_FIRST_GEN if CONV3D_FIRST_GEN else 0), mask.data_ptr() if mask is not None else None, ws.data_ptr(), ws.numel(),
                                   C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc:
         raise _lib.GnrError(f'gnr_conv3d_same failed: {_lib.ERRORS.get(rc, rc)} ({L.gnr_head_last_error().decode(errors="replace")})')
@@ -504,7 +507,8 @@ class _Conv3dSame(torch.autograd.Function):
             key = (x.device, 'wgrad', need)
             if key not in _CONV_WS:
                 _CONV_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
-            rc = L.gnr_conv3d_same_bwd_weight_masked(xc.data_ptr(), dy.data_ptr(), dw.data_ptr(), *dims, mask.data_ptr() if mask is not None else None,
+            kflag = k | (GNR_CONV3D_FIRST_GEN if CONV3D_FIRST_GEN else 0)
+            rc = L.gnr_conv3d_same_bwd_weight_masked(xc.data_ptr(), dy.data_ptr(), dw.data_ptr(), *dims[:-1], kflag, mask.data_ptr() if mask is not None else None,
                                                      _CONV_WS[key].data_ptr(), need, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             if rc:
                 raise _lib.GnrError(f'gnr_conv3d_same_bwd_weight failed: {rc}')

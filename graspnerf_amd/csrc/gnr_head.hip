@@ -852,10 +852,8 @@ extern "C" size_t gnr_conv3d_same_workspace_bytes(int Cin, int Cout, int K) {
 
 // mode 0: x [B][Cin][D][H][W] -> y [B][Cout][D][H][W] (+ bias [Cout] or NULL);  mode 1: x = dy [B][Cout][..] -> y = dx [B][Cin][..]
 // (bias ignored).  w = the layer's canonical weights [Cout][Cin][K][K][K] on the device.  K = 3 or 5.
-static std::atomic<int> g_conv3d_first_gen{0};
-// Debug switch (tests): route the K = 3 calls through the first-generation kernels (the path taken for volumes beyond the buffer
-// loads' 32-bit offsets).  Returns the previous setting.
-extern "C" int gnr_debug_conv3d_first_gen(int on) { return g_conv3d_first_gen.exchange(on ? 1 : 0); }
+// GNR_CONV3D_FIRST_GEN (tests; ORed into `mode` / `K`, include/gnr.h): route a K = 3 call through the first-generation kernels (the path
+// taken for volumes beyond the buffer loads' 32-bit offsets).  A per-call flag: the library keeps no switch.
 
 extern "C" size_t gnr_conv3d_tap_mask_words(int Cin, int Cout) {
     if (Cin < 1 || Cout < 1) return 0;
@@ -883,6 +881,8 @@ extern "C" int gnr_conv3d_same(const float* x, const float* w, const float* bias
 // `mask` = gnr_conv3d_tap_mask of the layer's weight pattern (or NULL: dense): taps without a weight are skipped.
 extern "C" int gnr_conv3d_same_masked(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H,
                                       int W, int K, int mode, const unsigned* mask, void* ws, size_t ws_bytes, void* stream) {
+    const bool first_gen = (mode & GNR_CONV3D_FIRST_GEN) != 0;
+    mode &= ~GNR_CONV3D_FIRST_GEN;
     if (!x || !w || !y || !ws) { snprintf(h_err, sizeof(h_err), "gnr_conv3d_same: null pointer"); return GNR_ERR_ARG; }
     if (B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5) || (mode != 0 && mode != 1)) {
         snprintf(h_err, sizeof(h_err), "gnr_conv3d_same: bad shape / mode (K must be 3 or 5)"); return GNR_ERR_SHAPE; }
@@ -905,7 +905,7 @@ extern "C" int gnr_conv3d_same_masked(const float* x, const float* w, const floa
         static std::atomic<unsigned long long> attr{0};
         if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
         hipLaunchKernelGGL(gnr_head::k_conv3d_s1<5>, dim3((unsigned)blocks, nbt), dim3(256), lds, st, a);
-    } else if (g_conv3d_first_gen.load() || (size_t)16 * D * H * W * sizeof(float) >= ((size_t)1 << 31) || (size_t)27 * 4 * nbt * 64 * sizeof(float) >= ((size_t)1 << 31)) {
+    } else if (first_gen || (size_t)16 * D * H * W * sizeof(float) >= ((size_t)1 << 31) || (size_t)27 * 4 * nbt * 64 * sizeof(float) >= ((size_t)1 << 31)) {
         // a chunk's 16 channels do not fit the 32-bit byte offsets of the buffer loads (> 32 M voxels): the first-generation kernel
         const size_t lds = (16 * (10 * 10 * 6) + 3 * 256) * sizeof(float);
         static std::atomic<unsigned long long> attr{0};
@@ -1202,6 +1202,8 @@ extern "C" int gnr_conv3d_same_bwd_weight(const float* x, const float* dy, float
 // `mask` = gnr_conv3d_tap_mask of the layer's weight pattern (or NULL): the gradient of an absent weight is not computed (stays as it was in dw).
 extern "C" int gnr_conv3d_same_bwd_weight_masked(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W,
                                                  int K, const unsigned* mask, void* ws, size_t ws_bytes, void* stream) {
+    const bool first_gen = (K & GNR_CONV3D_FIRST_GEN) != 0;
+    K &= ~GNR_CONV3D_FIRST_GEN;
     if (!x || !dy || !dw || !ws || B < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (K != 3 && K != 5)) return GNR_ERR_ARG;
     if (ws_bytes < gnr_conv3d_same_bwd_weight_workspace_bytes(B, Cin, Cout, D, H, W, K)) return GNR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1215,7 +1217,7 @@ extern "C" int gnr_conv3d_same_bwd_weight_masked(const float* x, const float* dy
             static std::atomic<unsigned long long> attr{0};
             if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
             hipLaunchKernelGGL(gnr_head::k_conv3d_wgrad_s1<5>, dim3((unsigned)gx, nbi * nbo), dim3(256), lds, st, x, dy, part, B, Cin, Cout, D, H, W, nbi, mask);
-        } else if (g_conv3d_first_gen.load() || (size_t)16 * D * H * W * sizeof(float) >= ((size_t)1 << 31)) {      // beyond the buffer loads' 32-bit byte offsets
+        } else if (first_gen || (size_t)16 * D * H * W * sizeof(float) >= ((size_t)1 << 31)) {      // beyond the buffer loads' 32-bit byte offsets
             const size_t lds = (16 * (10 * 10 * 6) + 16 * 256) * sizeof(float);
             static std::atomic<unsigned long long> attr{0};
             if (head_attr_needed(attr)) { HCHK(hipFuncSetAttribute((const void*)gnr_head::k_conv3d_wgrad_s1<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }

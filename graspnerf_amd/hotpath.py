@@ -25,6 +25,8 @@ def _f32(t, device):
 
 
 class HotPath:
+    default_options = 0          # options a new HotPath starts with (a Python-side default for test fixtures; the library itself keeps no switch)
+
     def __init__(self, packed_coarse, packed_fine=None, device='cuda:0'):
         self.L = _lib.lib()                      # raises if the HIP library is missing
         if not torch.cuda.is_available():
@@ -39,6 +41,7 @@ class HotPath:
         if packed_fine is not None and bool(np.asarray(packed_fine).reshape(-1)[flag] != 0) != self.use_vis:
             raise _lib.GnrError('use_vis must be the same for both levels (the reference evaluates the fine level with the coarse '
                                 "decoder's compute_prob, renderer.py:70-72)")
+        self.options = HotPath.default_options   # per-call options of this HotPath's calls (set_option; include/gnr.h GNR_OPT_*)
         self._ws = None
         self._keep = []
 
@@ -50,6 +53,20 @@ class HotPath:
                                 f'wrap the call in `with torch.cuda.device({self.device.index})`')
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _sc(self, scene):
+        """byref(scene) with this HotPath's per-call options (GnrScene.options, include/gnr.h GNR_OPT_*): the library keeps no switch,
+        so the options travel with every call; a prepared scene that is re-used picks up the current ones."""
+        scene.options = self.options
+        return C.byref(scene)
+
+    def set_option(self, name, on=True):
+        """Switch one of the per-call options (_lib.OPTIONS: fp32_chain, feature_grad_fixed, view1_one_wavefront, view2_one_wavefront,
+        ray_order_morton, poison_partials, direct_scatter, geo_dual_fp32, test_lose_partner) for the calls of THIS HotPath; -> previous."""
+        bit = _lib.OPTIONS[name]
+        prev = bool(self.options & bit)
+        self.options = (self.options | bit) if on else (self.options & ~bit)
+        return prev
+
     def _scene(self, ref):
         d = self.device
         t = {k: _f32(ref[k], d) for k in ('imgs', 'img_feats', 'ray_feats', 'poses', 'Ks', 'depth_range')}
@@ -58,11 +75,11 @@ class HotPath:
         assert t['img_feats'].shape == (B, V, 32, fh, fw) and t['ray_feats'].shape == (B, V, 32, fh, fw)
         assert t['poses'].shape == (B, V, 3, 4) and t['Ks'].shape == (B, V, 3, 3) and t['depth_range'].shape == (B, V, 2)
         s = GnrScene(B, V, H, W, fh, fw, t['imgs'].data_ptr(), t['img_feats'].data_ptr(), t['ray_feats'].data_ptr(),
-                     t['poses'].data_ptr(), t['Ks'].data_ptr(), t['depth_range'].data_ptr(), 1 if self.use_vis else 0)
+                     t['poses'].data_ptr(), t['Ks'].data_ptr(), t['depth_range'].data_ptr(), 1 if self.use_vis else 0, self.options)
         return s, t
 
     def _workspace(self, scene, res, rn, dn):
-        need = max(self.L.gnr_workspace_bytes(C.byref(scene), res, rn, dn), 0 if self._ws is None else self._ws.numel())
+        need = max(self.L.gnr_workspace_bytes(self._sc(scene), res, rn, dn), 0 if self._ws is None else self._ws.numel())
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -90,7 +107,7 @@ class HotPath:
         self._pass_seq = 0                               # render passes of this forward, counted for their persistent training workspaces
         scene, keep = self._scene(ref)
         ws = self._workspace(scene, res, rn, dn)
-        _lib.check(self.L.gnr_prepare(C.byref(scene), ws.data_ptr(), ws.numel(), self._stream()), 'gnr_prepare')
+        _lib.check(self.L.gnr_prepare(self._sc(scene), ws.data_ptr(), ws.numel(), self._stream()), 'gnr_prepare')
         self._prepared = (scene, keep, ws)
         return self._prepared
 
@@ -100,17 +117,25 @@ class HotPath:
         launches were recomputed by the fp32-MFMA twin."""
         scene, keep, ws = prepared or self._prepared
         flags = C.c_uint(0)
-        _lib.check(self.L.gnr_range_status(C.byref(scene), ws.data_ptr(), ws.numel(), C.byref(flags), self._stream()), 'gnr_range_status')
+        _lib.check(self.L.gnr_range_status(self._sc(scene), ws.data_ptr(), ws.numel(), C.byref(flags), self._stream()), 'gnr_range_status')
         return int(flags.value)
 
+    def status_words(self, prepared=None):
+        """The 64 status words of the prepared scene as an int32 DEVICE view of the workspace (no copy, no synchronisation):
+        `(words & 16).any()` = GNR_STATUS_LOST_PARTNER of the backward calls since that prepare (include/gnr.h)."""
+        scene, keep, ws = prepared or self._prepared
+        off = self.L.gnr_status_words_offset(C.byref(scene))
+        return ws[off:off + 256].view(torch.int32)
+
     def feature_grad_mode(self, fixed_point):
-        """Process-wide: feature-map gradients through 64-bit fixed-point adds (bit-reproducible) instead of float atomics
-        (include/gnr.h gnr_feature_grad_mode; -> previous setting).  range_status() bit 3 tells a clamped contribution."""
-        return bool(self.L.gnr_feature_grad_mode(1 if fixed_point else 0))
+        """Feature-map gradients of this HotPath's backward calls through 64-bit fixed-point adds (bit-reproducible) instead of float
+        sums in arrival order (GNR_OPT_FEATURE_GRAD_FIXED; -> previous setting).  range_status() bit 3 tells a clamped contribution."""
+        return self.set_option('feature_grad_fixed', fixed_point)
 
     def force_fp32_chain(self, on):
-        """Process-wide test / measurement switch: every chain launch on the fp32-input MFMA (-> previous setting)."""
-        return bool(self.L.gnr_force_fp32_chain(1 if on else 0))
+        """Test / measurement switch: every chain launch of this HotPath -- forward and backward -- on the fp32-input MFMA
+        (GNR_OPT_FP32_CHAIN; -> previous setting)."""
+        return self.set_option('fp32_chain', on)
 
     # ---- sample_volume (ref: renderer.py:164-199) ------------------------------------------
     def sample_volume(self, ref, res=40, want_mask=False, prepared=None):
@@ -119,7 +144,7 @@ class HotPath:
         bbox_min = _f32(ref['bbox3d'], self.device)[:, 0].contiguous()
         vol = torch.empty(B, 1, res, res, res, dtype=torch.float32, device=self.device)
         vmask = torch.empty(B, res, res, res, dtype=torch.uint8, device=self.device) if want_mask else None
-        _lib.check(self.L.gnr_sample_volume_fwd(C.byref(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(),
+        _lib.check(self.L.gnr_sample_volume_fwd(self._sc(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(),
                                                 vol.data_ptr(), vmask.data_ptr() if want_mask else None,
                                                 ws.data_ptr(), ws.numel(), self._stream()), 'gnr_sample_volume_fwd')
         return (vol, vmask) if want_mask else vol
@@ -128,7 +153,7 @@ class HotPath:
         scene, keep, ws = prepared or self.prepare(ref, res)
         bbox_min = _f32(ref['bbox3d'], self.device)[:, 0].contiguous()
         dbg = torch.zeros(scene.B, res ** 3, 32, dtype=torch.float32, device=self.device)
-        _lib.check(self.L.gnr_debug_volume_chain(C.byref(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(),
+        _lib.check(self.L.gnr_debug_volume_chain(self._sc(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(),
                                                  dbg.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                    'gnr_debug_volume_chain')
         return dbg
@@ -182,7 +207,7 @@ class HotPath:
             scene, keep, ws = prepared or self.prepare(ref, 1, rn, dn)
             rays, rkeep = self._rays(que, dn, fdn, cfg, scene.H, scene.W)
             co_s, co = self._alloc_out(B, rn, dn, 'imgs' in que, False, rays.ray_batch_num)
-            _lib.check(self.L.gnr_render_rays_fwd(C.byref(scene), C.byref(rays), self.wc.data_ptr(), None, C.byref(co_s), None, None, None,
+            _lib.check(self.L.gnr_render_rays_fwd(self._sc(scene), C.byref(rays), self.wc.data_ptr(), None, C.byref(co_s), None, None, None,
                                                   ws.data_ptr(), ws.numel(), self._stream()), 'gnr_render_rays_fwd')
             co['ray_mask'] = co['ray_mask'].bool()
             return co, None
@@ -197,7 +222,7 @@ class HotPath:
         fi_s, fi = self._alloc_out(B, rn, fine_dn, 'imgs' in que, debug, rays.ray_batch_num)
         fd_in = _f32(fine_depth_in, self.device) if fine_depth_in is not None else None
         inds = torch.empty(B, rn, fdn, dtype=torch.int32, device=self.device) if debug else None
-        _lib.check(self.L.gnr_render_rays_fwd(C.byref(scene), C.byref(rays), self.wc.data_ptr(), self.wf.data_ptr(),
+        _lib.check(self.L.gnr_render_rays_fwd(self._sc(scene), C.byref(rays), self.wc.data_ptr(), self.wf.data_ptr(),
                                               C.byref(co_s), C.byref(fi_s),
                                               fd_in.data_ptr() if fd_in is not None else None,
                                               inds.data_ptr() if debug else None,
@@ -214,7 +239,7 @@ class HotPath:
         rays, rkeep = self._rays(que, dn, dn, cfg, scene.H, scene.W)
         o_s, o = self._alloc_out(B, rn, dn, 'imgs' in que, debug, rays.ray_batch_num)
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_render_by_depth_fwd(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
+        _lib.check(self.L.gnr_render_by_depth_fwd(self._sc(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
                                                   C.byref(o_s), ws.data_ptr(), ws.numel(), self._stream()),
                    'gnr_render_by_depth_fwd')
         o['ray_mask'] = o['ray_mask'].bool()
@@ -227,7 +252,7 @@ class HotPath:
         B, pn, _ = coords.shape
         out = torch.empty(B, scene.V, pn, 2, dtype=torch.float32, device=self.device)
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_depth_mean_fwd(C.byref(scene), coords.data_ptr(), pn, w.data_ptr(), out.data_ptr(),
+        _lib.check(self.L.gnr_depth_mean_fwd(self._sc(scene), coords.data_ptr(), pn, w.data_ptr(), out.data_ptr(),
                                              ws.data_ptr(), ws.numel(), self._stream()), 'gnr_depth_mean_fwd')
         return out
 
@@ -238,7 +263,7 @@ class HotPath:
         if getattr(self, 'wb', None) is None or self.wb.get(level) is None:
             raise _lib.GnrError('depth_mean_bwd: call set_bwd_weights() first')
         scene, keep, ws = prepared or self.prepare(ref, 1)
-        need = self.L.gnr_depth_mean_bwd_workspace_bytes(C.byref(scene))
+        need = self.L.gnr_depth_mean_bwd_workspace_bytes(self._sc(scene))
         if getattr(self, '_dm_scratch', None) is None or self._dm_scratch.numel() < need:
             self._dm_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         coords = _f32(coords, self.device)
@@ -248,7 +273,7 @@ class HotPath:
         dcan = torch.zeros(self.L.gnr_canonical_weights_floats(), dtype=torch.float32, device=self.device)
         dray = torch.empty(B, scene.V, 32, scene.fh, scene.fw, dtype=torch.float32, device=self.device) if want_feat_grad else None
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_depth_mean_bwd(C.byref(scene), coords.data_ptr(), pn, w.data_ptr(), self.wb[level].data_ptr(),
+        _lib.check(self.L.gnr_depth_mean_bwd(self._sc(scene), coords.data_ptr(), pn, w.data_ptr(), self.wb[level].data_ptr(),
                                              dmean.data_ptr(), dcan.data_ptr(), dray.data_ptr() if want_feat_grad else None,
                                              ws.data_ptr(), ws.numel(), self._dm_scratch.data_ptr(), self._dm_scratch.numel(),
                                              self._stream()), 'gnr_depth_mean_bwd')
@@ -257,12 +282,12 @@ class HotPath:
     # ---- sample_volume for training: forward with saved states + staged backward (csrc/gnr_bwd.inc) --------------
     def sample_volume_train(self, ref, res=40, prepared=None):
         scene, keep, ws = prepared or self.prepare(ref, res)
-        need = self.L.gnr_sample_volume_train_workspace_bytes(C.byref(scene), res)
+        need = self.L.gnr_sample_volume_train_workspace_bytes(self._sc(scene), res)
         if getattr(self, '_tws', None) is None or self._tws.numel() < need:
             self._tws = torch.empty(need, dtype=torch.uint8, device=self.device)
         bbox_min = _f32(ref['bbox3d'], self.device)[:, 0].contiguous()
         vol = torch.empty(scene.B, 1, res, res, res, dtype=torch.float32, device=self.device)
-        _lib.check(self.L.gnr_sample_volume_fwd_train(C.byref(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(), vol.data_ptr(),
+        _lib.check(self.L.gnr_sample_volume_fwd_train(self._sc(scene), bbox_min.data_ptr(), res, self.wc.data_ptr(), vol.data_ptr(),
                                                       ws.data_ptr(), ws.numel(), self._tws.data_ptr(), self._tws.numel(),
                                                       self._stream()), 'gnr_sample_volume_fwd_train')
         self._train_ctx = (scene, keep, ws, res, self._tws)     # the saved states travel with the context: a release_training_workspaces()
@@ -272,7 +297,7 @@ class HotPath:
         """Float view of one section of the training workspace (tests): save1 save2 saveG dg16 dS2 dG dS1 dfeat64 dtail."""
         names = ['save1', 'save2', 'saveG', 'dg16', 'dS2', 'dG', 'dS1', 'dfeat64', 'dtail']
         off = (C.c_size_t * 9)()
-        _lib.check(self.L.gnr_train_workspace_layout(C.byref(scene), res, off), 'gnr_train_workspace_layout')
+        _lib.check(self.L.gnr_train_workspace_layout(self._sc(scene), res, off), 'gnr_train_workspace_layout')
         i = names.index(name)
         end = off[i + 1] if i + 1 < 9 else self._tws.numel()
         return self._tws[off[i]:end].view(torch.float32)
@@ -285,7 +310,7 @@ class HotPath:
         shp = (scene.B, scene.V, 32, scene.fh, scene.fw)
         dray = torch.zeros(shp, dtype=torch.float32, device=self.device) if want_feat_grads else None
         dimg = torch.zeros(shp, dtype=torch.float32, device=self.device) if want_feat_grads else None
-        _lib.check(self.L.gnr_sample_volume_bwd(C.byref(scene), res, self.wc.data_ptr(), self.wb['coarse'].data_ptr(),
+        _lib.check(self.L.gnr_sample_volume_bwd(self._sc(scene), res, self.wc.data_ptr(), self.wb['coarse'].data_ptr(),
                                                 canonical_dev.data_ptr(), dvol.data_ptr(), dcan.data_ptr(),
                                                 dray.data_ptr() if want_feat_grads else None,
                                                 dimg.data_ptr() if want_feat_grads else None, ws.data_ptr(), ws.numel(),
@@ -307,7 +332,7 @@ class HotPath:
             assert depth.shape[:2] == (B, rn)
         dn = dn0 if depth is None else depth.shape[2]
         rays, rkeep = self._rays(que, dn0, fdn, cfg, scene.H, scene.W)
-        need = self.L.gnr_workspace_bytes(C.byref(scene), 1, rn, dn)
+        need = self.L.gnr_workspace_bytes(self._sc(scene), 1, rn, dn)
         if ws.numel() < need:
             raise _lib.GnrError('render_chain_train: prepare() the workspace for the ray count first')
         # the pass's training workspace (saved per-view states + gradient staging: ~1 GB at 8 scenes x 512 rays x 40 samples) is kept
@@ -315,7 +340,7 @@ class HotPath:
         # activations left the caching allocator re-carving its pool, which showed up as occasional 50-80 ms host stalls inside the
         # forward.  Keyed by the pass's position in its forward (every ray chunk's passes are alive until the backward) and its
         # shape; safe to re-use across forwards: a training forward before the previous one's backward is refused (check_generation).
-        need_t = self.L.gnr_render_chain_train_workspace_bytes(C.byref(scene), rn, dn)
+        need_t = self.L.gnr_render_chain_train_workspace_bytes(self._sc(scene), rn, dn)
         pool = self.__dict__.setdefault('_pass_tws', {})
         seq = self._pass_seq = getattr(self, '_pass_seq', 0) + 1
         key = (seq, level)                               # one buffer per pass position, grown in place when a shape needs more
@@ -329,7 +354,7 @@ class HotPath:
                'pts': torch.empty(B * rn * dn, 3, dtype=torch.float32, device=self.device),
                'qdir': torch.empty(B * rn, 3, dtype=torch.float32, device=self.device)}
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_render_chain_fwd_train(C.byref(scene), C.byref(rays), None if depth is None else depth.data_ptr(), dn,
+        _lib.check(self.L.gnr_render_chain_fwd_train(self._sc(scene), C.byref(rays), None if depth is None else depth.data_ptr(), dn,
                                                      w.data_ptr(), stats.data_ptr(), colors.data_ptr(),
                                                      geo['depth'].data_ptr() if depth is None else None, geo['pts'].data_ptr(),
                                                      geo['qdir'].data_ptr(), ws.data_ptr(), ws.numel(), tws.data_ptr(), tws.numel(),
@@ -347,7 +372,7 @@ class HotPath:
         dray = torch.empty(shp, dtype=torch.float32, device=self.device)
         dimg = torch.empty(shp, dtype=torch.float32, device=self.device)
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_render_chain_bwd(C.byref(scene), rn, dn, w.data_ptr(), self.wb[level].data_ptr(), dstats.data_ptr(),
+        _lib.check(self.L.gnr_render_chain_bwd(self._sc(scene), rn, dn, w.data_ptr(), self.wb[level].data_ptr(), dstats.data_ptr(),
                                                dcolors.data_ptr(), dcan.data_ptr(), dray.data_ptr(), dimg.data_ptr(), ws.data_ptr(),
                                                ws.numel(), tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_chain_bwd')
         return dcan, dray, dimg
@@ -368,7 +393,7 @@ class HotPath:
         o_s.view_mask = None
         fd = torch.empty(scene.B, rn, rays.fdn, dtype=torch.float32, device=self.device) if want_fine_depth else None
         w = self.wc if level == 'coarse' else self.wf
-        _lib.check(self.L.gnr_render_tail_fwd_train(C.byref(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(), C.byref(o_s),
+        _lib.check(self.L.gnr_render_tail_fwd_train(self._sc(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(), C.byref(o_s),
                                                     fd.data_ptr() if want_fine_depth else None, ws.data_ptr(), ws.numel(),
                                                     tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_tail_fwd_train')
         o['ray_mask'] = o['ray_mask'].bool()
@@ -400,7 +425,7 @@ class HotPath:
             self._gd_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         _lib.check(self.L.gnr_geo_dual_bwd(canon.data_ptr(), stats.data_ptr(), pts.data_ptr(), gamma.data_ptr(), gbar.data_ptr(),
                                            gdbar.data_ptr(), dstats.data_ptr(), dcan.data_ptr(), P, self._gd_scratch.data_ptr(),
-                                           self._gd_scratch.numel(), self._stream()), 'gnr_geo_dual_bwd')
+                                           self._gd_scratch.numel(), self.options, self._stream()), 'gnr_geo_dual_bwd')
         return dstats, dcan
 
     def composite_bwd(self, level, sdf, grad, col, depth, qdir, dpix, ddepth=None, wgerr=None, dalpha=None, dhit=None):
@@ -433,7 +458,7 @@ class HotPath:
         scr = self._scratch('tail', self.L.gnr_ray_tail_dual_bwd_workspace_bytes())
         _lib.check(self.L.gnr_ray_tail_dual_bwd(w.data_ptr(), g.data_ptr(), gd.data_ptr(), a.data_ptr(), nvalid.data_ptr(),
                                                 gbar.data_ptr(), gdbar.data_ptr(), dtail.data_ptr(), R, dn, scr.data_ptr(), scr.numel(),
-                                                self._stream()), 'gnr_ray_tail_dual_bwd')
+                                                self.options, self._stream()), 'gnr_ray_tail_dual_bwd')
         return gbar, gdbar, dtail
 
     def release_training_workspaces(self):
@@ -453,7 +478,7 @@ class HotPath:
         recorded on the launch stream inside the library."""
         scene, keep, ws = self.prepare(ref, res)
         ms = C.c_float(0)
-        _lib.check(self.L.gnr_time_chain_kernel(C.byref(scene), res, self.wc.data_ptr(), ws.data_ptr(), ws.numel(),
+        _lib.check(self.L.gnr_time_chain_kernel(self._sc(scene), res, self.wc.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 iters, C.byref(ms), self._stream()), 'gnr_time_chain_kernel')
         return ms.value
 

@@ -383,7 +383,22 @@ class NeuralRayRenderer(nn.Module):
         elif getattr(self, '_hot_ver', None) != ver:
             self._repack_on_device(with_bwd=False)
             self._hot_ver = ver
+        if self.__dict__.get('_hot_option_bits') is not None:
+            self._hot.options = self._hot_option_bits
         return self._hot
+
+    def set_hot_option(self, name, on=True):
+        """A per-call option of the HIP path (include/gnr.h GNR_OPT_*; hotpath.HotPath.set_option) for every call THIS module makes --
+        kept here because the HotPath is rebuilt whenever the parameters move (`.to()`, load_state_dict); -> previous setting."""
+        from . import _lib
+        bit = _lib.OPTIONS[name]
+        bits = self.__dict__.get('_hot_option_bits')
+        if bits is None:
+            bits = self._hot.options if self._hot is not None else HotPath.default_options
+        self.__dict__['_hot_option_bits'] = (bits | bit) if on else (bits & ~bit)
+        if self._hot is not None:
+            self._hot.options = self._hot_option_bits
+        return bool(bits & bit)
 
     def _upload(self, name, host_tensor, dev):
         """Host tensor -> device through a persistent pinned staging buffer (one per name): `x.pin_memory()` every step
@@ -421,6 +436,8 @@ class NeuralRayRenderer(nn.Module):
                 or getattr(self._hot, 'can_dev', None) is None or getattr(self, '_bwd_ver', None) != ver:
             self._repack_on_device(with_bwd=True)
         self._hot_ver = self._bwd_ver = ver
+        if self.__dict__.get('_hot_option_bits') is not None:
+            self._hot.options = self._hot_option_bits
         return self._hot
 
     def _train_prep(self, ref_imgs_info, rn=0):

@@ -46,8 +46,13 @@ def exp_decay_lr(step, lr_init=1e-4, decay_step=100000, decay_rate=0.5, lr_min=1
 class Trainer:
     def __init__(self, net, lr_cfg=None, batched=True, log_every=1, flat_exchange='auto', reproducible_feature_grads=False):
         """reproducible_feature_grads: the path's feature-map gradients (the gradients it hands the 2D backbones) through 64-bit
-        fixed-point adds instead of float atomics (include/gnr.h gnr_feature_grad_mode): with it every gradient the HIP path produces is
-        the same bits from run to run, as on the reference's CPU path; process-wide, ~0.7 % of the step.
+        fixed-point adds instead of float sums in arrival order (include/gnr.h GNR_OPT_FEATURE_GRAD_FIXED): with it every gradient the HIP
+        path produces is the same bits from run to run, as on the reference's CPU path.  A per-call option of THIS net's calls (set either
+        way here: another Trainer in the process is not affected, and a later Trainer with False is not left in the fixed-point mode).
+        A backward whose status words carry GNR_STATUS_LOST_PARTNER (include/gnr.h: a wavefront of the view kernels gave up waiting for its
+        partner -- the gradients are garbage) does not reach the parameters: the flag is tested ON THE DEVICE (no host wait), joins the
+        gradient exchange, and the fused Adam step skips itself on it (`found_inf`, the mechanism of torch's GradScaler);
+        `skipped_steps()` counts them.
         log_every: the loss terms leave the device every log_every-th step only (the reference writes its log every
         `train_log_step` = 20 steps, trainer.py:31,159; what it reads back EVERY step is the loss shown in its progress bar, :190).  With
         log_every = 1 every step() returns floats -- and ends in a device-to-host copy the host waits for, so the queue of the next step
@@ -55,16 +60,20 @@ class Trainer:
         of the latest step stay on the device until last_log() asks for them."""
         self.net = net
         self.batched = batched
-        if reproducible_feature_grads:
-            from . import _lib
-            _lib.lib().gnr_feature_grad_mode(1)
+        nr = getattr(net, 'nr_net', None)
+        if hasattr(nr, 'set_hot_option'):
+            nr.set_hot_option('feature_grad_fixed', bool(reproducible_feature_grads))
+        self._bad = None                                   # device bool: a backward of the current step flagged GNR_STATUS_LOST_PARTNER
+        self._skipped = None                               # device counter of skipped optimiser steps
         self.log_every = max(int(log_every), 1)
         self._pending = None
         self.flat_exchange = flat_exchange
         self._flat = self._views = None
         self.lr_cfg = lr_cfg or {}
         self.params = [p for p in net.parameters()]
-        self.optimizer = torch.optim.Adam(self.params, lr=1e-3)            # lr_common_manager.py:9-13
+        # lr_common_manager.py:9-13.  Fused on the GPU: one multi-tensor kernel, and the only Adam that takes the device-side skip flag
+        self._fused = bool(self.params) and all(p.is_cuda for p in self.params)
+        self.optimizer = torch.optim.Adam(self.params, lr=1e-3, **({'fused': True} if self._fused else {}))
         self.step_id = 0
 
     def _mode_modules(self):
@@ -78,14 +87,26 @@ class Trainer:
                     ms.append(getattr(nr, n))
         return ms
 
+    def _note_backward_status(self):
+        """After a backward: OR the lost-partner bit of the HIP path's status words into the step's flag -- on the device, nothing waits."""
+        hot = getattr(getattr(self.net, 'nr_net', None), '_hot', None)
+        if hot is None or getattr(hot, '_prepared', None) is None:
+            return
+        bad = (hot.status_words() & 16).ne(0).any()
+        self._bad = bad if self._bad is None else (self._bad | bad)
+
+    def skipped_steps(self):
+        """Optimiser steps skipped because a backward reported GNR_STATUS_LOST_PARTNER (one device-to-host copy)."""
+        return 0 if self._skipped is None else int(self._skipped.item())
+
     def _flat_views(self):
-        """One persistent flat fp32 buffer for the gradient exchange (all parameters + one scene counter) and the per-parameter views
+        """One persistent flat fp32 buffer for the gradient exchange (all parameters + a bad-step flag + one scene counter) and the per-parameter views
         into it, made once: a step then moves the gradients in with ONE multi-tensor copy and out with one (no 346-way torch.cat,
         no per-tensor reshape / split on the host every step)."""
         if self._flat is None or self._flat.device != self.params[0].device:
             n = sum(p.numel() for p in self.params)
-            self._flat = torch.zeros(n + 1, dtype=torch.float32, device=self.params[0].device)
-            self._views = [v.view(p.shape) for v, p in zip(torch.split(self._flat[:-1], [p.numel() for p in self.params]), self.params)]
+            self._flat = torch.zeros(n + 2, dtype=torch.float32, device=self.params[0].device)
+            self._views = [v.view(p.shape) for v, p in zip(torch.split(self._flat[:-2], [p.numel() for p in self.params]), self.params)]
         return self._flat, self._views
 
     def _allreduce_grads(self, n_local):
@@ -106,8 +127,14 @@ class Trainer:
         torch._foreach_copy_(views, grads)
         flat[-1:].fill_(float(n_local))                     # (a kernel launch; `flat[-1] = x` is a pageable host-to-device copy the HOST waits for:
                                                             #  measured, tools/dbg/allreduce_blocking.py -- it cost the step its run-ahead, 3 - 4.6 ms)
+        if self._bad is None:
+            flat[-2:-1].zero_()
+        else:
+            flat[-2:-1].copy_(self._bad.to(torch.float32).reshape(1))      # a rank's garbage gradients must not reach ANY rank's parameters
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat[:-1].div_(flat[-1:].clamp(min=1.0))           # (a one-element tensor, broadcast on the device)
+        flat[:-2].div_(flat[-1:].clamp(min=1.0))           # (a one-element tensor, broadcast on the device)
+        if self._bad is not None or self._fused:
+            self._bad = flat[-2:-1].gt(0).reshape(())
         torch._foreach_copy_(grads, views)
         return world
 
@@ -131,21 +158,35 @@ class Trainer:
             # loss launches for the batch, second the per-scene dicts and the per-scene losses
             st = self.net.forward_scenes(datas, stacked=True)
             outs = self.net.forward_scenes(datas) if st is None else None
+        self._bad = None
         if st is not None:
             terms = train_losses_stacked(st, datas)
             losses.total_loss(terms, scenes=len(datas)).backward()
+            self._note_backward_status()
             all_terms = terms
         elif outs is not None:
             all_terms = [train_losses(o, d) for o, d in zip(outs, datas)]
             sum(losses.total_loss(t) for t in all_terms).backward()
+            self._note_backward_status()
         else:
             all_terms = []
             for data in datas:
                 terms = train_losses(self.net(data), data)
                 losses.total_loss(terms).backward()                       # accumulates into .grad
+                self._note_backward_status()                              # (the next scene's prepare zeroes the status words)
                 all_terms.append(terms)
         self._allreduce_grads(len(scenes))
-        self.optimizer.step()
+        if self._bad is not None and self._fused:
+            # the step skips itself on the device when a backward lost a partner wavefront: no host wait, no garbage in the parameters
+            found = self._bad.to(torch.float32).reshape(1)
+            self._skipped = found.clone() if self._skipped is None else self._skipped + found
+            self.optimizer.grad_scale, self.optimizer.found_inf = None, found
+            try:
+                self.optimizer.step()
+            finally:
+                del self.optimizer.grad_scale, self.optimizer.found_inf
+        else:
+            self.optimizer.step()
         self.step_id += 1
         # loss terms leave the device in ONE copy after the whole step is queued (a float() per term and scene would
         # stall the host 80 times in front of the all-reduce and the optimiser)

@@ -5,7 +5,11 @@
  * Plain pointers and sizes only: every `const float*` below is a DEVICE pointer to
  * contiguous fp32 unless the name says `_host`.  `stream` is a hipStream_t passed as void*.
  * All entry points are stateless and return 0 (GNR_OK) or a negative error code; nothing
- * throws across the ABI.  The caller owns every buffer, including the workspace.
+ * throws across the ABI.  The caller owns every buffer, including the workspace.  STATELESS is
+ * meant literally: the library keeps no mutable switch -- what a call computes depends on its arguments alone (the per-call
+ * switches are GnrScene.options / the `options` argument of the entry points without a scene), so two callers, or two streams,
+ * of one process can hold different settings.  (The only process-wide state is the opt-in measurement tooling at the end of
+ * this header, which adds event brackets around launches and changes nothing they compute.)
  *
  * Typical call sequence (what graspnerf_amd/renderer.py does through ctypes):
  *   gnr_pack_weights(canonical_host, packed_host)         once per load_state_dict, per level
@@ -45,7 +49,38 @@ typedef struct GnrScene {
                                  gnr_pack_vis_decoder_bwd) and the chain runs the fourth decoder branch; the gradient
                                  blobs of the *_bwd entry points then have gnr_canonical_weights_floats() +
                                  gnr_canonical_vis_floats() floats; 0 -> configs/nrvgn_sdf.yaml                          */
+    unsigned options;         /* per-call switches, an OR of GNR_OPT_* below; 0 = the product path.  Unknown bits: GNR_ERR_ARG   */
 } GnrScene;
+
+/* ---- per-call options (GnrScene.options; `options` of gnr_ray_tail_dual_bwd / gnr_geo_dual_bwd) -------------
+ * Product switches:
+ *   GNR_OPT_FEATURE_GRAD_FIXED  the feature-map gradients of this call (gnr_depth_mean_bwd, gnr_sample_volume_bwd,
+ *                               gnr_render_chain_bwd) are BIT-REPRODUCIBLE: 64-bit fixed-point adds instead of float sums in
+ *                               arrival order (see "backward twins" below); costs twice the atomic traffic.
+ * Measurement / test switches (same results to rounding unless stated):
+ *   GNR_OPT_FP32_CHAIN          every chain launch of the call -- forward, training forward and the backward's view kernels -- runs
+ *                               its fp32-input-MFMA instantiation (what the range guard falls back to); the pair kernels are skipped
+ *   GNR_OPT_VIEW1_ONE_WAVEFRONT / GNR_OPT_VIEW2_ONE_WAVEFRONT   the backward of the first / second view loop as one wavefront per tile
+ *                               (k_view1_bwd / k_view2_bwd) instead of a compute wavefront and its partner (k_view*_bwd_pw)
+ *   GNR_OPT_DIRECT_SCATTER      the feature-map gradient of k_view1_bwd_pw as direct float atomics instead of the binned scatter
+ *                               (csrc/gnr_bwd_scatter.inc: rows parked in HBM, summed per feature-map pixel first)
+ *   GNR_OPT_RAY_ORDER_MORTON    the inference render passes traverse a scene's rays in the Morton order of their pixels (internal
+ *                               layout only; every array of the ABI keeps the caller's ray order, results are bit-identical)
+ *   GNR_OPT_GEO_DUAL_FP32       the per-point half of gnr_geo_dual_bwd as fp32 FMAs, one lane per point, instead of the fp16-pair chain
+ *   GNR_OPT_POISON_PARTIALS     the partial-gradient buffers are filled with NaN patterns before the kernels run (an entry no wavefront
+ *                               stores would show in the reduced gradient)
+ *   GNR_OPT_TEST_LOSE_PARTNER   (tests) the partner wavefronts of k_view1_bwd_pw / k_view2_bwd_pw return at once: the compute wavefronts'
+ *                               bounded waits give up, the call's gradients are garbage and bit 4 of gnr_range_status says so */
+#define GNR_OPT_FP32_CHAIN 0x001u
+#define GNR_OPT_FEATURE_GRAD_FIXED 0x002u
+#define GNR_OPT_VIEW1_ONE_WAVEFRONT 0x004u
+#define GNR_OPT_VIEW2_ONE_WAVEFRONT 0x008u
+#define GNR_OPT_RAY_ORDER_MORTON 0x010u
+#define GNR_OPT_POISON_PARTIALS 0x020u
+#define GNR_OPT_DIRECT_SCATTER 0x040u
+#define GNR_OPT_GEO_DUAL_FP32 0x080u
+#define GNR_OPT_TEST_LOSE_PARTNER 0x100u
+#define GNR_OPT_ALL 0x1ffu
 
 /* Query rays of B scenes.  Replaces the `que_imgs_info` dict (imgs_info.py:126-135). */
 typedef struct GnrRays {
@@ -144,22 +179,26 @@ int gnr_prepare(const GnrScene* scene, void* workspace, size_t workspace_bytes, 
  * gnr_prepare, activations and cross-view statistics in the kernel) and is followed by its fp32-input-MFMA twin, which returns
  * immediately unless the watch tripped and otherwise recomputes the launch: out-of-range scenes get the fp32 kernel's values,
  * in-range scenes pay ~5 us per chain launch, and no call synchronises with the host.
- * gnr_range_status reads the watch word of the last gnr_prepare on this workspace (synchronises `stream`):
+ * gnr_range_status reads the status words of the last gnr_prepare on this workspace (synchronises `stream`):
  *   bit 0: a feature-map value >= 6e4 in magnitude or not finite;  bit 1: an activation / statistic beyond the fp16 range (k_chain), or a
  *   non-finite value in the matrix-core tail of the per-ray kernel (an operand or a per-ray weight beyond the fp16 range: that launch and the
  *   later per-ray launches on the prepared scene are recomputed by their fp32 instantiation);
  *   bit 2: a weight beyond the fp16 range (gnr_pack_weights marks such a blob instead of refusing it);
- *   bit 3: (backward, gnr_feature_grad_mode(1) only) a feature-map gradient contribution was clamped to the fixed-point range.
+ *   bit 3: (backward, GNR_OPT_FEATURE_GRAD_FIXED only) a feature-map gradient contribution was clamped to the fixed-point range;
+ *   bit 4: (backward) GNR_STATUS_LOST_PARTNER -- a wavefront of k_view1_bwd_pw / k_view2_bwd_pw waited ~2^22 polls for its partner and
+ *          gave up: THE GRADIENTS OF THAT BACKWARD CALL ARE INVALID.  The entry points still return GNR_OK (nothing synchronises with the
+ *          host); a training loop must not apply such a step (graspnerf_amd/trainer.py skips the optimiser step on the device).
  * Bits 0 and 2 hold for every launch on the prepared scene (the pair kernel then returns at once and the twin computes the launch);
  * bit 1 is watched per launch slot (volume, coarse pass, fine pass, the training forwards), so a scene whose coarse pass tripped it
  * does not pay the recomputation on its volume or fine pass; the status word is the OR over the slots.
- * gnr_force_fp32_chain(1) makes every chain launch run the fp32-MFMA kernel (tests, measurements); returns the old setting. */
+ * The backward twins follow the same guard (round 6): gnr_sample_volume_bwd / gnr_render_chain_bwd launch their fp16-pair view kernels
+ * and, behind each, the fp32-input-MFMA instantiation; the former return at once when bits 0 / 2 of the scene or bit 1 of the pass's
+ * training forward are set, the latter unless -- a range-tripped pass gets bitwise the gradients of GNR_OPT_FP32_CHAIN.
+ * gnr_status_words_offset: byte offset of the 64 status words (unsigned) inside the workspace, for callers that test them on the device
+ * (OR of the words & GNR_STATUS_LOST_PARTNER) instead of synchronising. */
+#define GNR_STATUS_LOST_PARTNER 16u
 int gnr_range_status(const GnrScene* scene, const void* workspace, size_t workspace_bytes, unsigned* flags_out, void* stream);
-int gnr_force_fp32_chain(int on);
-/* gnr_debug_ray_order(1): the inference render passes traverse a scene's rays in the Morton order of their pixels (internal
- * layout only: every array of the ABI keeps the caller's ray order, results are bit-identical).  Off by default: measured, it does
- * not change the render launches' time (tools/ab_ray_order.py).  Returns the old setting. */
-int gnr_debug_ray_order(int on);
+size_t gnr_status_words_offset(const GnrScene* scene);
 
 /* sample_volume (renderer.py:164-199), volume_type [sdf]:
  *   sdf_out[b,x,y,z] for voxel centre bbox_min[b] + ((x,y,z)+.5)*(0.3/res).
@@ -235,7 +274,8 @@ int gnr_conv3d_same(const float* x, const float* w, const float* bias, float* y,
  * weight that happens to be 0.0 still has a gradient) and writes gnr_conv3d_tap_mask_words(Cin, Cout) uint32 words: per (16 input
  * channels, 16 output channels) block the set of taps that exist.  The _masked entry points are gnr_conv3d_same /
  * gnr_conv3d_same_bwd_weight that skip the absent taps (mask == NULL: dense, the same as the plain entry points). */
-int gnr_debug_conv3d_first_gen(int on);   /* tests: K = 3 calls through the first-generation kernels (the > 32 M voxel path); returns the previous setting */
+#define GNR_CONV3D_FIRST_GEN 0x100   /* tests: OR into `mode` (gnr_conv3d_same*) / `K` (gnr_conv3d_same_bwd_weight*): the K = 3 call runs the
+                                        first-generation kernels (the > 32 M voxel path) */
 size_t gnr_conv3d_tap_mask_words(int Cin, int Cout);
 int gnr_conv3d_tap_mask(const float* pattern, unsigned* mask, int Cin, int Cout, int K, void* stream);
 int gnr_conv3d_same_masked(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int D, int H, int W,
@@ -278,14 +318,14 @@ int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, i
  * double) into d_canonical / dtail.  Two calls on the same inputs return the same bits (the reference's CPU backward is
  * deterministic as well: ibrnet.py:497-504 + autograd).  The feature-map gradients (d_ray_feats, d_img_feats: a bilinear
  * scatter, like ATen's grid_sampler backward on a GPU) are accumulated with float atomics by default: their low bits depend on
- * the arrival order.  gnr_feature_grad_mode(1) makes them BIT-REPRODUCIBLE too: every contribution is rounded once to a multiple
- * of a launch-wide power-of-two quantum (2^-28 of the launch's largest upstream gradient, found by an order-independent maximum)
- * and added as a 64-bit integer (integer adds commute); a contribution more than 2^14 times the upstream maximum is clamped and
- * raises bit 3 of gnr_range_status.  Costs twice the atomic traffic of the float path.  Process-wide; returns the old mode.
+ * the arrival order.  GNR_OPT_FEATURE_GRAD_FIXED (GnrScene.options of the backward call) makes them BIT-REPRODUCIBLE too: every
+ * contribution is rounded once to a multiple of a launch-wide power-of-two quantum (2^-28 of the launch's largest upstream gradient,
+ * found by an order-independent maximum) and added as a 64-bit integer (integer adds commute); a contribution more than 2^14 times the
+ * upstream maximum is clamped and raises bit 3 of gnr_range_status.  Costs twice the atomic traffic of the float path.
  * Every entry point that produces feature-map gradients honours it (gnr_depth_mean_bwd, gnr_sample_volume_bwd,
- * gnr_render_chain_bwd); their workspaces are sized for either mode.
- * gnr_debug_poison_partials(1) fills the partial buffers with NaN patterns before the kernels run (tests: an entry no
- * wavefront stores would show in the reduced gradient); returns the old setting.
+ * gnr_render_chain_bwd); their workspaces are sized for either mode.  In the float mode the view kernels' scatter is BINNED (round 6,
+ * csrc/gnr_bwd_scatter.inc): the per-(view, point) rows are parked in the training workspace and summed per feature-map pixel before
+ * anything is added atomically (786 M -> ~40 M atomic dwords per 8-scene volume launch).
  * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
  * consumed by DepthLoss, loss.py:87-144).  sample_volume and the per-view chain of the render passes follow below;
  * the render path's twin pairs (per-view chain, per-ray tail, compositing) follow further down.
@@ -296,17 +336,6 @@ int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, i
  *                         workspace (feature maps in channel-last form) and a separate scratch buffer of
  *                         gnr_depth_mean_bwd_workspace_bytes(scene) for the partial parameter gradients and the
  *                         channel-last feature gradient (required, also with d_ray_feats == NULL).            */
-int gnr_debug_poison_partials(int on);
-int gnr_feature_grad_mode(int mode);       /* 0: float atomics (default); 1: 64-bit fixed point, bit-reproducible */
-/* Measurement / test switch: the backward of the first view loop as k_view1_bwd (one wavefront per tile, 0) or as k_view1_bwd_pw
- * (a compute wavefront and its partner per tile, 1: the default).  Same outputs either way; returns the old setting. */
-int gnr_debug_view1_partner(int on);
-/* Measurement / test switch: the feature-map gradient of k_view1_bwd_pw as the binned scatter (1: the default; csrc/gnr_bwd_scatter.inc:
- * rows parked in HBM, summed per feature-map pixel before anything is added atomically) or as direct float atomics (0). */
-int gnr_debug_scatter_bins(int on);
-/* Measurement / test switch: the per-point half of gnr_geo_dual_bwd on the f16 matrix cores (1: the default) or as fp32 FMAs with one
- * lane per point (0).  Same outputs to rounding; returns the old setting. */
-int gnr_debug_geo_dual_matrix_cores(int on);
 int gnr_packed_bwd_floats(void);
 int gnr_pack_weights_bwd(const float* canonical_host, float* packed_bwd_host);
 size_t gnr_depth_mean_bwd_workspace_bytes(const GnrScene* scene);
@@ -381,14 +410,16 @@ int gnr_geo_dual_fwd(const float* canonical_dev, const float* stats, const float
  * gnr_geo_dual_bwd_workspace_bytes(P) bytes. */
 size_t gnr_geo_dual_bwd_workspace_bytes(int P);
 int gnr_geo_dual_bwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, const float* gbar,
-                     const float* gdbar, float* dstats, float* d_canonical, int P, void* scratch, size_t scratch_bytes, void* stream);
+                     const float* gdbar, float* dstats, float* d_canonical, int P, void* scratch, size_t scratch_bytes, unsigned options,
+                     void* stream);
 /* Backward of NeuS alpha + compositing (aggregate_net.py:105-121, render_ops.py:72-80, renderer.py:110-123) for a flat list
  * of rays, forward values taken from the tensors the forward wrote: sdf [nrays*dn], grad, col [nrays*dn,3], depth
  * [nrays*dn], qdir [nrays,3].  Upstream: dpix [nrays,3]; ddepth [nrays], wgerr [nrays] (d L / d sum_k (|grad_k|-1)^2 of the
  * ray), dalpha, dhit [nrays*dn] may be null.  Out: a_out = dL/d sdf, gamma_out = dL/d grad (the upstreams of
  * gnr_ray_tail_dual_bwd), dcol_out, dvar_out[0] = dL/d deviation_network.variance (all overwritten).
  * scratch: gnr_composite_bwd_workspace_bytes(nrays) / gnr_ray_tail_dual_bwd_workspace_bytes() bytes, caller-owned (the
- * per-wavefront partial sums of the parameter gradients).                                                            */
+ * per-wavefront partial sums of the parameter gradients).  `options` of gnr_ray_tail_dual_bwd / gnr_geo_dual_bwd: GNR_OPT_* (these
+ * entry points take no GnrScene): GNR_OPT_POISON_PARTIALS, and GNR_OPT_GEO_DUAL_FP32 for gnr_geo_dual_bwd.                 */
 size_t gnr_composite_bwd_workspace_bytes(int nrays);
 int gnr_composite_bwd(const float* level_weights, const float* sdf, const float* grad, const float* col, const float* depth,
                       const float* qdir, const float* dpix, const float* ddepth, const float* wgerr, const float* dalpha,
@@ -397,7 +428,7 @@ int gnr_composite_bwd(const float* level_weights, const float* sdf, const float*
 size_t gnr_ray_tail_dual_bwd_workspace_bytes(void);
 int gnr_ray_tail_dual_bwd(const float* level_weights, const float* g, const float* gd, const float* a, const float* nvalid,
                           float* gbar, float* gdbar, float* dtail, int nrays, int dn, void* scratch, size_t scratch_bytes,
-                          void* stream);
+                          unsigned options, void* stream);
 
 /* ---- host helper ---------------------------------------------------------------------------
  * The first k entries of torch.randperm(n) on the CPU generator, bit-exact, in O(k + n/624) instead of n random-access swaps:

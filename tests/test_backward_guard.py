@@ -1,0 +1,169 @@
+"""Round 6: what the backward says when something went wrong (pytest -m gpu, through the C ABI).
+
+* Range guard of the backward twins (include/gnr.h, csrc/gnr_bwd.inc BwdGuard).  Since round 5 the view kernels of the backward
+  recompute the forward and run their dX chains on fp16 pairs.  A pass whose training forward left the pair range (a feature of
+  1e5, features x3000: cross-view statistics ~1e7, a weight without a pair) gets its gradients from the fp32-input-MFMA
+  instantiations launched behind the pair kernels: finite everywhere and BITWISE the gradients of GNR_OPT_FP32_CHAIN (parameter
+  gradients are deterministic; the feature-map gradients are compared in the bit-reproducible mode).  An in-range pass leaves the
+  twins idle: same bits as a run without them would give, status 0.
+* GNR_STATUS_LOST_PARTNER: a partner wavefront that never answers (GNR_OPT_TEST_LOSE_PARTNER makes the partners return at once) must
+  not hang the device and must not go unnoticed: bit 4 of gnr_range_status is set, and graspnerf_amd.trainer.Trainer does not let
+  the step reach the parameters (fused Adam skipped on the device, no host wait)."""
+import numpy as np
+import pytest
+import torch
+
+from graspnerf_amd import weights, _lib
+from graspnerf_amd.synth import make_scene
+
+pytestmark = pytest.mark.gpu
+
+DN, RES = 16, 16
+CFG = {'depth_sample_num': DN, 'fine_depth_sample_num': DN, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+
+
+def _hot(wnp):
+    from graspnerf_amd.hotpath import HotPath
+    hp = HotPath(weights.pack_state_dict(wnp, 'coarse'), weights.pack_state_dict(wnp, 'fine'))
+    can = {lvl: weights.canonical_blob(wnp, lvl) for lvl in ('coarse', 'fine')}
+    hp.set_bwd_weights(weights.pack_bwd(can['coarse']), weights.pack_bwd(can['fine']))
+    hp.can_dev = {lvl: torch.from_numpy(can[lvl]).cuda() for lvl in can}
+    return hp
+
+
+def _backward_of_a_step(hp, ref, que, seed=3):
+    """Training forward + backward of the volume and of one render pass on one scene -> (gradients, status after the backward)."""
+    from graspnerf_amd.hotpath import batch_scenes
+    bref, bque = batch_scenes([(ref, que)])
+    bref = {k: torch.from_numpy(v).cuda() for k, v in bref.items()}
+    bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
+    RN = bq['coords'].shape[1]
+    g = torch.Generator().manual_seed(seed)
+    dvol = torch.randn(1, 1, RES, RES, RES, generator=g).cuda() * 1e-3
+    ds = torch.randn(1, RN * DN, 65, generator=g).cuda() * 1e-2
+    dc = torch.randn(1, RN * DN, 3, generator=g).cuda() * 1e-2
+    prep = hp.prepare(bref, RES, RN, DN)
+    hp.sample_volume_train(bref, RES, prepared=prep)
+    vol_g = hp.sample_volume_bwd(dvol, hp.can_dev['coarse'])
+    _, _, _, ctx = hp.render_chain_train(bq, None, 'coarse', CFG, prep)
+    ren_g = hp.render_chain_bwd(ctx, ds, dc)
+    torch.cuda.synchronize()
+    names = ['volume d_canonical', 'volume d_ray_feats', 'volume d_img_feats', 'render d_canonical', 'render d_ray_feats', 'render d_img_feats']
+    return dict(zip(names, [t.clone() for t in vol_g] + [t.clone() for t in ren_g])), hp.range_status(prep)
+
+
+def _case(name, weights_np):
+    ref, que = make_scene(0, 'cfg1')
+    w = dict(weights_np)
+    if name == 'features x3000':
+        ref = dict(ref, ray_feats=ref['ray_feats'] * np.float32(3000), img_feats=ref['img_feats'] * np.float32(3000))
+        want = 2
+    elif name == 'one feature = 1e5':
+        ref = dict(ref, ray_feats=ref['ray_feats'].copy())
+        ref['ray_feats'][1, 7, 10, 13] = 1e5
+        want = 1
+    elif name == 'a weight without an fp16 pair':
+        k = 'dist_decoder.mean_decoder.0.weight'
+        w[k] = w[k].copy()
+        w[k][3, 5] = 1e5
+        want = 4
+    else:
+        want = 0
+    return w, ref, que, want
+
+
+@pytest.mark.parametrize('case', ['features x3000', 'one feature = 1e5', 'a weight without an fp16 pair'])
+def test_range_tripped_backward_is_the_fp32_backward(case, weights_np):
+    w, ref, que, want = _case(case, weights_np)
+    hp = _hot(w)
+    hp.feature_grad_mode(True)                              # bit-reproducible feature-map gradients: every output can be compared bitwise
+    got, flags = _backward_of_a_step(hp, ref, que)
+    assert flags & want == want, (case, flags)
+    assert flags & _lib.GNR_STATUS_LOST_PARTNER == 0
+    for k, v in got.items():
+        assert bool(torch.isfinite(v).all()), f'{case}: {k} is not finite'
+        assert float(v.abs().max()) > 0, f'{case}: {k} is all zero'
+    prev = hp.force_fp32_chain(True)
+    try:
+        f32, _ = _backward_of_a_step(hp, ref, que)
+    finally:
+        hp.force_fp32_chain(prev)
+    for k in got:
+        assert torch.equal(got[k], f32[k]), (case, k, float((got[k] - f32[k]).abs().max()), float(f32[k].abs().max()))
+
+
+def test_in_range_backward_leaves_the_twins_idle(weights_np):
+    """Status 0, and the pair kernels' gradients sit where they sat before the guard existed: within the twins' tolerance of the
+    fp32-MFMA backward (tests/test_bwd_twins.py checks them against autograd), not bitwise -- i.e. the fp32 twins did NOT run."""
+    w, ref, que, _ = _case('in range', weights_np)
+    hp = _hot(w)
+    hp.feature_grad_mode(True)
+    got, flags = _backward_of_a_step(hp, ref, que)
+    assert flags == 0
+    again, _ = _backward_of_a_step(hp, ref, que)
+    for k in got:
+        assert torch.equal(got[k], again[k]), k
+    prev = hp.force_fp32_chain(True)
+    try:
+        f32, _ = _backward_of_a_step(hp, ref, que)
+    finally:
+        hp.force_fp32_chain(prev)
+    differ = 0
+    for k in got:
+        scale = float(f32[k].abs().max())
+        assert float((got[k] - f32[k]).abs().max()) <= 2e-3 * scale + 1e-12, k
+        differ += int(not torch.equal(got[k], f32[k]))
+    assert differ > 0, 'the pair kernels and the fp32 kernels cannot agree bitwise: the fp32 twins must have run on an in-range pass'
+
+
+def test_a_lost_partner_raises_the_status_bit(weights_np):
+    w, ref, que, _ = _case('in range', weights_np)
+    hp = _hot(w)
+    good, flags = _backward_of_a_step(hp, ref, que)
+    assert flags == 0
+    hp.set_option('test_lose_partner', True)
+    try:
+        _, flags = _backward_of_a_step(hp, ref, que)              # (returns: the bounded waits give up after ~2^22 polls)
+    finally:
+        hp.set_option('test_lose_partner', False)
+    assert flags & _lib.GNR_STATUS_LOST_PARTNER, flags
+    # the next prepare clears the word, and the kernels are none the worse for it
+    again, flags = _backward_of_a_step(hp, ref, que)
+    assert flags == 0
+    for k in good:
+        if 'canonical' in k:
+            assert torch.equal(good[k], again[k]), k
+    # unknown option bits are refused, not ignored
+    hp.options |= 1 << 20
+    try:
+        with pytest.raises(_lib.GnrError):
+            _backward_of_a_step(hp, ref, que)
+    finally:
+        hp.options &= ~(1 << 20)
+
+
+def test_trainer_does_not_apply_a_step_whose_backward_lost_a_partner():
+    from test_train_step import build, scene_data
+    from graspnerf_amd.trainer import Trainer
+    net = build('cuda')
+    net.nr_net.cfg['ray_batch_num'] = 4096
+    tr = Trainer(net, {'lr_init': 1e-3}, log_every=100)
+    datas = [scene_data('cuda', scene_id=i, loss_seed=5 + i) for i in range(2)]
+    torch.manual_seed(1)
+    tr.step(datas)                                                 # a regular step first (Adam state exists)
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    steps_before = tr.optimizer.state[tr.params[0]]['step'].clone()
+    net.nr_net.set_hot_option('test_lose_partner', True)
+    try:
+        tr.step(datas)
+    finally:
+        net.nr_net.set_hot_option('test_lose_partner', False)
+    torch.cuda.synchronize()
+    assert tr.skipped_steps() == 1
+    changed = [k for k, p in net.named_parameters() if not torch.equal(p.detach(), before[k])]
+    assert not changed, (len(changed), changed[:5])
+    assert torch.equal(tr.optimizer.state[tr.params[0]]['step'], steps_before)
+    tr.step(datas)
+    torch.cuda.synchronize()
+    assert tr.skipped_steps() == 1
+    assert any(not torch.equal(p.detach(), before[k]) for k, p in net.named_parameters())

@@ -319,7 +319,7 @@ def test_render_chain_twin_matches_autograd(V, rn, dn, weights_np):
 def test_partner_wavefront_kernels_agree_with_the_single_wavefront_kernels(V, res, B, weights_np):
     """Round 5: the two view loops' backward runs as k_view{1,2}_bwd_pw (a compute wavefront and its partner per tile, two per SIMD);
     the single-wavefront kernels of rounds 1-4 stay in the library (use_vis levels take k_view1_bwd<true>) behind
-    gnr_debug_view1_partner.  Same sums in another order: parameter gradients (per tensor) and feature-map gradients equal to 2e-5
+    GNR_OPT_VIEW{1,2}_ONE_WAVEFRONT.  Same sums in another order: parameter gradients (per tensor) and feature-map gradients equal to 2e-5
     of their scale -- on the volume points and on a render pass, with small (1e-4) and large (1e3) upstream gradients."""
     from graspnerf_amd import _lib
     from graspnerf_amd.hotpath import HotPath, batch_scenes
@@ -339,10 +339,9 @@ def test_partner_wavefront_kernels_agree_with_the_single_wavefront_kernels(V, re
     cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
     bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
     out = {}
-    old = L.gnr_debug_view1_partner(1)
     try:
         for mode in (1, 0):
-            L.gnr_debug_view1_partner(mode)
+            hp.set_option('view1_one_wavefront', not mode); hp.set_option('view2_one_wavefront', not mode)
             hp.sample_volume_train(bref, res)
             vol_g = hp.sample_volume_bwd(dvol, torch.from_numpy(can['coarse']).cuda())
             prep = hp.prepare(bref, 1, rn, dn)
@@ -351,7 +350,7 @@ def test_partner_wavefront_kernels_agree_with_the_single_wavefront_kernels(V, re
             torch.cuda.synchronize()
             out[mode] = [t.clone() for t in vol_g] + [t.clone() for t in ren_g]
     finally:
-        L.gnr_debug_view1_partner(old & 1 if old in (0, 1) else 1)
+        hp.set_option('view1_one_wavefront', False); hp.set_option('view2_one_wavefront', False)
     names = ['volume d_canonical', 'volume d_ray_feats', 'volume d_img_feats', 'render d_canonical', 'render d_ray_feats', 'render d_img_feats']
     for name, a, b in zip(names, out[1], out[0]):
         assert torch.isfinite(a).all() and float(b.abs().max()) > 0, name

@@ -3,7 +3,7 @@ fixed-order reduction in double, no float atomics): two calls on the same inputs
 reference's CPU backward (ibrnet.py:497-504 + autograd, trainer.py:146-158), and every entry of every partial slot is
 stored by exactly one wavefront (the poisoned run would show a missing store as NaN in the reduced gradient).
 The feature-map gradients are a bilinear scatter: with float atomics (the default, like ATen's grid_sampler backward on a GPU) they
-may differ between runs within rounding; with gnr_feature_grad_mode(1) (64-bit fixed-point adds, include/gnr.h) they are equal
+may differ between runs within rounding; with GNR_OPT_FEATURE_GRAD_FIXED (64-bit fixed-point adds, include/gnr.h) they are equal
 bit for bit as well, and equal to the float path's within its own run-to-run spread.  Every test runs in both modes."""
 import numpy as np
 import pytest
@@ -30,9 +30,12 @@ def _feat_close(a, b):
 
 @pytest.fixture(params=['float_atomics', 'fixed_point'])
 def feat_same(request):
-    """Sets the feature-gradient mode; yields the comparison two runs' feature-map gradients must pass."""
-    L = _lib.lib()
-    prev = L.gnr_feature_grad_mode(1 if request.param == 'fixed_point' else 0)
+    """Sets the feature-gradient mode of the HotPath objects the test creates (a per-call option, HotPath.default_options); yields the
+    comparison two runs' feature-map gradients must pass."""
+    from graspnerf_amd.hotpath import HotPath
+    bit = _lib.OPTIONS['feature_grad_fixed']
+    prev = HotPath.default_options
+    HotPath.default_options = (prev | bit) if request.param == 'fixed_point' else (prev & ~bit)
 
     def same(a, b):
         if request.param == 'fixed_point':
@@ -41,17 +44,16 @@ def feat_same(request):
             _feat_close(a, b)
     same.fixed = request.param == 'fixed_point'
     yield same
-    L.gnr_feature_grad_mode(prev)
+    HotPath.default_options = prev
 
 
-def _float_mode(fn):
-    """fn() with the float-atomic scatter (reference values for the fixed-point runs)."""
-    L = _lib.lib()
-    prev = L.gnr_feature_grad_mode(0)
+def _float_mode(hp, fn):
+    """fn() with hp's float scatter (reference values for the fixed-point runs)."""
+    prev = hp.feature_grad_mode(False)
     try:
         return fn()
     finally:
-        L.gnr_feature_grad_mode(prev)
+        hp.feature_grad_mode(prev)
 
 
 def _not_clamped(hp, prep=None):
@@ -61,10 +63,11 @@ def _not_clamped(hp, prep=None):
 @pytest.fixture()
 def poison():
     """Runs the test body with the partial buffers poisoned (NaN patterns) before every backward kernel."""
-    L = _lib.lib()
-    prev = L.gnr_debug_poison_partials(1)
+    from graspnerf_amd.hotpath import HotPath
+    prev = HotPath.default_options
+    HotPath.default_options = prev | _lib.OPTIONS['poison_partials']
     yield
-    L.gnr_debug_poison_partials(prev)
+    HotPath.default_options = prev
 
 
 def _volume_case(hp, V, res, B, H=96, W=128):
@@ -90,7 +93,7 @@ def test_sample_volume_bwd_is_bit_reproducible(V, res, B, H, W, weights_np, pois
         assert torch.equal(r[0], runs[0][0])
         feat_same(r[1], runs[0][1]); feat_same(r[2], runs[0][2])
     if feat_same.fixed:                                            # the same values as the float path, to that path's own spread
-        ref = _float_mode(lambda: hp.sample_volume_bwd(dvol, hp.can_dev['coarse']))
+        ref = _float_mode(hp, lambda: hp.sample_volume_bwd(dvol, hp.can_dev['coarse']))
         assert torch.equal(ref[0], runs[0][0])
         _feat_close(runs[0][1], ref[1]); _feat_close(runs[0][2], ref[2])
         assert float(runs[0][1].abs().max()) > 0 and float(runs[0][2].abs().max()) > 0
@@ -137,7 +140,7 @@ def test_render_pass_bwd_is_bit_reproducible(V, rn, dn, weights_np, poison, feat
         assert torch.equal(p1[k], v) and torch.equal(p2[k], v), k
     feat_same(f1[0], f0[0]); feat_same(f1[1], f0[1]); feat_same(f2[0], f0[0]); feat_same(f2[1], f0[1])
     if feat_same.fixed:
-        pr, fr = _float_mode(once)
+        pr, fr = _float_mode(hp, once)
         assert torch.equal(pr['dcan'], p0['dcan'])
         _feat_close(f0[0], fr[0]); _feat_close(f0[1], fr[1])
         assert float(f0[0].abs().max()) > 0 and float(f0[1].abs().max()) > 0
@@ -160,7 +163,7 @@ def test_depth_mean_bwd_is_bit_reproducible(weights_np, poison, feat_same):
         assert torch.equal(r[0], runs[0][0])
         feat_same(r[1], runs[0][1])
     if feat_same.fixed:
-        ref = _float_mode(lambda: hp.depth_mean_bwd(bref, coords, dmean, 'coarse', prepared=prep))
+        ref = _float_mode(hp, lambda: hp.depth_mean_bwd(bref, coords, dmean, 'coarse', prepared=prep))
         _feat_close(runs[0][1], ref[1])
         assert float(runs[0][1].abs().max()) > 0
         _not_clamped(hp, prep)

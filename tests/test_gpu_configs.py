@@ -285,7 +285,7 @@ def test_use_vis_model_mirror(weights_np, golden):
 @pytest.mark.gpu
 @pytest.mark.parametrize('cfg_name,extra', [('cfg1', {}), ('cfg2', {}), ('cfg1', {'fine_depth_use_all': True}), ('cfg1', {'ray_batch_num': 24})])
 def test_ray_traversal_order_is_invisible(cfg_name, extra, weights_np):
-    """gnr_debug_ray_order(1): the inference render passes lay their internal per-point arrays out in the Morton order of the rays'
+    """GNR_OPT_RAY_ORDER_MORTON: the inference render passes lay their internal per-point arrays out in the Morton order of the rays'
     pixels (k_ray_order) and write every output through the permutation -- all outputs, both levels, the resampling indices and the
     per-chunk eikonal terms equal bit for bit to the caller-order run."""
     from graspnerf_amd import _lib
@@ -296,13 +296,13 @@ def test_ray_traversal_order_is_invisible(cfg_name, extra, weights_np):
     n = 16 if cfg_name == 'cfg1' else 40
     cfg = dict({'depth_sample_num': n, 'fine_depth_sample_num': n}, **extra)
     outs = []
-    prev = L.gnr_debug_ray_order(0)
+    prev = hp.set_option('ray_order_morton', False)
     try:
         for on in (0, 1):
-            L.gnr_debug_ray_order(on)
+            hp.set_option('ray_order_morton', bool(on))
             outs.append(hp.render(bref, bque, cfg, debug=True))
     finally:
-        L.gnr_debug_ray_order(prev)
+        hp.set_option('ray_order_morton', prev)
     torch.cuda.synchronize()
     for lvl in (0, 1):
         for k in outs[0][lvl]:

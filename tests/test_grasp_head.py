@@ -146,7 +146,7 @@ def test_stride2_layers_on_the_hip_path(k, ci, co, n, B):
 @pytest.mark.parametrize('masked', [False, True])
 def test_k3_kernel_generations_agree(masked):
     """The pipelined K = 3 kernels (k_conv3d_s1_k3 / k_conv3d_wgrad_k3: buffer loads, register prefetch) against the first-generation
-    ones they replace (kept for volumes beyond 32-bit byte offsets; gnr_debug_conv3d_first_gen): same products in the same order per
+    ones they replace (kept for volumes beyond 32-bit byte offsets; GNR_CONV3D_FIRST_GEN per call): same products in the same order per
     output, so forward and backward data agree to rounding of the MFMA chain and the weight gradient to 1e-5 of its scale."""
     from graspnerf_amd import backbone, _lib
     L = _lib.lib()
@@ -162,13 +162,13 @@ def test_k3_kernel_generations_agree(masked):
     b = torch.randn(w.shape[0], device='cuda', requires_grad=True)
     res = []
     for gen in (0, 1):
-        prev = L.gnr_debug_conv3d_first_gen(gen)
+        prev, backbone.CONV3D_FIRST_GEN = backbone.CONV3D_FIRST_GEN, bool(gen)
         try:
             y = f()
             g = torch.autograd.grad((y * torch.cos(y.detach())).sum(), (x, w))
             torch.cuda.synchronize()
         finally:
-            L.gnr_debug_conv3d_first_gen(prev)
+            backbone.CONV3D_FIRST_GEN = prev
         res.append((y.detach(), g[0], g[1]))
     for a, c in zip(*res):
         assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max()) + 1e-7

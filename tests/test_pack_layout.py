@@ -343,12 +343,13 @@ def test_training_tail_entry_points_validate_arguments():
     p = 4096                                       # any non-null address: validation happens first
     assert L.gnr_ray_tail_grad_floats() == 1073
     big = 1 << 30
-    assert L.gnr_ray_tail_dual_bwd(None, p, p, p, p, p, p, p, 4, 40, p, big, None) == -1
-    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 40, None, 0, None) == -1         # the partial-sum scratch is required
-    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 2, p, big, None) == -2
-    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 129, p, big, None) == -2
-    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 0, 40, p, big, None) == -2
-    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 40, p, 16, None) == -4            # scratch too small
+    assert L.gnr_ray_tail_dual_bwd(None, p, p, p, p, p, p, p, 4, 40, p, big, 0, None) == -1
+    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 40, None, 0, 0, None) == -1         # the partial-sum scratch is required
+    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 2, p, big, 0, None) == -2
+    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 129, p, big, 0, None) == -2
+    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 0, 40, p, big, 0, None) == -2
+    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 40, p, 16, 0, None) == -4            # scratch too small
+    assert L.gnr_ray_tail_dual_bwd(p, p, p, p, p, p, p, p, 4, 40, p, big, 1 << 20, None) == -1     # unknown option bits
     assert L.gnr_ray_tail_dual_bwd_workspace_bytes() >= 4 * (1024 + 34)
     assert L.gnr_composite_bwd(p, p, p, p, p, p, None, None, None, None, None, p, p, p, p, 4, 40, p, big, None) == -1      # dpix is required
     assert L.gnr_composite_bwd(p, p, p, p, p, p, p, None, None, None, None, p, p, p, p, 4, 129, p, big, None) == -2
@@ -356,8 +357,9 @@ def test_training_tail_entry_points_validate_arguments():
     assert L.gnr_composite_bwd_workspace_bytes(130) >= 3 * 8
     assert L.gnr_geo_dual_fwd(p, p, p, None, p, p, 10, None) == -1
     assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 0, None) == -2
-    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, None, 10, p, 1 << 20, None) == -1
-    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, p, 10, p, 16, None) == -4             # scratch too small
+    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, None, 10, p, 1 << 20, 0, None) == -1
+    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, p, 10, p, 16, 0, None) == -4          # scratch too small
+    assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, p, 10, p, 1 << 30, 1 << 20, None) == -1   # unknown option bits (GNR_OPT_*) are refused, not ignored
     assert L.gnr_geo_dual_bwd_workspace_bytes(10) >= 10 * 288 * 4
     assert b'geo_dual_bwd' in L.gnr_last_error()
 

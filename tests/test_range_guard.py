@@ -8,7 +8,7 @@ twin, which recomputes the launch when the watch tripped.
 * in range: the watch word stays 0 and the fp32 twin leaves the outputs alone;
 * out of range (feature maps x3000: cross-view variances ~1e7; a feature of 1e5; weights that drive an ELU output past 65 504):
   the word is set, every output is finite and equals -- bitwise -- what the fp32-MFMA kernel produces when it is forced to run
-  alone (`gnr_force_fp32_chain`), and sits within the usual tolerance of the fp32 oracle on the same inputs;
+  alone (`GNR_OPT_FP32_CHAIN`), and sits within the usual tolerance of the fp32 oracle on the same inputs;
 * fp64 arbiter: on feature maps x1, x30 and x1e-3 and on decoder / geometry weights x3 the distance of the HIP path from the
   float64 evaluation of the oracle is compared with the distance of the fp32 oracle (the reference's arithmetic on the CPU)
   from it, over all 16^3 voxels (quantiles: single voxels can sit on a bilinear-tap edge where fp32 and fp64 pick

@@ -204,7 +204,7 @@ def test_geometry_dual_kernels(P_, level, weights_np):
 @pytest.mark.parametrize('scale_x,scale_adj', [(1.0, 1e-6), (3e4, 1e3), (1.0, 1e-20)])
 def test_geo_dual_bwd_on_the_matrix_cores_agrees_with_the_fp32_kernel(scale_x, scale_adj, weights_np):
     """gnr_geo_dual_bwd's per-point half as a chained fp16-pair MFMA (k_geo_dual_bwd_pts_mm, the default) against the fp32 FMA kernel
-    (gnr_debug_geo_dual_matrix_cores(0)): d stats and geometry_fc's gradients equal to 2e-5 of their scale for training-step magnitudes
+    (GNR_OPT_GEO_DUAL_FP32): d stats and geometry_fc's gradients equal to 2e-5 of their scale for training-step magnitudes
     and for adjoints of 1e-20 (every operand block is normalised before it is split); with statistics near the fp16 limit (pre-activations
     of 1e5: a hidden unit whose pre-activation rounds to the other side of the ELU's kink changes its derivative from 1 to ~0, in either
     kernel -- tools/ab_geo_dual.py: both are then 1.5e-3 off a float64 evaluation at the worst point, 1.4e-5 rms) they agree point by
@@ -222,13 +222,13 @@ def test_geo_dual_bwd_on_the_matrix_cores_agrees_with_the_fp32_kernel(scale_x, s
     gbar = (rng.standard_normal((Pn, 16)) * scale_adj).astype(np.float32)
     gdbar = (rng.standard_normal((Pn, 16)) * scale_adj * 0.1).astype(np.float32)
     L = _lib.lib()
-    prev = L.gnr_debug_geo_dual_matrix_cores(1)
+    prev = hp.set_option('geo_dual_fp32', False)
     try:
         got = [x.double() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
-        L.gnr_debug_geo_dual_matrix_cores(0)
+        hp.set_option('geo_dual_fp32', True)
         want = [x.double() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
     finally:
-        L.gnr_debug_geo_dual_matrix_cores(prev)
+        hp.set_option('geo_dual_fp32', prev)
     torch.cuda.synchronize()
     for g, w, name in zip(got, want, ('d stats', 'd geometry_fc')):
         assert bool(torch.isfinite(g).all()), name
@@ -260,13 +260,13 @@ def test_geo_dual_bwd_weight_without_an_fp16_pair_falls_back_to_the_fp32_kernel(
     pts = rng.uniform(-0.5, 0.5, (Pn, 3)).astype(np.float32)
     gamma, gbar, gdbar = (rng.standard_normal(sh).astype(np.float32) * 1e-3 for sh in ((Pn, 3), (Pn, 16), (Pn, 16)))
     L = _lib.lib()
-    prev = L.gnr_debug_geo_dual_matrix_cores(1)
+    prev = hp.set_option('geo_dual_fp32', False)
     try:
         got = [x.clone() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
-        L.gnr_debug_geo_dual_matrix_cores(0)
+        hp.set_option('geo_dual_fp32', True)
         want = [x.clone() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
     finally:
-        L.gnr_debug_geo_dual_matrix_cores(prev)
+        hp.set_option('geo_dual_fp32', prev)
     torch.cuda.synchronize()
     for g, x in zip(got, want):
         assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0

@@ -1,5 +1,5 @@
 """A/B of the per-point half of gnr_geo_dual_bwd: k_geo_dual_bwd_pts_mm (16 points as MFMA columns, fp16-pair chain: the default) against
-k_geo_dual_bwd_pts (fp32 FMAs, one lane per point: gnr_debug_geo_dual_matrix_cores(0)) in one process, on P synthetic points with
+k_geo_dual_bwd_pts (fp32 FMAs, one lane per point: GNR_OPT_GEO_DUAL_FP32) in one process, on P synthetic points with
 inputs of the magnitudes of a training step (statistics O(1), adjoints 1e-6) and of a scaled-up one; per-kernel ms (HIP events on the
 launch stream), agreement of d stats / geometry_fc's gradients, and both against a float64 evaluation on the host (a sample of points).
     python tools/ab_geo_dual.py [--points 163840]"""
@@ -51,7 +51,7 @@ for label, sx, sa in (('training-step magnitudes', 1.0, 1e-6), ('statistics x 3e
     dev = [torch.from_numpy(x).cuda() for x in (stats, pts, gamma, gbar, gdbar)]
     res = {}
     for on in (0, 1, 0, 1):
-        L.gnr_debug_geo_dual_matrix_cores(on)
+        hp.set_option('geo_dual_fp32', not on)
         for _ in range(2):
             ds, dc = hp.geo_dual_bwd(canon, *dev)
         torch.cuda.synchronize()
@@ -62,7 +62,7 @@ for label, sx, sa in (('training-step magnitudes', 1.0, 1e-6), ('statistics x 3e
         t = _lib.timing_end()
         res.setdefault(on, {'ms': []})['ms'].append({k.split('@')[0]: round(v[1] / a.iters, 4) for k, v in t.items()})
         res[on]['ds'], res[on]['dc'] = ds.double().cpu().numpy(), dc.double().cpu().numpy()
-    L.gnr_debug_geo_dual_matrix_cores(1)
+    hp.set_option('geo_dual_fp32', False)
     idx = rng.choice(P, 4096, replace=False)
     ref = f64_reference(stats, pts, gamma, gbar, gdbar, idx)
     sc = np.abs(ref).max()

@@ -1,5 +1,5 @@
 """A/B of the Morton traversal order of the inference render passes' rays (csrc/gnr_kernels.hip k_ray_order) in ONE process:
-gnr_debug_ray_order(0 / 1) around the same B = 32 forward step; per-kernel ms (HIP events on the launch stream) and a
+GNR_OPT_RAY_ORDER_MORTON off / on around the same B = 32 forward step; per-kernel ms (HIP events on the launch stream) and a
 bit-equality check of every render output between the two orders.   python tools/ab_ray_order.py [--batch 32] [--steps 20]"""
 import argparse, json, os, sys
 import numpy as np, torch
@@ -30,7 +30,7 @@ def step():
 res, outs = {}, {}
 for rep in range(2):
     for on in (0, 1):
-        L.gnr_debug_ray_order(on)
+        hp.set_option('ray_order_morton', bool(on))
         for _ in range(3):
             o = step()
         torch.cuda.synchronize()
@@ -42,7 +42,7 @@ for rep in range(2):
         t = _lib.timing_end()
         res[(rep, on)] = {k: round(v[1] / a.steps, 4) for k, v in t.items() if k.startswith(('k_chain.render', 'k_ray.render', 'k_ray_order', 'k_points_rays'))}
         print('sorted' if on else 'caller order', 'run', rep, res[(rep, on)], 'render-side total', round(sum(res[(rep, on)].values()), 4), flush=True)
-L.gnr_debug_ray_order(0)                                  # the library default
+hp.set_option('ray_order_morton', False)                   # the default
 same = True
 for lvl in (0, 1):
     for k in outs[0][lvl]:

@@ -63,7 +63,7 @@ prep = hp.prepare(bref, 40, rn, 40)
 hp.sample_volume_train(bref, 40, prepared=prep)
 outs = {}
 for mode in (0, 1):
-    L.gnr_debug_scatter_bins(mode)
+    hp.set_option('direct_scatter', not mode)
     f = lambda: hp.sample_volume_bwd(dvol, can_dev, stages=1)       # stage 1 alone: dS1 stays what the full backward below left
     hp.sample_volume_bwd(dvol, can_dev, stages=0x1f)
     outs[mode] = [x.clone() for x in hp.sample_volume_bwd(dvol, can_dev, stages=1)]
@@ -86,7 +86,7 @@ dstats = torch.randn(B, rn * 40, 65, device='cuda') * 1e-3
 dcolors = torch.randn(B, rn * 40, 3, device='cuda') * 1e-3
 outs = {}
 for mode in (0, 1):
-    L.gnr_debug_scatter_bins(mode)
+    hp.set_option('direct_scatter', not mode)
     f = lambda: hp.render_chain_bwd(ctx, dstats, dcolors)
     outs[mode] = [x.clone() for x in f()]
     tab = kernel_table(f, a.iters)
@@ -100,7 +100,7 @@ for name, i in (('d_ray_feats', 1), ('d_img_feats', 2)):
     print(f'render {name}: max|direct - binned| / max|direct| = {d / s:.3e}   (max {s:.3e})')
 res['render_d_canonical_equal'] = bool(torch.equal(outs[0][0], outs[1][0]))
 print('render d_canonical equal:', res['render_d_canonical_equal'])
-L.gnr_debug_scatter_bins(1)
+hp.set_option('direct_scatter', False)
 if a.json:
     os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
     json.dump(res, open(a.json, 'w'), indent=1)

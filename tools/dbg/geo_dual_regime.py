@@ -19,11 +19,11 @@ for seed in (11, 12):
     gamma = (rng.standard_normal((Pn, 3)) * 1e3).astype(np.float32)
     gbar = (rng.standard_normal((Pn, 16)) * 1e3).astype(np.float32)
     gdbar = (rng.standard_normal((Pn, 16)) * 1e2).astype(np.float32)
-    L.gnr_debug_geo_dual_matrix_cores(1)
+    hp.set_option('geo_dual_fp32', False)
     got = [x.double() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
-    L.gnr_debug_geo_dual_matrix_cores(0)
+    hp.set_option('geo_dual_fp32', True)
     want = [x.double() for x in hp.geo_dual_bwd(canon, stats, pts, gamma, gbar, gdbar)]
-    L.gnr_debug_geo_dual_matrix_cores(1)
+    hp.set_option('geo_dual_fp32', False)
     for g, w, name in zip(got, want, ('d stats', 'd geometry_fc')):
         d = (g - w).abs()
         print(seed, name, 'max', float(d.max() / w.abs().max()), 'rms rel', float(d.pow(2).mean().sqrt() / w.pow(2).mean().sqrt()),

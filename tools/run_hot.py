@@ -13,12 +13,12 @@ ap.add_argument('--iters', type=int, default=3)
 ap.add_argument('--volume-only', action='store_true')
 ap.add_argument('--sort-rays', action='store_true', help='experiment: visit the rays of a scene in pixel-Morton order')
 ap.add_argument('--distinct', action='store_true', help='32 distinct scenes instead of one scene repeated')
-ap.add_argument('--ray-order', action='store_true', help='gnr_debug_ray_order(1): the library lays the rays out in pixel-Morton order internally (bit-identical outputs)')
+ap.add_argument('--ray-order', action='store_true', help='GNR_OPT_RAY_ORDER_MORTON: the library lays the rays out in pixel-Morton order internally (bit-identical outputs)')
 a = ap.parse_args()
 wnp = dict(np.load(os.path.join(ROOT, 'tests/golden/weights_seed0.npz')))
 hp = HotPath(weights.pack_state_dict(wnp, 'coarse'), weights.pack_state_dict(wnp, 'fine'))
 if a.ray_order:
-    hp.L.gnr_debug_ray_order(1)
+    hp.set_option('ray_order_morton', True)
 one = make_scene(0, 'cfg2', with_query_image=False)
 scenes = [one] * a.batch if (a.batch > 4 and not a.distinct) else [make_scene(i, 'cfg2', with_query_image=False) for i in range(a.batch)]
 bref, bque = batch_scenes(scenes)

@@ -10,8 +10,8 @@ from graspnerf_amd.synth import make_scene
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--scenes', type=int, default=8)
-ap.add_argument('--fixed-point-feature-grads', action='store_true', help='gnr_feature_grad_mode(1): 64-bit fixed-point scatter')
-ap.add_argument('--direct-scatter', action='store_true', help='feature-map gradients as direct float atomics (gnr_debug_scatter_bins(0))')
+ap.add_argument('--fixed-point-feature-grads', action='store_true', help='GNR_OPT_FEATURE_GRAD_FIXED: 64-bit fixed-point scatter')
+ap.add_argument('--direct-scatter', action='store_true', help='feature-map gradients as direct float atomics (GNR_OPT_DIRECT_SCATTER)')
 ap.add_argument('--distinct-scenes', action='store_true', help='scenes 0..n-1 of the synthetic generator instead of n copies of scene 0')
 a = ap.parse_args()
 wnp = dict(np.load(os.path.join(ROOT, 'tests/golden/weights_seed0.npz')))
@@ -20,7 +20,7 @@ can = weights.canonical_blob(wnp, 'coarse')
 hp.set_bwd_weights(weights.pack_bwd(can))
 can_dev = torch.from_numpy(can).cuda()
 hp.feature_grad_mode(a.fixed_point_feature_grads)
-hp.L.gnr_debug_scatter_bins(0 if a.direct_scatter else 1)
+hp.set_option('direct_scatter', a.direct_scatter)
 one = make_scene(0, 'cfg2', with_query_image=False)
 bref, _ = batch_scenes([make_scene(i, 'cfg2', with_query_image=False) for i in range(a.scenes)] if a.distinct_scenes else [one] * a.scenes)
 bref = {k: torch.from_numpy(v).cuda() for k, v in bref.items()}

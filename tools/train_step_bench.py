@@ -18,7 +18,7 @@ ap.add_argument('--coords-rng', default='cpu', choices=['cpu', 'device'], help="
 ap.add_argument('--sync-debug', action='store_true')
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark: let MIOpen search its convolution solvers')
 ap.add_argument('--profile', default=None, help='write torch.profiler tables of one extra step to this file')
-ap.add_argument('--reproducible-feature-grads', action='store_true', help='feature-map gradients through 64-bit fixed-point adds (gnr_feature_grad_mode(1))')
+ap.add_argument('--reproducible-feature-grads', action='store_true', help='feature-map gradients through 64-bit fixed-point adds (GNR_OPT_FEATURE_GRAD_FIXED)')
 ap.add_argument('--cpus', type=int, default=0, help='pin the process to its first N allowed CPUs before torch is imported (0: leave the affinity alone)')
 ap.add_argument('--flat-exchange-steps', type=int, default=0, help='after the timed steps: this many further steps with the N > 1 gradient exchange (flat buffer + RCCL all-reduce on a one-rank group)')
 a = ap.parse_args()
