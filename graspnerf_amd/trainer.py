@@ -178,7 +178,7 @@ class Trainer:
         self._allreduce_grads(len(scenes))
         if self._bad is not None and self._fused:
             # the step skips itself on the device when a backward lost a partner wavefront: no host wait, no garbage in the parameters
-            found = self._bad.to(torch.float32).reshape(1)
+            found = self._bad.to(torch.float32).reshape(())              # (0-dim, as torch's GradScaler hands it over)
             self._skipped = found.clone() if self._skipped is None else self._skipped + found
             self.optimizer.grad_scale, self.optimizer.found_inf = None, found
             try:
@@ -187,6 +187,10 @@ class Trainer:
                 del self.optimizer.grad_scale, self.optimizer.found_inf
         else:
             self.optimizer.step()
+        if self._fused:
+            # torch's fused Adam writes the parameters without bumping their version counters (2.10: checked), and the packed copies of
+            # the hot path / the grasp head are refreshed when a version moves (renderer._hot_versions): bump them (no data is touched)
+            torch.autograd.graph.increment_version(self.params)
         self.step_id += 1
         # loss terms leave the device in ONE copy after the whole step is queued (a float() per term and scene would
         # stall the host 80 times in front of the all-reduce and the optimiser)
