@@ -101,6 +101,8 @@ def lib():
     L.gnr_depth_mean_fwd.argtypes = [C.POINTER(GnrScene), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_depth_mean_fwd.restype = C.c_int
+    L.gnr_merge_depths.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.gnr_merge_depths.restype = C.c_int
     L.gnr_render_by_depth_fwd.argtypes = [C.POINTER(GnrScene), C.POINTER(GnrRays), C.c_void_p, C.c_int, C.c_void_p,
                                           C.POINTER(GnrRenderOut), C.c_void_p, C.c_size_t, C.c_void_p]
     L.gnr_render_by_depth_fwd.restype = C.c_int
@@ -217,7 +219,7 @@ def lib():
 
 
 EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pack_weights', 'gnr_pack_vis_decoder', 'gnr_pack_vis_decoder_bwd', 'gnr_canonical_vis_floats', 'gnr_pack_weights_device', 'gnr_pack_weights_bwd_device', 'gnr_pack_vis_decoder_device', 'gnr_pack_vis_decoder_bwd_device', 'gnr_layout_offset', 'gnr_workspace_bytes',
-            'gnr_prepare', 'gnr_range_status', 'gnr_status_words_offset', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
+            'gnr_prepare', 'gnr_range_status', 'gnr_status_words_offset', 'gnr_sample_volume_fwd', 'gnr_debug_volume_chain', 'gnr_depth_mean_fwd', 'gnr_merge_depths', 'gnr_render_by_depth_fwd', 'gnr_render_rays_fwd',
             'gnr_dominant_kernel_name', 'gnr_last_error', 'gnr_time_chain_kernel', 'gnr_head_canonical_floats',
             'gnr_head_packed_floats', 'gnr_pack_grasp_head', 'gnr_grasp_head_workspace_bytes', 'gnr_grasp_head_fwd',
             'gnr_head_last_error', 'gnr_chain_timing_begin', 'gnr_chain_timing_end', 'gnr_timing_begin', 'gnr_timing_begin_only', 'gnr_timing_end', 'gnr_grasp_select_workspace_bytes',

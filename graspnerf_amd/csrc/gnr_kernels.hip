@@ -2054,18 +2054,11 @@ __global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restri
 
 }  // namespace gnr
 
-#ifndef GNR_PROTO_P1
-#define GNR_PROTO_P1 0          // 1: measurement builds with the phase-1 prototype of the 8-point x (view pair) tile (gnr_chain_p1.inc)
-#endif
-#if GNR_PROTO_P1
-#include "gnr_chain_p1.inc"
-#endif
+// (The round-5 phase-1 prototype of the 8-point x (view pair) tile -- measured 6 % slower at three wavefronts per SIMD -- lives with its
+// A/B record under docs/experiments/r05_chain_p1/; its README says how to splice it back in for a measurement build.)
 #define GNR_HD __host__ __device__
 #include "gnr_pack_body.h"      // (k_pack_geo_dual: the packer's pair-block builder on the device)
 #include "gnr_bwd.inc"
 #ifndef GNR_DEV_NO_CAPI         // tools/isa_one.sh: the kernels alone + one explicit instantiation (register / spill checks in seconds)
 #include "gnr_capi.inc"
-#endif
-#if GNR_PROTO_P1
-#include "gnr_chain_p1_capi.inc"
 #endif

@@ -245,6 +245,16 @@ class HotPath:
         o['ray_mask'] = o['ray_mask'].bool()
         return o
 
+    def merge_depths(self, a, b):
+        """sort(cat([a, b], -1), -1) of two per-ray ascending depth lists [..., na], [..., nb] on the device (gnr_merge_depths;
+        renderer.py:145-146, fine_depth_use_all under training)."""
+        a, b = _f32(a, self.device), _f32(b, self.device)
+        assert a.shape[:-1] == b.shape[:-1]
+        out = torch.empty(*a.shape[:-1], a.shape[-1] + b.shape[-1], dtype=torch.float32, device=self.device)
+        _lib.check(self.L.gnr_merge_depths(a.data_ptr(), a.shape[-1], b.data_ptr(), b.shape[-1], out.data_ptr(), a.numel() // a.shape[-1],
+                                           self._stream()), 'gnr_merge_depths')
+        return out
+
     def depth_mean(self, ref, coords, level='coarse', prepared=None):   # noqa: D401
         """predict_mean_for_depth_loss for one level: coords [B,pn,2] (x,y) -> mean [B,V,pn,2]."""
         scene, keep, ws = prepared or self.prepare(ref, 1)

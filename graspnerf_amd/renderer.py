@@ -566,7 +566,7 @@ class NeuralRayRenderer(nn.Module):
             coarse, ex = self._train_pass(hot, prep, q, None, 'coarse', True, ray_feats, img_feats, P)
             fine_depth = ex['fine_depth']
             if self.cfg['fine_depth_use_all']:                              # renderer.py:145-146: coarse and resampled depths together
-                fine_depth = torch.sort(torch.cat([ex['depth'].reshape(B, n, -1), fine_depth], -1), -1)[0]
+                fine_depth = hot.merge_depths(ex['depth'].reshape(B, n, -1), fine_depth)     # (a rank merge of two ascending lists in HIP: no ATen arithmetic on the path)
             fine, _ = self._train_pass(hot, prep, q, fine_depth, 'fine', False, ray_feats, img_feats, P)
             parts.append(dict(self._stacked(coarse, B, n), **self._stacked(fine, B, n, '_fine')))
         st = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]} if len(parts) > 1 else parts[0]

@@ -225,6 +225,11 @@ int gnr_render_rays_fwd(const GnrScene* scene, const GnrRays* rays, const float*
                         const float* fine_depth_in, int* fine_inds_out, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* fine_depth_use_all under training (renderer.py:145-146: the fine pass renders torch.sort(torch.cat([coarse depths, resampled depths])))
+ * -- depth_a [nrays,na], depth_b [nrays,nb], each ascending per ray -> out [nrays,na+nb] ascending (na + nb <= 128).  The inference
+ * entry point gnr_render_rays_fwd does this merge itself (GnrRays.fine_depth_use_all). */
+int gnr_merge_depths(const float* depth_a, int na, const float* depth_b, int nb, float* out, int nrays, void* stream);
+
 /* predict_mean_for_depth_loss (renderer.py:222-266) for one level: bilinear gather of ray_feats at
  * `coords` [B,pn,2] (x,y in full-res pixels, shared by the V views of a scene; the caller keeps the
  * reference's (row,col)-as-(x,y) quirk) + the decoder mean branch.  mean_out [B,V,pn,2]. */

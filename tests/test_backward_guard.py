@@ -167,3 +167,18 @@ def test_trainer_does_not_apply_a_step_whose_backward_lost_a_partner():
     torch.cuda.synchronize()
     assert tr.skipped_steps() == 1
     assert any(not torch.equal(p.detach(), before[k]) for k, p in net.named_parameters())
+
+
+def test_merge_depths_is_sort_of_cat(weights_np):
+    """gnr_merge_depths (fine_depth_use_all under training, renderer.py:145-146): rank merge of two ascending lists per ray."""
+    hp = _hot(weights_np)
+    g = torch.Generator().manual_seed(0)
+    for na, nb, shape in ((16, 16, (2, 37)), (40, 40, (3, 64)), (1, 5, (7,)), (64, 64, (1, 9))):
+        a = torch.sort(torch.rand(*shape, na, generator=g), -1)[0].cuda()
+        b = torch.sort(torch.rand(*shape, nb, generator=g), -1)[0].cuda()
+        b[..., 0] = a[..., 0]                                          # ties
+        b = torch.sort(b, -1)[0]
+        got = hp.merge_depths(a, b)
+        assert torch.equal(got, torch.sort(torch.cat([a, b], -1), -1)[0])
+    with pytest.raises(_lib.GnrError):
+        hp.merge_depths(torch.zeros(2, 100).cuda(), torch.zeros(2, 100).cuda())      # more than 128 samples per ray
