@@ -222,6 +222,40 @@ def pmc_age_commits(d):
         return None
 
 
+_EXTRAS = {'t0': None, 'budget': 300.0, 'skipped': []}
+
+
+def extras_left(name):
+    """True while the optional legs' wall-clock budget (--extras-budget-s) lasts; a leg refused here is named in the line."""
+    if _EXTRAS['t0'] is None:
+        _EXTRAS['t0'] = time.perf_counter()
+    if time.perf_counter() - _EXTRAS['t0'] <= _EXTRAS['budget']:
+        return True
+    _EXTRAS['skipped'].append(name)
+    return False
+
+
+def recorded_bwd_arbiter():
+    """The float64 arbiter of the BACKWARD at the benched training shape (tests/test_bwd_arbiter.py), from the newest committed
+    profiles/*bwd_arbiter*.json: per parameter tensor |HIP gradient - float64| / |torch fp32 autograd - float64|."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*bwd_arbiter*.json')), reverse=True):
+        try:
+            doc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        out = {'source': os.path.relpath(f, ROOT)}
+        for tag, rows in doc.items():
+            r = [x['rms_ratio'] for x in rows.values()]
+            out[tag] = {'tensors': len(r), 'median_rms_ratio': round(float(np.median(r)), 3), 'within_1.5': int(sum(x <= 1.5 for x in r)),
+                        'worst_rms_ratio': round(max(r), 2), 'd_ray_feats': rows.get('d_ray_feats'), 'd_img_feats': rows.get('d_img_feats')}
+        out['note'] = ('8 scenes, 6 views, 40^3 + 512 x (40 + 40): `arithmetic` = prob_embed.0 biased away from its ReLU kink (smooth path, the '
+                       'ratios measure arithmetic), `as packed` = the test weights as they are (rows on the kink flip in every fp32 evaluation); '
+                       'which tensors sit beyond 1.5 and why: tests/test_bwd_arbiter.py')
+        return out
+    return None
+
+
 def recorded_arbiter():
     """The fp64 arbiter at the benched shape (tests/test_range_guard.py::test_fp64_arbiter_benched_shape), from the newest committed
     profiles/*parity_errors*.json that holds its rows: distance of the pair-form path from a float64 evaluation, relative to the fp32
@@ -531,6 +565,9 @@ def train_leg(args, world, rank, dev, dist, sync):
                          'host_cpu_ms_each_step = CPU time of the process (all threads) per step -- what the step needs from the host',
             'max_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 3),
             'loss': {k: round(v, 6) for k, v in log.items() if k.startswith('loss')},
+            'optimizer': 'torch.optim.Adam(fused=True); a step whose backward reports GNR_STATUS_LOST_PARTNER is skipped on the device (found_inf), no host wait',
+            'skipped_steps': tr.skipped_steps(),
+            'bwd_fp64_arbiter_at_benched_shape': recorded_bwd_arbiter(),
             'split_ms_per_step': {'hip_path_kernels': round(path_ms, 3), 'hip_grasp_head_kernels': round(head_ms, 3),
                                   'everything_else': round(dt / K * 1e3 - path_ms - head_ms, 3),
                                   'note': 'HIP events around every libgnr.so launch in two further steps (include/gnr.h gnr_timing_*); '
@@ -542,8 +579,10 @@ def train_leg(args, world, rank, dev, dist, sync):
                          'launches_timed': cnt, 'flops_per_launch': fl, 'traffic': recorded_bwd_traffic(n)[0],
                          'traffic_source': recorded_bwd_traffic(n)[1],
                          'note': 'algorithmic fp32 FLOPs 2*2*(6304+2112+624+264) per (view, point): dX + dW of decoder, prob_embed, '
-                                 'ray_dir_fc, neuray gate; the recomputed forward is not counted.  Next to it the kernel scatters '
-                                 '4 taps x 64 channels x 4 B = 1 KB of feature-map gradient per (view, point) through L2 atomics'},
+                                 'ray_dir_fc, neuray gate; the recomputed forward is not counted.  The feature-map gradient leaves the kernel as one parked '
+                                 '256-byte row per (view, point) (binned scatter, csrc/gnr_bwd_scatter.inc: k_scatter_place / k_scatter_gather sum the rows '
+                                 'per feature-map pixel -- their times are in hip_kernels_ms_per_step); round 5 scattered 4 taps x 64 channels per (view, point) '
+                                 'through L2 atomics from this kernel'},
         }
     # isolated fwd+bwd of the PyTorch parts on the same batch (torch events): what `everything_else` is made of
     if rank == 0:
@@ -568,7 +607,7 @@ def train_leg(args, world, rank, dev, dist, sync):
             rec['allreduce'] = ar
     del tr, net
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_train_2cpu:
+    if rank == 0 and world == 1 and not args.no_train_2cpu and extras_left('train_step.at_2_cpus'):
         rec['at_2_cpus'] = train_at_2_cpus(args, rec['ms_per_step'])
     return rec
 
@@ -670,10 +709,11 @@ def main():
     ap.add_argument('--no-train', action='store_true', help='skip the configs[4] train-step sub-record')
     ap.add_argument('--no-backbones', action='store_true', help='skip the images -> grasps figure')
     ap.add_argument('--no-live-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (N = 1)')
+    ap.add_argument('--extras-budget-s', type=float, default=300.0, help='wall-clock budget of the OPTIONAL legs behind the timed steps (live PMC child passes, the 2-CPU train child, images -> grasps, the fp32-MFMA companion build): a leg that would start beyond it is skipped and the line says so; the timed forward steps, the train_step record and cpu_baseline always run')
     ap.add_argument('--no-f32-build', action='store_true', help='skip timing the fp32-MFMA companion build next to the product')
     ap.add_argument('--train-scenes', type=int, default=8)
     ap.add_argument('--no-train-2cpu', action='store_true', help='skip the train step of a child process pinned to 2 CPUs (the host budget of one rank of an 8-rank node)')
-    ap.add_argument('--train-steps', type=int, default=16, help='timed steps of the train_step record (16: one stalled step moves the mean by 5 %, not 12)')
+    ap.add_argument('--train-steps', type=int, default=16, help='timed steps of the train_step record (16: one stalled step moves the mean by 5 %%, not 12)')
     ap.add_argument('--train-log-step', type=int, default=20, help="the loss terms leave the device every N-th step, the reference's train_log_step (trainer.py:31,159: 20); 1 = a device-to-host copy the host waits for at the end of EVERY step (what the reference's progress bar does, trainer.py:190)")
     ap.add_argument('--train-warmup', type=int, default=24, help='the caching allocators and MIOpen (solvers compiled on their first uses) settle over ~20 steps: profiles/r03_d, r03_f show stalled steps up to the 13th')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (the product); gloo only with --stub-step-ms')
@@ -814,7 +854,8 @@ def main():
         fl_ren = executed_mfma_flops(B * rn * dn, True)
         fl_ren_alg = chain_flops(B * rn * dn, c['V'], render=True)
         achieved = fl_exe / (ms * 1e-3) / 1e12
-        if world == 1 and not args.no_live_pmc and not stub:
+        _EXTRAS['budget'] = args.extras_budget_s
+        if world == 1 and not args.no_live_pmc and not stub and extras_left('live_pmc'):
             live_pmc()                                   # counters of THIS run when the box has the profiler (else the recorded, sha-stamped ones)
         traffic, counters, valu = (None, None, None) if stub else recorded_pmc(B)
         if counters is not None:
@@ -882,13 +923,14 @@ def main():
         rec = train_leg_stub(args, world, rank, dev, dist, sync) if stub else train_leg(args, world, rank, dev, dist, sync)
         if rank == 0:
             out['train_step'] = rec
-    if rank == 0 and world == 1 and not args.no_backbones and not stub:
+    if rank == 0 and world == 1 and not args.no_backbones and not stub and extras_left('with_backbones'):
         out['with_backbones'] = backbone_leg(hp, bref, bque, dev, B, step_ms)
-    if rank == 0 and world == 1 and not args.no_f32_build and not stub:
+    if rank == 0 and world == 1 and not args.no_f32_build and not stub and extras_left('f32_mfma_build'):
         out['f32_mfma_build'] = f32_mfma_build_leg(out['value'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:    # the CPU leg is reported at N=1 only (the other ranks would wait)
         out['cpu_baseline'] = cpu_baseline(wnp)
     if rank == 0:
+        out['optional_legs_skipped_for_time'] = _EXTRAS['skipped']
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
