@@ -90,13 +90,15 @@ def newest_pmc(stamp_key, *sources):
 
 def recorded_bwd_traffic(scenes):
     """HBM-side bytes per launch of k_view1_bwd (volume points, 8 scenes) from the recorded PMC passes, or None."""
-    d, src = newest_pmc('bwd_source_sha16', 'gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc')
+    d, src = newest_pmc('bwd_source_sha16', 'gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_scatter.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc')
     if d is None:
         return None, None
     try:
         ks = d['kernels']                                  # (round 5: the partner-wavefront kernel, a template since the fixed-point mode; before: the single-wavefront kernel)
-        k = ks.get('k_view1_bwd_pw<false>') or ks.get('k_view1_bwd_pw') or ks.get('k_view1_bwd<false>') or ks['k_view1_bwd']
-        return (int(k['hbm_bytes_corrected']), src) if scenes == 8 else (None, None)
+        # (round 6: the binned-scatter instantiation; its rows come back through k_scatter_place / k_scatter_gather, counted with it)
+        k = ks.get('k_view1_bwd_pw<false, true>') or ks.get('k_view1_bwd_pw<false>') or ks.get('k_view1_bwd_pw') or ks.get('k_view1_bwd<false>') or ks['k_view1_bwd']
+        extra = sum(int(ks[n]['hbm_bytes_corrected']) for n in ('k_scatter_place', 'k_scatter_gather') if n in ks and 'hbm_bytes_corrected' in ks[n])
+        return (int(k['hbm_bytes_corrected']) + extra, src) if scenes == 8 else (None, None)
     except KeyError:
         return None, None
 
@@ -146,8 +148,8 @@ def recorded_pmc(batch):
             return o
         counters['other_kernels'] = {n: brief(n, sc) for n, sc in (('k_chain<6, true, false, false, true>', 32), ('k_ray<true>', 32), ('k_ray<false>', 32),
                                                                     ('k_repack_feats', 32))}
-        if d.get('bwd_source_sha16') == source_sha16('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc'):
-            counters['backward_kernels'] = {n: brief(n, 8) for n in d['kernels'] if '_bwd' in n}
+        if d.get('bwd_source_sha16') == source_sha16('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_scatter.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc'):
+            counters['backward_kernels'] = {n: brief(n, 8) for n in d['kernels'] if '_bwd' in n or n.startswith('k_scatter_')}
         counters['pmc_age_commits'] = pmc_age_commits(d)
         return int(k['hbm_bytes_corrected']), counters, valu
     except (KeyError, ValueError, ZeroDivisionError, StopIteration):

@@ -26,7 +26,7 @@ def aggregate(src):
                 k = m.group(1)
                 # the backward passes (pmc/bwd_*: tools/time_volume_bwd.py, 8 scenes) also launch inference kernels at another batch
                 # size: keep only the training kernels from them
-                if os.sep + 'bwd_' in ff and not ('_bwd' in k or re.match(r'k_chain<\d+, (true|false), true,', k)):      # k_chain<V, RENDER, SAVE, ..>
+                if os.sep + 'bwd_' in ff and not ('_bwd' in k or k.startswith('k_scatter_') or re.match(r'k_chain<\d+, (true|false), true,', k)):      # k_chain<V, RENDER, SAVE, ..>
                     continue
                 acc[k][cname].append(v)
     res = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
@@ -38,7 +38,7 @@ def aggregate(src):
 
 import hashlib
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'graspnerf_amd', 'csrc')
-BWD_SOURCES = ('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc')
+BWD_SOURCES = ('gnr_kernels.hip', 'gnr_bwd.inc', 'gnr_bwd_scatter.inc', 'gnr_bwd_view1_pw.inc', 'gnr_bwd_view2_pw.inc', 'gnr_bwd_geo_dual_mm.inc')
 
 
 def sha16(*names):
