@@ -713,6 +713,9 @@ constexpr int SW = 20;     // per-view state width: X[9] E[8] gate m rgb  /  H2[
 #ifndef GNR_TWO_QUEUES
 #define GNR_TWO_QUEUES 0
 #endif
+#ifndef GNR_RDF2_PAIRS
+#define GNR_RDF2_PAIRS 0      // measurement build: ray_dir_fc.2 on the f16 matrix cores (gnr_pack_body.h c16_pairs; round-6 A/B record)
+#endif
 // rows of the two queues
 constexpr int rows_a(int V) { return GNR_TWO_QUEUES ? (V + 1) / 2 : V; }
 constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
@@ -1014,6 +1017,10 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 load_bias<3, LF>(lds + LO(pk::B_RDF2), g, acc3);
                 // 4 k-steps: stays on the fp32 MFMA (zero-padded into a K32 pair block: 3.68 vs 3.71 ms alone, but 3.80 together
                 // with the padded tails of HOIST / GEO1, which gain more: 3.63)
+#if GNR_RDF2_PAIRS
+                if constexpr (SP && !USEVIS) { const P8 dp = split8z<0, 4>(d1); mm16<1, 3, LF>(lds + pk::c16_off(pk::DECV1), lane, &dp, acc3); }
+                else
+#endif
                 mm<4, 3, 0, LF>(lds + LO(pk::RDF2), lane, d1, acc3);
                 elu_to<3, true>(acc3, df);
 #pragma unroll

@@ -161,6 +161,9 @@ GNR_HD inline float f16_to_f32(uint16_t h, bool& finite) {
 
 // which k-steps of a layer become K32 pair blocks (runs of <= 8 consecutive k-steps; a short run is zero-padded) and which stay
 // fp32 fragments (k_chain's call sites use the same split)
+#ifndef GNR_RDF2_PAIRS
+#define GNR_RDF2_PAIRS 0      // see c16_pairs
+#endif
 struct C16Plan { int off, J, NB, nblk; int k0[5], kn[5]; int nrest; int rest[2]; };
 constexpr int C16_PLANS = 18;
 GNR_HD inline C16Plan c16_plan(int n) {
@@ -246,6 +249,12 @@ GNR_HD void c16_pairs(const Ex& ex, float* p) {
         const C16Plan pl = c16_plan(n);
         to_pairs(ex, p + pk::C16 + pk::c16_off(pl.off), p + pl.off, pl, p + pk::T_VIS + 2, p + pk::C16 + pk::c16_off(pk::T_VIS) + 2);
     }
+#if GNR_RDF2_PAIRS
+    // measurement build (tools/ab_chain.py, profiles/r06_*_chain_ab.json): ray_dir_fc.2's 4 k-steps as ONE zero-padded K32 pair block.  The
+    // C16 image has no room left (156.3 of 160 KB): the block overlays the vis_decoder's slots, so this build serves use_vis = 0 only.
+    to_pairs(ex, p + pk::C16 + pk::c16_off(pk::DECV1), p + pk::RDF2, C16Plan{pk::RDF2, 4, 3, 1, {0}, {4}, 0, {0, 0}}, p + pk::T_VIS + 2,
+             p + pk::C16 + pk::c16_off(pk::T_VIS) + 2);
+#endif
 }
 
 // prob_embed.2 (32x32 + bias, no activation) folded into a consumer's rows: (W o P2)[o][i] = sum_k W[o][k] P2[k][i], products in
