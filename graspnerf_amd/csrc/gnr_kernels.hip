@@ -18,6 +18,7 @@
 // Layout conventions are documented in gnr_layout.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "gnr_layout.h"
 

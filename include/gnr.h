@@ -56,7 +56,8 @@ typedef struct GnrScene {
  * Product switches:
  *   GNR_OPT_FEATURE_GRAD_FIXED  the feature-map gradients of this call (gnr_depth_mean_bwd, gnr_sample_volume_bwd,
  *                               gnr_render_chain_bwd) are BIT-REPRODUCIBLE: 64-bit fixed-point adds instead of float sums in
- *                               arrival order (see "backward twins" below); costs twice the atomic traffic.
+ *                               arrival order (see "backward twins" below).  Since round 6 the view kernels' binned scatter sums
+ *                               the same parked rows as integers: the mode costs what the float mode costs.
  * Measurement / test switches (same results to rounding unless stated):
  *   GNR_OPT_FP32_CHAIN          every chain launch of the call -- forward, training forward and the backward's view kernels -- runs
  *                               its fp32-input-MFMA instantiation (what the range guard falls back to); the pair kernels are skipped
@@ -326,11 +327,12 @@ int gnr_upsample2x_bilinear(const float* x, float* y, long long planes, int H, i
  * the arrival order.  GNR_OPT_FEATURE_GRAD_FIXED (GnrScene.options of the backward call) makes them BIT-REPRODUCIBLE too: every
  * contribution is rounded once to a multiple of a launch-wide power-of-two quantum (2^-28 of the launch's largest upstream gradient,
  * found by an order-independent maximum) and added as a 64-bit integer (integer adds commute); a contribution more than 2^14 times the
- * upstream maximum is clamped and raises bit 3 of gnr_range_status.  Costs twice the atomic traffic of the float path.
+ * upstream maximum is clamped and raises bit 3 of gnr_range_status.
  * Every entry point that produces feature-map gradients honours it (gnr_depth_mean_bwd, gnr_sample_volume_bwd,
  * gnr_render_chain_bwd); their workspaces are sized for either mode.  In the float mode the view kernels' scatter is BINNED (round 6,
  * csrc/gnr_bwd_scatter.inc): the per-(view, point) rows are parked in the training workspace and summed per feature-map pixel before
- * anything is added atomically (786 M -> ~40 M atomic dwords per 8-scene volume launch).
+ * anything is added atomically (786 M -> ~40 M atomic dwords per 8-scene volume launch).  In the fixed-point mode the same rows are
+ * summed as 64-bit integers (same rounding per contribution, same bits as the direct fixed-point scatter): no extra cost.
  * gnr_depth_mean_bwd: the backward of gnr_depth_mean_fwd (predict_mean_for_depth_loss, renderer.py:230-266,
  * consumed by DepthLoss, loss.py:87-144).  sample_volume and the per-view chain of the render passes follow below;
  * the render path's twin pairs (per-view chain, per-ray tail, compositing) follow further down.

@@ -182,3 +182,41 @@ def test_merge_depths_is_sort_of_cat(weights_np):
         assert torch.equal(got, torch.sort(torch.cat([a, b], -1), -1)[0])
     with pytest.raises(_lib.GnrError):
         hp.merge_depths(torch.zeros(2, 100).cuda(), torch.zeros(2, 100).cuda())      # more than 128 samples per ray
+
+
+@pytest.mark.parametrize('cfg_name', ['cfg1', 'cfg2'])
+def test_fixed_point_binned_scatter_is_the_direct_fixed_point_scatter(cfg_name, weights_np):
+    """GNR_OPT_FEATURE_GRAD_FIXED through the binned scatter (k_scatter_gather<true>: the parked rows summed as 64-bit integers) against
+    the direct 64-bit scatter out of k_view1_bwd_pw<true> (GNR_OPT_DIRECT_SCATTER): every contribution is rounded to the same multiple of
+    the same quantum, integer sums do not care about order or chunking -> the feature-map gradients are the same BITS, three times over."""
+    from graspnerf_amd.hotpath import batch_scenes
+    hp = _hot(weights_np)
+    hp.feature_grad_mode(True)
+    scenes = [make_scene(i, cfg_name, with_query_image=False) for i in range(2)]
+    bref, bque = batch_scenes(scenes)
+    bref = {k: torch.from_numpy(v).cuda() for k, v in bref.items()}
+    bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
+    res, rn, dn = (16, bq['coords'].shape[1], 16) if cfg_name == 'cfg1' else (40, bq['coords'].shape[1], 40)
+    cfg = dict(CFG, depth_sample_num=dn, fine_depth_sample_num=dn)
+    g = torch.Generator().manual_seed(4)
+    dvol = torch.randn(2, 1, res, res, res, generator=g).cuda() * 1e-4
+    ds = torch.randn(2, rn * dn, 65, generator=g).cuda() * 1e2
+    dc = torch.randn(2, rn * dn, 3, generator=g).cuda() * 1e2
+    outs = {}
+    for direct in (True, False, False, False):
+        hp.set_option('direct_scatter', direct)
+        prep = hp.prepare(bref, res, rn, dn)
+        _, _, _, ctx = hp.render_chain_train(bq, None, 'coarse', cfg, prep)
+        hp.sample_volume_train(bref, res, prepared=prep)
+        v = hp.sample_volume_bwd(dvol, hp.can_dev['coarse'])
+        r = hp.render_chain_bwd(ctx, ds, dc)
+        torch.cuda.synchronize()
+        assert hp.range_status(prep) & 8 == 0
+        got = [t.clone() for t in (v[1], v[2], r[1], r[2])]
+        assert all(float(t.abs().max()) > 0 for t in got)
+        if direct:
+            want = got
+        else:
+            for a, b, name in zip(got, want, ('volume d_ray_feats', 'volume d_img_feats', 'render d_ray_feats', 'render d_img_feats')):
+                assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    hp.set_option('direct_scatter', False)
