@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void k_repack_feats(const float* __restrict__ 
 __global__ void k_view_setup(const float* __restrict__ poses, const float* __restrict__ Ks,
                              const float* __restrict__ dr, float* __restrict__ viewp, int nviews, unsigned* __restrict__ range_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 64 && range_flag) range_flag[i] = 0u;          // gnr_prepare launches this kernel first: new watch words per prepare (word 0 + one per launch slot)
+    if (i < 64 && range_flag) { range_flag[i] = 0u; range_flag[64 + i] = 0u; }   // gnr_prepare launches this kernel first: new watch words per prepare (word 0 + one per launch slot), and the
+                                                                                 // tile counters of the chain launches behind them (words 64.., ChainArgs::tile_ctr)
     if (i >= nviews) return;
     const float* P = poses + i * 12;
     const float* K = Ks + i * 9;
@@ -591,6 +592,9 @@ struct ChainArgs {
     // inference render passes: the points are laid out in the Morton order of their rays (k_ray_order); the user-visible
     // per-point outputs (colours, view masks) go to the caller's ray order: point (slot s, sample k) -> ray_perm[b][s] * dn + k
     const int* ray_perm; int perm_rn, perm_dn;
+    // dynamic tile hand-out (null: static round-robin).  [x] = next tile of XCD x's chunk, [8] = wavefronts of the launch that are through:
+    // zero before the first launch (gnr_prepare), set back to zero by the last wavefront of every launch
+    unsigned* tile_ctr;
 };
 
 struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
@@ -721,6 +725,11 @@ constexpr int SW = 20;     // per-view state width: X[9] E[8] gate m rgb  /  H2[
 constexpr int rows_a(int V) { return GNR_TWO_QUEUES ? (V + 1) / 2 : V; }
 constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
 
+#ifndef GNR_DYN_TILES
+#define GNR_DYN_TILES 1         // k_chain takes its tiles from a per-XCD counter (ChainArgs::tile_ctr); 0: static round-robin shares; 2: a wavefront whose XCD's chunk is
+                                // empty goes on with the next XCD's -- MEASURED NEGATIVE (profiles/r06_c_dyn_tiles_ab.json: step 6.40 -> 6.83 ms, render launches
+                                // 2.28 -> 2.58 ms: the time between two tiles of a wavefront goes from 2.4 % to 6.7 % of its life)
+#endif
 #ifndef GNR_SKIP_MASKED
 #define GNR_SKIP_MASKED 1      // skip the (tile, view) pairs without a single valid point (inference kernels)
 #endif
@@ -734,10 +743,20 @@ constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
 // run-time branch it cost the default kernels 5 - 18 % (3.65 -> 3.82 ms volume, 1.29 -> 1.52 ms render launch)
 // SP: the wide layers as fp16 pairs on the f16 matrix cores (the product's launches) / on the fp32-input MFMA (the range
 // guard's fallback, and every launch of the -DGNR_SPLIT16=0 companion build)
+#ifndef GNR_WAVE_CLOCK
+#define GNR_WAVE_CLOCK 0      // measurement build (tools/wave_clock.py): per-wavefront start / staged / end stamps and per-tile ticks of the inference launches
+#endif
+#if GNR_WAVE_CLOCK
+__device__ unsigned long long g_wave_clock[2][4096][4];      // [RENDER][workgroup * 8 + wavefront][start, staged, end, tiles]   (100 MHz ticks)
+__device__ unsigned g_tile_clock[2][1 << 17];                // [RENDER][tile] ticks of one tile
+#endif
 template <int V, bool RENDER, bool SAVE = false, bool USEVIS = false, bool SP = (GNR_SPLIT16 != 0)>
 __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LF = (GNR_LICM_FENCE != 0) || V > 6;      // per-layer LICM fences (see mm())
+#if GNR_WAVE_CLOCK
+    const unsigned long long wc_t0 = wall_clock64();
+#endif
     if (a.only_if_flagged) {                                // the fp32 twin: runs only when the scene's or this launch's watch word is set
         const unsigned w0 = a.range_flag ? __builtin_nontemporal_load(a.range_flag) : 0u;
         const unsigned w1 = a.range_launch ? __builtin_nontemporal_load(a.range_launch) : 0u;
@@ -761,7 +780,14 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     {
         const f4* src = reinterpret_cast<const f4*>(a.wpk + (SP ? pk::C16 : 0));
         f4* dst = reinterpret_cast<f4*>(lds);
-        for (int i = threadIdx.x; i < (SP ? pk::C16_END : pk::CHAIN_END) / 4; i += blockDim.x) dst[i] = src[i];
+        constexpr int N4 = (SP ? pk::C16_END : pk::CHAIN_END) / 4, SU = 6;      // six loads in flight per lane (one per trip: 10 us per launch, tools/wave_clock.py)
+        for (int i0 = threadIdx.x; i0 < N4; i0 += blockDim.x * SU) {
+            f4 tmp[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { const int i = i0 + u * (int)blockDim.x; tmp[u] = src[i < N4 ? i : N4 - 1]; }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { const int i = i0 + u * (int)blockDim.x; if (i < N4) dst[i] = tmp[u]; }
+        }
     }
     constexpr int COOP_TAB = SP ? pk::C16_END : pk::CHAIN_END;            // per-lane-group constants of project_coop
     if (threadIdx.x < 4) {
@@ -781,6 +807,10 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if GNR_WAVE_CLOCK
+    const unsigned long long wc_t1 = wall_clock64();
+    unsigned long long wc_n = 0;
+#endif
     const int waves_per_block = blockDim.x >> 6;
     const int tps = (a.P + 15) >> 4;                       // tiles per scene
     const int ntiles = a.B * tps;
@@ -796,8 +826,30 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     const int nlblk = ((int)gridDim.x - xcd + NXCD - 1) / NXCD;            // workgroups that share this XCD
     const int chunk = (ntiles + NXCD - 1) / NXCD;
     const int t_end = min(ntiles, (xcd + 1) * chunk);
-    for (int tile = xcd * chunk + lblk * waves_per_block + wave; tile < t_end; tile += nlblk * waves_per_block) {
+    // Tiles are handed out by an atomic counter per XCD, not round-robin: the wavefronts of a launch do not run at one speed (the SIMD
+    // issues its older wavefront first; tools/wave_clock.py: tile times 37 - 66 us at equal work, the fastest wavefront through after
+    // 75 % of a volume launch), and a slot that stands empty while its SIMD partner finishes alone is the launch's tail: mean
+    // wavefront life 0.88 (volume) / 0.85 (render) of the launch with static shares.  The next index is fetched one stage ahead
+    // (after the second view loop), so its latency is hidden; the order in which an XCD sweeps its chunk is unchanged.
+    const bool dyn = GNR_DYN_TILES != 0 && a.tile_ctr != nullptr;
+    int cx = xcd, hops = 0;                                // the chunk this wavefront draws from; chunks it has found empty
+    auto grab = [&]() -> unsigned { unsigned t = 0u; if (lane == 0) t = atomicAdd(a.tile_ctr + cx, 1u); return t; };
+    auto resolve = [&](unsigned t_raw) -> int {            // fetched index -> tile, walking on while the chunk is exhausted; -1: nothing left
+        int t = __builtin_amdgcn_readfirstlane((int)t_raw);
+        while (t >= min(ntiles, (cx + 1) * chunk) - cx * chunk) {
+            if (++hops >= (GNR_DYN_TILES > 1 ? NXCD : 1)) return -1;
+            cx = cx + 1 == NXCD ? 0 : cx + 1;
+            t = __builtin_amdgcn_readfirstlane((int)grab());
+        }
+        return cx * chunk + t;
+    };
+    int tile = dyn ? resolve(grab()) : xcd * chunk + lblk * waves_per_block + wave;
+    for (; dyn ? tile >= 0 : tile < t_end;) {
         GNR_ITER_FENCE();
+        unsigned tile_nxt = 0u;
+#if GNR_WAVE_CLOCK
+        const unsigned long long wc_tt = wall_clock64();
+#endif
         const int b = tile / tps;
         int ts = tile - b * tps;
         if (a.vol_res > 0) {
@@ -1231,6 +1283,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         };
         phase2(SA, 0);
         if constexpr (VB > 0) phase2(SB, VA);
+        if (dyn) tile_nxt = grab();
 
         // ================= cross-view reduction 2 (ibrnet.py:482-484,488) + colour blend (:510-511)
         float Z[23];
@@ -1311,7 +1364,25 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
                 d[24] = msum; d[25] = wbar; d[26] = Z[0] * kLn2; d[27] = Z[8] * kLn2 * kLn2; d[28] = SV[8]; d[29] = G[0].x * kLn2; d[30] = gg[0] * kLn2; d[31] = vsum;
             }
         }
+#if GNR_WAVE_CLOCK
+        if constexpr (SP && !SAVE) { ++wc_n; if (lane == 0 && tile < (1 << 17)) g_tile_clock[RENDER ? 1 : 0][tile] = (unsigned)(wall_clock64() - wc_tt); }
+#endif
+        tile = dyn ? resolve(tile_nxt) : tile + nlblk * waves_per_block;
     }
+    if (dyn && lane == 0) {        // the launch's last wavefront (every other one has made its last, failing, fetches) re-arms the counters for the next launch
+        if (atomicAdd(a.tile_ctr + 8, 1u) == gridDim.x * (unsigned)waves_per_block - 1u) {
+#pragma unroll
+            for (int x = 0; x < 9; ++x) atomicExch(a.tile_ctr + x, 0u);
+        }
+    }
+#if GNR_WAVE_CLOCK
+    if constexpr (SP && !SAVE) {
+        if (lane == 0 && !a.only_if_flagged && blockIdx.x * 8 + wave < 4096) {
+            unsigned long long* w = g_wave_clock[RENDER ? 1 : 0][blockIdx.x * 8 + wave];
+            w[0] = wc_t0; w[1] = wc_t1; w[2] = wall_clock64(); w[3] = wc_n;
+        }
+    }
+#endif
     if constexpr (SP) {      // range guard
         if (range_tripped && lane == 0) {
             if (a.range_launch) atomicOr(a.range_launch, 2u);
