@@ -173,7 +173,9 @@ def lib():
     L.gnr_composite_bwd_workspace_bytes.restype = C.c_size_t
     L.gnr_host_randperm_prefix.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p]
     L.gnr_host_randperm_prefix.restype = C.c_int
-    L.gnr_geo_dual_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    L.gnr_geo_dual_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]
+    L.gnr_geo_dual_fwd_workspace_bytes.argtypes = []
+    L.gnr_geo_dual_fwd_workspace_bytes.restype = C.c_size_t
     L.gnr_geo_dual_fwd.restype = C.c_int
     L.gnr_geo_dual_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]
     L.gnr_geo_dual_bwd_workspace_bytes.argtypes = [C.c_int]
@@ -227,7 +229,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_depth_mean_bwd_workspace_bytes', 'gnr_depth_mean_bwd', 'gnr_sample_volume_train_workspace_bytes',
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
             'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_tap_mask_words', 'gnr_conv3d_tap_mask', 'gnr_conv3d_same_masked', 'gnr_conv3d_same_bwd_weight_masked', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
-            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_geo_dual_fwd', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
+            'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_geo_dual_fwd', 'gnr_geo_dual_fwd_workspace_bytes', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
             'gnr_img_last_error', 'gnr_instnorm_act', 'gnr_instnorm_act_bwd', 'gnr_reflect_pad2d', 'gnr_reflect_pad2d_bwd', 'gnr_upsample2x_bilinear']
 
 

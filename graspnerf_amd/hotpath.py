@@ -413,15 +413,19 @@ class HotPath:
         return o
 
     def geo_dual_fwd(self, canon, stats, pts, gamma):
-        """geometry_fc on dual numbers (k_geo_dual_fwd): canon = the level's canonical blob on the device, stats [P,66],
+        """geometry_fc on dual numbers (k_geo_dual_fwd_mm; k_geo_dual_fwd with the option geo_dual_fp32): canon = the level's canonical blob on the device, stats [P,66],
         pts, gamma [P,3] -> g, gd [P,16] (value / tangent of geometry_fc's output)."""
         stats, pts, gamma = (_f32(x, self.device) for x in (stats, pts, gamma))
         P = stats.shape[0]
         assert stats.shape == (P, 66) and pts.shape == (P, 3) and gamma.shape == (P, 3)
         g = torch.empty(P, 16, dtype=torch.float32, device=self.device)
         gd = torch.empty_like(g)
+        need = self.L.gnr_geo_dual_fwd_workspace_bytes()
+        if getattr(self, '_gdf_scratch', None) is None or self._gdf_scratch.numel() < need:
+            self._gdf_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         _lib.check(self.L.gnr_geo_dual_fwd(canon.data_ptr(), stats.data_ptr(), pts.data_ptr(), gamma.data_ptr(), g.data_ptr(),
-                                           gd.data_ptr(), P, self._stream()), 'gnr_geo_dual_fwd')
+                                           gd.data_ptr(), P, self._gdf_scratch.data_ptr(), self._gdf_scratch.numel(), self.options,
+                                           self._stream()), 'gnr_geo_dual_fwd')
         return g, gd
 
     def geo_dual_bwd(self, canon, stats, pts, gamma, gbar, gdbar):

@@ -67,7 +67,7 @@ typedef struct GnrScene {
  *                               (csrc/gnr_bwd_scatter.inc: rows parked in HBM, summed per feature-map pixel first)
  *   GNR_OPT_RAY_ORDER_MORTON    the inference render passes traverse a scene's rays in the Morton order of their pixels (internal
  *                               layout only; every array of the ABI keeps the caller's ray order, results are bit-identical)
- *   GNR_OPT_GEO_DUAL_FP32       the per-point half of gnr_geo_dual_bwd as fp32 FMAs, one lane per point, instead of the fp16-pair chain
+ *   GNR_OPT_GEO_DUAL_FP32       gnr_geo_dual_fwd and the per-point half of gnr_geo_dual_bwd as fp32 FMAs, one lane per point, instead of the fp16-pair chain
  *   GNR_OPT_POISON_PARTIALS     the partial-gradient buffers are filled with NaN patterns before the kernels run (an entry no wavefront
  *                               stores would show in the reduced gradient)
  *   GNR_OPT_TEST_LOSE_PARTNER   (tests) the partner wavefronts of k_view1_bwd_pw / k_view2_bwd_pw return at once: the compute wavefronts'
@@ -409,8 +409,13 @@ int gnr_ray_tail_grad_floats(void);
  * the level's parameters in state-dict order on the device; stats [P,66] (mean 32, var 32, wbar, n_valid), pts, gamma [P,3].
  * fwd: g, gd [P,16] = value / derivative along gamma of geometry_fc's output.  bwd: gbar, gdbar [P,16] -> dstats [P,66]
  * (overwritten) and the gradients of geometry_fc.{0,2}.{weight,bias} ACCUMULATED into d_canonical (state-dict order).   */
+/* fwd runs on the f16 matrix cores like the backward's per-point half (16 points as the columns of a chained fp16-pair MFMA, fragments
+ * packed per call into caller-owned scratch of gnr_geo_dual_fwd_workspace_bytes() bytes; a call whose outputs come out non-finite -- a
+ * weight or an operand beyond the fp16 range -- is recomputed by the fp32 kernel launched behind it); GNR_OPT_GEO_DUAL_FP32: the fp32 FMA
+ * kernel alone (scratch may then be NULL). */
+size_t gnr_geo_dual_fwd_workspace_bytes(void);
 int gnr_geo_dual_fwd(const float* canonical_dev, const float* stats, const float* pts, const float* gamma, float* g, float* gd,
-                     int P, void* stream);
+                     int P, void* scratch, size_t scratch_bytes, unsigned options, void* stream);
 /* bwd runs as two kernels (the per-point reverse pass -- 16 points as the columns of a chained fp16-pair MFMA, its fragments packed per
  * call from canonical_dev -- then the weight-gradient outer products over the points on the matrix cores) with the per-point adjoints
  * between them (288 floats per point), the fragment image (64 KB) and the partial weight gradients in caller-owned scratch of
@@ -425,8 +430,8 @@ int gnr_geo_dual_bwd(const float* canonical_dev, const float* stats, const float
  * ray), dalpha, dhit [nrays*dn] may be null.  Out: a_out = dL/d sdf, gamma_out = dL/d grad (the upstreams of
  * gnr_ray_tail_dual_bwd), dcol_out, dvar_out[0] = dL/d deviation_network.variance (all overwritten).
  * scratch: gnr_composite_bwd_workspace_bytes(nrays) / gnr_ray_tail_dual_bwd_workspace_bytes() bytes, caller-owned (the
- * per-wavefront partial sums of the parameter gradients).  `options` of gnr_ray_tail_dual_bwd / gnr_geo_dual_bwd: GNR_OPT_* (these
- * entry points take no GnrScene): GNR_OPT_POISON_PARTIALS, and GNR_OPT_GEO_DUAL_FP32 for gnr_geo_dual_bwd.                 */
+ * per-wavefront partial sums of the parameter gradients).  `options` of gnr_ray_tail_dual_bwd / gnr_geo_dual_fwd / gnr_geo_dual_bwd: GNR_OPT_* (these
+ * entry points take no GnrScene): GNR_OPT_POISON_PARTIALS, and GNR_OPT_GEO_DUAL_FP32 for gnr_geo_dual_fwd / gnr_geo_dual_bwd.                 */
 size_t gnr_composite_bwd_workspace_bytes(int nrays);
 int gnr_composite_bwd(const float* level_weights, const float* sdf, const float* grad, const float* col, const float* depth,
                       const float* qdir, const float* dpix, const float* ddepth, const float* wgerr, const float* dalpha,

@@ -355,8 +355,11 @@ def test_training_tail_entry_points_validate_arguments():
     assert L.gnr_composite_bwd(p, p, p, p, p, p, p, None, None, None, None, p, p, p, p, 4, 129, p, big, None) == -2
     assert L.gnr_composite_bwd(p, p, p, p, p, p, p, None, None, None, None, p, p, p, p, 4, 40, p, 4, None) == -4
     assert L.gnr_composite_bwd_workspace_bytes(130) >= 3 * 8
-    assert L.gnr_geo_dual_fwd(p, p, p, None, p, p, 10, None) == -1
-    assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 0, None) == -2
+    assert L.gnr_geo_dual_fwd(p, p, p, None, p, p, 10, p, 1 << 20, 0, None) == -1
+    assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 0, p, 1 << 20, 0, None) == -2
+    assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 10, p, 16, 0, None) == -4            # scratch too small
+    assert L.gnr_geo_dual_fwd(p, p, p, p, p, p, 10, p, 1 << 20, 1 << 20, None) == -1   # unknown option bits
+    assert L.gnr_geo_dual_fwd_workspace_bytes() >= 64 * 1024
     assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, None, 10, p, 1 << 20, 0, None) == -1
     assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, p, 10, p, 16, 0, None) == -4          # scratch too small
     assert L.gnr_geo_dual_bwd(p, p, p, p, p, p, p, p, 10, p, 1 << 30, 1 << 20, None) == -1   # unknown option bits (GNR_OPT_*) are refused, not ignored

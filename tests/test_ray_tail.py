@@ -273,6 +273,88 @@ def test_geo_dual_bwd_weight_without_an_fp16_pair_falls_back_to_the_fp32_kernel(
         assert torch.equal(g, x)
 
 
+def _geo_dual_fwd_f64(weights_np, level, stats, pts, gamma):
+    """geometry_fc (ibrnet.py:488-489) on dual numbers in float64: x = [mean 32, var 32, wbar, embed(p) 21] (neus.py:37-45), tangent along gamma."""
+    agg = ('agg_net.' if level == 'coarse' else 'fine_agg_net.') + 'agg_impl.geometry_fc.'
+    W1, b1, W2, b2 = (torch.from_numpy(np.asarray(weights_np[agg + k])).double() for k in ('0.weight', '0.bias', '2.weight', '2.bias'))
+    st, p, gm = (torch.from_numpy(x).double() for x in (stats, pts, gamma))
+    emb = [p] + [f(p * m) for m in (1.0, 2.0, 4.0) for f in (torch.sin, torch.cos)]
+    demb = [gm] + [d * gm for m in (1.0, 2.0, 4.0) for d in (m * torch.cos(p * m), -m * torch.sin(p * m))]
+    x = torch.cat([st[:, :65]] + emb, 1)
+    xd = torch.cat(demb, 1)
+    h = x @ W1.T + b1
+    hd = xd @ W1[:, 65:].T
+    elu = lambda u: torch.where(u > 0, u, torch.expm1(u))
+    delu = lambda u: torch.where(u > 0, torch.ones_like(u), torch.exp(u))
+    gp = elu(h) @ W2.T + b2
+    gpd = (delu(h) * hd) @ W2.T
+    return elu(gp), delu(gp) * gpd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scale_x,scale_g,Pn', [(1.0, 1.0, 4 * 512 * 40 + 13), (1.0, 1e-20, 777), (3e4, 1e3, 20000), (1.0, 1.0, 5)])
+def test_geo_dual_fwd_on_the_matrix_cores_agrees_with_the_fp32_kernel_and_float64(scale_x, scale_g, Pn, weights_np):
+    """gnr_geo_dual_fwd as a chained fp16-pair MFMA (k_geo_dual_fwd_mm, the default since round 6) against the fp32 FMA kernel
+    (GNR_OPT_GEO_DUAL_FP32) and a float64 evaluation: value and tangent of geometry_fc's output; the matrix-core kernel is no farther from
+    float64 than the fp32 kernel (x 1.5); tangents of 1e-20 (operand blocks are normalised before they are split), statistics near the
+    fp16 limit, ragged point counts."""
+    from graspnerf_amd.hotpath import HotPath
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    canon = torch.from_numpy(weights.canonical_blob(weights_np, 'fine')).cuda()
+    rng = np.random.default_rng(12)
+    stats = (rng.standard_normal((Pn, 66)) * scale_x).astype(np.float32)
+    stats[:, 32:64] = np.abs(stats[:, 32:64]); stats[:, 64] = rng.uniform(0, 1, Pn); stats[:, 65] = 6
+    pts = rng.uniform(-0.5, 0.5, (Pn, 3)).astype(np.float32)
+    gamma = (rng.standard_normal((Pn, 3)) * scale_g).astype(np.float32)
+    prev = hp.set_option('geo_dual_fp32', False)
+    try:
+        got = [x.double().cpu() for x in hp.geo_dual_fwd(canon, stats, pts, gamma)]
+        hp.set_option('geo_dual_fp32', True)
+        f32 = [x.double().cpu() for x in hp.geo_dual_fwd(canon, stats, pts, gamma)]
+    finally:
+        hp.set_option('geo_dual_fp32', prev)
+    want = _geo_dual_fwd_f64(weights_np, 'fine', stats, pts, gamma)
+    for g, f, w, name in zip(got, f32, want, ('g', 'gd')):
+        assert bool(torch.isfinite(g).all()), name
+        sc = float(w.abs().max())
+        assert sc > 0
+        e_mm, e_32 = float((g - w).pow(2).mean().sqrt()) / sc, float((f - w).pow(2).mean().sqrt()) / sc
+        assert e_mm <= 1.5 * e_32 + 1e-9, (name, e_mm, e_32)
+        if scale_x == 1.0:
+            assert float((g - f).abs().max()) <= 2e-5 * sc, name
+        else:                               # pre-activations of 1e5: a hidden unit on the other side of the ELU's kink in one of the two kernels
+            row = (g - f).abs().max(1)[0] / f.abs().max(1)[0].clamp(min=1e-30)
+            assert float(row.median()) <= 2e-5 and float((row > 1e-3).double().mean()) <= 5e-3, name
+
+
+@pytest.mark.gpu
+def test_geo_dual_fwd_weight_without_an_fp16_pair_falls_back_to_the_fp32_kernel(weights_np):
+    """A geometry_fc weight of 1e5 has no fp16 pair (k_pack_geo_dual stores inf): k_geo_dual_fwd_mm's outputs turn non-finite, its range word
+    makes the fp32 kernel launched behind it recompute the call -- the outputs are that kernel's, bit for bit."""
+    from graspnerf_amd.hotpath import HotPath
+    w = dict(weights_np)
+    k = 'fine_agg_net.agg_impl.geometry_fc.2.weight'
+    w[k] = w[k].copy(); w[k][5, 11] = 1e5
+    hp = HotPath(weights.pack_state_dict(weights_np, 'coarse'), weights.pack_state_dict(weights_np, 'fine'))
+    canon = torch.from_numpy(weights.canonical_blob(w, 'fine')).cuda()
+    rng = np.random.default_rng(3)
+    Pn = 5000
+    stats = rng.standard_normal((Pn, 66)).astype(np.float32); stats[:, 32:64] = np.abs(stats[:, 32:64]); stats[:, 65] = 6
+    pts = rng.uniform(-0.5, 0.5, (Pn, 3)).astype(np.float32)
+    gamma = rng.standard_normal((Pn, 3)).astype(np.float32) * 1e-3
+    prev = hp.set_option('geo_dual_fp32', False)
+    try:
+        got = [x.clone() for x in hp.geo_dual_fwd(canon, stats, pts, gamma)]
+        hp.set_option('geo_dual_fp32', True)
+        want = [x.clone() for x in hp.geo_dual_fwd(canon, stats, pts, gamma)]
+    finally:
+        hp.set_option('geo_dual_fp32', prev)
+    torch.cuda.synchronize()
+    for g, x in zip(got, want):
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+        assert torch.equal(g, x)
+
+
 def test_positive_cumprod_backward_equals_autograd():
     """reference_autograd._CumprodPositive: torch.cumprod's values, and its gradient for strictly positive factors, without the
     `(x == 0).any()` host read of the stock backward."""
