@@ -747,7 +747,7 @@ constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
 #define GNR_WAVE_CLOCK 0      // measurement build (tools/wave_clock.py): per-wavefront start / staged / end stamps and per-tile ticks of the inference launches
 #endif
 #if GNR_WAVE_CLOCK
-__device__ unsigned long long g_wave_clock[2][4096][4];      // [RENDER][workgroup * 8 + wavefront][start, staged, end, tiles]   (100 MHz ticks)
+__device__ unsigned long long g_wave_clock[2][4096][8];      // [RENDER][workgroup * 8 + wavefront][start, staged, end, tiles, ticks in: head + view loop 1, reduction 1 + hoist, view loop 2, tail]   (100 MHz ticks)
 __device__ unsigned g_tile_clock[2][1 << 17];                // [RENDER][tile] ticks of one tile
 #endif
 template <int V, bool RENDER, bool SAVE = false, bool USEVIS = false, bool SP = (GNR_SPLIT16 != 0)>
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if GNR_WAVE_CLOCK
     const unsigned long long wc_t1 = wall_clock64();
-    unsigned long long wc_n = 0;
+    unsigned long long wc_n = 0, wc_ph[4] = {0, 0, 0, 0};
 #endif
     const int waves_per_block = blockDim.x >> 6;
     const int tps = (a.P + 15) >> 4;                       // tiles per scene
@@ -1102,6 +1102,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         };
         phase1(SA, 0);
         if constexpr (VB > 0) phase1(SB, VA);
+#if GNR_WAVE_CLOCK
+        const unsigned long long wc_p1 = wall_clock64();
+#endif
 
         // ================= cross-view reduction 1 (ibrnet.py:466-472), in-lane
         float SV[36];
@@ -1143,6 +1146,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             sp[16 * 64] = inv_msum;
         }
 
+#if GNR_WAVE_CLOCK
+        const unsigned long long wc_p2 = wall_clock64();
+#endif
         // ================= phase 2: per view, base_fc / vis_fc / vis_fc2 (/ rgb_fc)
         float vsum = 0.f;
         // the oldest row of the queue is copied out, the queue advances, the view's results become its last row
@@ -1283,6 +1289,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         };
         phase2(SA, 0);
         if constexpr (VB > 0) phase2(SB, VA);
+#if GNR_WAVE_CLOCK
+        const unsigned long long wc_p3 = wall_clock64();
+#endif
         if (dyn) tile_nxt = grab();
 
         // ================= cross-view reduction 2 (ibrnet.py:482-484,488) + colour blend (:510-511)
@@ -1365,7 +1374,8 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             }
         }
 #if GNR_WAVE_CLOCK
-        if constexpr (SP && !SAVE) { ++wc_n; if (lane == 0 && tile < (1 << 17)) g_tile_clock[RENDER ? 1 : 0][tile] = (unsigned)(wall_clock64() - wc_tt); }
+        if constexpr (SP && !SAVE) { const unsigned long long wc_e = wall_clock64(); ++wc_n; wc_ph[0] += wc_p1 - wc_tt; wc_ph[1] += wc_p2 - wc_p1; wc_ph[2] += wc_p3 - wc_p2; wc_ph[3] += wc_e - wc_p3;
+            if (lane == 0 && tile < (1 << 17)) g_tile_clock[RENDER ? 1 : 0][tile] = (unsigned)(wc_e - wc_tt); }
 #endif
         tile = dyn ? resolve(tile_nxt) : tile + nlblk * waves_per_block;
     }
@@ -1380,6 +1390,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         if (lane == 0 && !a.only_if_flagged && blockIdx.x * 8 + wave < 4096) {
             unsigned long long* w = g_wave_clock[RENDER ? 1 : 0][blockIdx.x * 8 + wave];
             w[0] = wc_t0; w[1] = wc_t1; w[2] = wall_clock64(); w[3] = wc_n;
+            w[4] = wc_ph[0]; w[5] = wc_ph[1]; w[6] = wc_ph[2]; w[7] = wc_ph[3];
         }
     }
 #endif

@@ -34,7 +34,7 @@ L.gnr_dbg_wave_clock.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
 L.gnr_dbg_wave_clock.restype = C.c_int
 res = {}
 for which, name in ((0, 'volume'), (1, 'render (the step\'s last launch: the fine pass)')):
-    w = np.zeros((4096, 4), np.uint64)
+    w = np.zeros((4096, 8), np.uint64)
     t = np.zeros(1 << 17, np.uint32)
     assert L.gnr_dbg_wave_clock(which, w.ctypes.data, t.ctypes.data) == 0
     keep = w[:, 3] > 0
@@ -52,6 +52,7 @@ for which, name in ((0, 'volume'), (1, 'render (the step\'s last launch: the fin
              tile_us_mean=float(tt.mean()), tile_us_p05=float(np.percentile(tt, 5)), tile_us_p50=float(np.percentile(tt, 50)),
              tile_us_p95=float(np.percentile(tt, 95)), tile_us_max=float(tt.max()),
              sum_tile_over_life=float(tt.sum() / life.sum()))
+    r['phase_us_per_tile'] = {k: float(w[:, 4 + j].sum() * 0.01 / ntile) for j, k in enumerate(('head + view loop 1', 'reduction 1 + hoist', 'view loop 2', 'reduction 2 + geometry_fc + record'))}
     # per XCD (workgroup b -> XCD b % 8): when its last wavefront ends, relative to the launch start
     r['xcd_end_us'] = [float((t2[(wg % 8) == x].max() - t0.min()) * 0.01) for x in range(8)]
     r['xcd_mean_life_us'] = [float(life[(wg % 8) == x].mean()) for x in range(8)]
