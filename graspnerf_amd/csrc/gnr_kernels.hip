@@ -730,6 +730,12 @@ constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
                                 // empty goes on with the next XCD's -- MEASURED NEGATIVE (profiles/r06_c_dyn_tiles_ab.json: step 6.40 -> 6.83 ms, render launches
                                 // 2.28 -> 2.58 ms: the time between two tiles of a wavefront goes from 2.4 % to 6.7 % of its life)
 #endif
+#ifndef GNR_DYN_CTR_INC
+#define GNR_DYN_CTR_INC 0
+#endif
+#ifndef GNR_DYN_TRAIN
+#define GNR_DYN_TRAIN 1       // 1: the training-forward volume instantiation too; 2: and the render one (measured negative); 0: inference only
+#endif
 #ifndef GNR_SKIP_MASKED
 #define GNR_SKIP_MASKED 1      // skip the (tile, view) pairs without a single valid point (inference kernels)
 #endif
@@ -831,17 +837,32 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     // 75 % of a volume launch), and a slot that stands empty while its SIMD partner finishes alone is the launch's tail: mean
     // wavefront life 0.88 (volume) / 0.85 (render) of the launch with static shares.  The next index is fetched one stage ahead
     // (after the second view loop), so its latency is hidden; the order in which an XCD sweeps its chunk is unchanged.
-    const bool dyn = GNR_DYN_TILES != 0 && a.tile_ctr != nullptr;
-    int cx = xcd, hops = 0;                                // the chunk this wavefront draws from; chunks it has found empty
+    // (the training-forward render instantiation keeps its static shares: five tiles per wavefront at 8 scenes, and the fetch's wait drains
+    // the state stores in front of it -- 378 us per launch static, 412 dynamic; the volume one gains 2 %: profiles/r06_c_dyn_tiles_ab.json)
+    const bool dyn = GNR_DYN_TILES != 0 && (GNR_DYN_TRAIN > 1 || !(SAVE && RENDER)) && (GNR_DYN_TRAIN != 0 || !SAVE) && a.tile_ctr != nullptr;
+    int cx = xcd;                                          // the chunk this wavefront draws from
+    // (GNR_DYN_CTR_INC 1: atomicInc instead of atomicAdd.  The compiler's atomic optimiser rewrites a uniform atomicAdd under a lane mask into
+    // its wave-aggregated form, whose broadcast -- s_waitcnt vmcnt(0) + v_readfirstlane -- sits right behind the instruction, so the fetch is
+    // waited for in the middle of the tile; a wrapping increment with the bound 2^32 - 1 is the same operation, is left alone, and with the
+    // index pinned in its vector register until the end of the tile the wait moves there.  MEASURED NEGATIVE: render launches 2.35 -> 2.46 ms,
+    // volume launch unchanged -- the other wavefront of the SIMD covers the wait, the longer live range costs the render instantiation more.)
+#if GNR_DYN_CTR_INC
+    auto grab = [&]() -> unsigned { unsigned t = 0u; if (lane == 0) t = atomicInc(a.tile_ctr + cx, 0xFFFFFFFFu); return t; };
+#else
     auto grab = [&]() -> unsigned { unsigned t = 0u; if (lane == 0) t = atomicAdd(a.tile_ctr + cx, 1u); return t; };
-    auto resolve = [&](unsigned t_raw) -> int {            // fetched index -> tile, walking on while the chunk is exhausted; -1: nothing left
+#endif
+    auto resolve = [&](unsigned t_raw) -> int {            // fetched index -> tile; -1: nothing left
         int t = __builtin_amdgcn_readfirstlane((int)t_raw);
-        while (t >= min(ntiles, (cx + 1) * chunk) - cx * chunk) {
-            if (++hops >= (GNR_DYN_TILES > 1 ? NXCD : 1)) return -1;
+#if GNR_DYN_TILES > 1
+        for (int hops = 0; t >= min(ntiles, (cx + 1) * chunk) - cx * chunk;) {      // measured negative: walk on to the next XCD's chunk
+            if (++hops >= NXCD) return -1;
             cx = cx + 1 == NXCD ? 0 : cx + 1;
             t = __builtin_amdgcn_readfirstlane((int)grab());
         }
         return cx * chunk + t;
+#else
+        return t < t_end - xcd * chunk ? xcd * chunk + t : -1;
+#endif
     };
     int tile = dyn ? resolve(grab()) : xcd * chunk + lblk * waves_per_block + wave;
     for (; dyn ? tile >= 0 : tile < t_end;) {
@@ -1376,6 +1397,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #if GNR_WAVE_CLOCK
         if constexpr (SP && !SAVE) { const unsigned long long wc_e = wall_clock64(); ++wc_n; wc_ph[0] += wc_p1 - wc_tt; wc_ph[1] += wc_p2 - wc_p1; wc_ph[2] += wc_p3 - wc_p2; wc_ph[3] += wc_e - wc_p3;
             if (lane == 0 && tile < (1 << 17)) g_tile_clock[RENDER ? 1 : 0][tile] = (unsigned)(wc_e - wc_tt); }
+#endif
+#if GNR_DYN_CTR_INC
+        if (dyn) asm volatile("" : "+v"(tile_nxt));       // the fetched index stays in its vector register until here
 #endif
         tile = dyn ? resolve(tile_nxt) : tile + nlblk * waves_per_block;
     }
