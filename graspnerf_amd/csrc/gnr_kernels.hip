@@ -730,6 +730,10 @@ constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
                                 // empty goes on with the next XCD's -- MEASURED NEGATIVE (profiles/r06_c_dyn_tiles_ab.json: step 6.40 -> 6.83 ms, render launches
                                 // 2.28 -> 2.58 ms: the time between two tiles of a wavefront goes from 2.4 % to 6.7 % of its life)
 #endif
+#ifndef GNR_DESC_PREFETCH
+#define GNR_DESC_PREFETCH 0      // 1: the next tile's point descriptors are loaded behind the second view loop (eight registers carried through the tile's tail).
+                                 // MEASURED NEGATIVE: step 6.45 -> 6.55 ms, render launches 2.28 -> 2.35 (scratch 72 -> 108 B, volume 12 -> 48 B)
+#endif
 #ifndef GNR_DYN_CTR_INC
 #define GNR_DYN_CTR_INC 0
 #endif
@@ -864,15 +868,10 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         return t < t_end - xcd * chunk ? xcd * chunk + t : -1;
 #endif
     };
-    int tile = dyn ? resolve(grab()) : xcd * chunk + lblk * waves_per_block + wave;
-    for (; dyn ? tile >= 0 : tile < t_end;) {
-        GNR_ITER_FENCE();
-        unsigned tile_nxt = 0u;
-#if GNR_WAVE_CLOCK
-        const unsigned long long wc_tt = wall_clock64();
-#endif
-        const int b = tile / tps;
-        int ts = tile - b * tps;
+    // scene and (brick-permuted) tile-in-scene of a tile of the list
+    auto locate = [&](int tile_, int& b_, int& ts_) {
+        b_ = tile_ / tps;
+        ts_ = tile_ - b_ * tps;
         if (a.vol_res > 0) {
             // Volume points are stored column-major (x, y, then z top->down).  Visit them in bricks of
             // (R/4) x (R/4) columns instead of whole x-planes: at R = 40 a brick (100 columns, 250 tiles) is what the
@@ -882,11 +881,26 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
             // Bijection on 2-column groups (2R points = R/8 tiles); requires R % 8 == 0 (host checks).
             const int R = a.vol_res, tpg = R >> 3, gpr = R >> 1;
             const int BX = R >> 2, GY = R >> 3, GB = BX * GY;             // a plane = 4 x 4 bricks of (R/4) x (R/4) columns
-            const int sidx = ts / tpg, tin = ts - sidx * tpg;
+            const int sidx = ts_ / tpg, tin = ts_ - sidx * tpg;
             const int brick = sidx / GB, wi = sidx - brick * GB;
             const int bx = brick >> 2, by = brick & 3;
-            ts = ((BX * bx + wi / GY) * gpr + GY * by + wi % GY) * tpg + tin;
+            ts_ = ((BX * bx + wi / GY) * gpr + GY * by + wi % GY) * tpg + tin;
         }
+    };
+    auto point_of = [&](int b_, int ts_) -> size_t { const int nr = ts_ * 16 + r; return (size_t)b_ * a.P + (nr < a.P ? nr : a.P - 1); };
+    int tile = dyn ? resolve(grab()) : xcd * chunk + lblk * waves_per_block + wave;
+    constexpr bool DPF = GNR_DESC_PREFETCH != 0 && !SAVE;      // the next tile's point descriptors are fetched behind the second view loop
+    f4 d0n = {0.f, 0.f, 0.f, 0.f}, d1n = d0n;
+    bool have_nxt = false;                                  // wave-uniform
+    for (; dyn ? tile >= 0 : tile < t_end;) {
+        GNR_ITER_FENCE();
+        unsigned tile_nxt = 0u;
+        int tile_after = -1;
+#if GNR_WAVE_CLOCK
+        const unsigned long long wc_tt = wall_clock64();
+#endif
+        int b, ts;
+        locate(tile, b, ts);
         const int n_raw = ts * 16 + r;
         const bool row_ok = n_raw < a.P;
         const int n = row_ok ? n_raw : a.P - 1;
@@ -898,7 +912,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         }
         float p[3], qd[3], lo, hi;
         {
-            const f4 d0 = reinterpret_cast<const f4*>(a.desc)[pt * 2], d1 = reinterpret_cast<const f4*>(a.desc)[pt * 2 + 1];
+            f4 d0, d1;
+            if (DPF && have_nxt) { d0 = d0n; d1 = d1n; }
+            else { d0 = reinterpret_cast<const f4*>(a.desc)[pt * 2]; d1 = reinterpret_cast<const f4*>(a.desc)[pt * 2 + 1]; }
             p[0] = d0.x; p[1] = d0.y; p[2] = d0.z; qd[0] = d0.w; qd[1] = d1.x; qd[2] = d1.y; lo = d1.z; hi = d1.w;
         }
         constexpr int VA = rows_a(V), VB = rows_b(V);
@@ -1314,6 +1330,16 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         const unsigned long long wc_p3 = wall_clock64();
 #endif
         if (dyn) tile_nxt = grab();
+        if constexpr (DPF) {
+            tile_after = dyn ? resolve(tile_nxt) : tile + nlblk * waves_per_block;
+            have_nxt = dyn ? tile_after >= 0 : tile_after < t_end;
+            if (have_nxt) {
+                int bn, tsn;
+                locate(tile_after, bn, tsn);
+                const size_t ptn = point_of(bn, tsn);
+                d0n = reinterpret_cast<const f4*>(a.desc)[ptn * 2]; d1n = reinterpret_cast<const f4*>(a.desc)[ptn * 2 + 1];
+            }
+        }
 
         // ================= cross-view reduction 2 (ibrnet.py:482-484,488) + colour blend (:510-511)
         float Z[23];
@@ -1401,7 +1427,8 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #if GNR_DYN_CTR_INC
         if (dyn) asm volatile("" : "+v"(tile_nxt));       // the fetched index stays in its vector register until here
 #endif
-        tile = dyn ? resolve(tile_nxt) : tile + nlblk * waves_per_block;
+        if constexpr (DPF) tile = have_nxt ? tile_after : (dyn ? -1 : t_end);
+        else tile = dyn ? resolve(tile_nxt) : tile + nlblk * waves_per_block;
     }
     if (dyn && lane == 0) {        // the launch's last wavefront (every other one has made its last, failing, fetches) re-arms the counters for the next launch
         if (atomicAdd(a.tile_ctr + 8, 1u) == gridDim.x * (unsigned)waves_per_block - 1u) {
