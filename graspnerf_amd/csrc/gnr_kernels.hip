@@ -308,10 +308,16 @@ DEV void range_watch(float& word, const f4& a) {   // a: an output block of a pa
 // 2e-7 ... 2e-5, at one and at two wavefronts per SIMD) -- a dependency the compiler's hazard tables (ROCm 7.2) do not
 // cover; tails are zero-padded into a K32 block instead.
 // WATCH: the B operands are not bounded by construction (range guard, RangeWatch)
+#ifndef GNR_MFMA_PRIO
+#define GNR_MFMA_PRIO 0      // measurement builds: 1 = the younger half of a workgroup (wavefronts 4-7) at s_setprio 1 for the whole kernel; 2 = s_setprio 1 around every pair-form MFMA cluster
+#endif
 template <int KB, int NB, bool LF, bool WATCH = false>
 DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, f4 (&acc)[NB], float* rw = nullptr) {
     if constexpr (LF) asm volatile("" ::: "memory");
     const h8* w8 = reinterpret_cast<const h8*>(w) + lane;
+#if GNR_MFMA_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         f4 lo = {0.f, 0.f, 0.f, 0.f};
@@ -334,6 +340,9 @@ DEV void mm16(const float* __restrict__ w, int lane, const P8* __restrict__ x8, 
         acc[nb].z = fmaf(lo.z, kPairSi, acc[nb].z); acc[nb].w = fmaf(lo.w, kPairSi, acc[nb].w);
 #endif
     }
+#if GNR_MFMA_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if constexpr (WATCH) range_watch(*rw, acc[GNR_WATCH_LAST ? NB - 1 : 0]);
 }
 // the same layer on unscaled activation pairs: three products into ONE accumulator (the k-blocks outermost, so that
@@ -342,6 +351,9 @@ template <int KB, int NB, bool LF, bool WATCH = false>
 DEV void mm16u(const float* __restrict__ w, int lane, const P8U* __restrict__ x8, f4 (&acc)[NB], float* rw = nullptr) {
     if constexpr (LF) asm volatile("" ::: "memory");
     const h8* w8 = reinterpret_cast<const h8*>(w) + lane;
+#if GNR_MFMA_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         h8 wh[NB], wm[NB];
@@ -354,6 +366,9 @@ DEV void mm16u(const float* __restrict__ w, int lane, const P8U* __restrict__ x8
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32h(wm[nb], x8[kb].s, acc[nb]);
     }
+#if GNR_MFMA_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if constexpr (WATCH) range_watch(*rw, acc[0]);
 }
 
@@ -817,6 +832,9 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if GNR_MFMA_PRIO == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #if GNR_WAVE_CLOCK
     const unsigned long long wc_t1 = wall_clock64();
     unsigned long long wc_n = 0, wc_ph[4] = {0, 0, 0, 0};
