@@ -61,7 +61,7 @@ class HotPath:
 
     def set_option(self, name, on=True):
         """Switch one of the per-call options (_lib.OPTIONS: fp32_chain, feature_grad_fixed, view1_one_wavefront, view2_one_wavefront,
-        ray_order_morton, poison_partials, direct_scatter, geo_dual_fp32, test_lose_partner) for the calls of THIS HotPath; -> previous."""
+        ray_order_morton, poison_partials, direct_scatter, geo_dual_fp32, test_lose_partner, static_tiles) for the calls of THIS HotPath; -> previous."""
         bit = _lib.OPTIONS[name]
         prev = bool(self.options & bit)
         self.options = (self.options | bit) if on else (self.options & ~bit)
