@@ -209,7 +209,7 @@ class HotPath:
             co_s, co = self._alloc_out(B, rn, dn, 'imgs' in que, False, rays.ray_batch_num)
             _lib.check(self.L.gnr_render_rays_fwd(self._sc(scene), C.byref(rays), self.wc.data_ptr(), None, C.byref(co_s), None, None, None,
                                                   ws.data_ptr(), ws.numel(), self._stream()), 'gnr_render_rays_fwd')
-            co['ray_mask'] = co['ray_mask'].bool()
+            co['ray_mask'] = co['ray_mask'].view(torch.bool)
             return co, None
         if self.wf is None:
             raise _lib.GnrError('render() needs the fine-level weights')
@@ -228,7 +228,7 @@ class HotPath:
                                               inds.data_ptr() if debug else None,
                                               ws.data_ptr(), ws.numel(), self._stream()), 'gnr_render_rays_fwd')
         for o in (co, fi):
-            o['ray_mask'] = o['ray_mask'].bool()
+            o['ray_mask'] = o['ray_mask'].view(torch.bool)       # the kernels write 0 / 1 bytes: a view, not a conversion kernel
         return (co, fi, inds) if debug else (co, fi)
 
     def render_by_depth(self, ref, que, depth, level='coarse', cfg=None, debug=False, prepared=None):
@@ -242,7 +242,7 @@ class HotPath:
         _lib.check(self.L.gnr_render_by_depth_fwd(self._sc(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(),
                                                   C.byref(o_s), ws.data_ptr(), ws.numel(), self._stream()),
                    'gnr_render_by_depth_fwd')
-        o['ray_mask'] = o['ray_mask'].bool()
+        o['ray_mask'] = o['ray_mask'].view(torch.bool)       # the kernels write 0 / 1 bytes: a view, not a conversion kernel
         return o
 
     def merge_depths(self, a, b):
@@ -406,7 +406,7 @@ class HotPath:
         _lib.check(self.L.gnr_render_tail_fwd_train(self._sc(scene), C.byref(rays), depth.data_ptr(), dn, w.data_ptr(), C.byref(o_s),
                                                     fd.data_ptr() if want_fine_depth else None, ws.data_ptr(), ws.numel(),
                                                     tws.data_ptr(), tws.numel(), self._stream()), 'gnr_render_tail_fwd_train')
-        o['ray_mask'] = o['ray_mask'].bool()
+        o['ray_mask'] = o['ray_mask'].view(torch.bool)       # the kernels write 0 / 1 bytes: a view, not a conversion kernel
         o.pop('depth'), o.pop('view_mask')
         if want_fine_depth:
             o['fine_depth'] = fd
