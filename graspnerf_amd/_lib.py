@@ -20,7 +20,7 @@ class GnrScene(C.Structure):
 
 # per-call options (GnrScene.options; the `options` argument of gnr_ray_tail_dual_bwd / gnr_geo_dual_bwd): include/gnr.h GNR_OPT_*
 OPTIONS = {'fp32_chain': 0x001, 'feature_grad_fixed': 0x002, 'view1_one_wavefront': 0x004, 'view2_one_wavefront': 0x008,
-           'ray_order_morton': 0x010, 'poison_partials': 0x020, 'direct_scatter': 0x040, 'geo_dual_fp32': 0x080, 'test_lose_partner': 0x100, 'static_tiles': 0x200}
+           'ray_order_morton': 0x010, 'poison_partials': 0x020, 'direct_scatter': 0x040, 'geo_dual_fp32': 0x080, 'test_lose_partner': 0x100, 'static_tiles': 0x200, 'split_launch': 0x400}
 GNR_STATUS_LOST_PARTNER = 16
 
 

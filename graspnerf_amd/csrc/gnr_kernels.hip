@@ -610,6 +610,7 @@ struct ChainArgs {
     // dynamic tile hand-out (null: static round-robin).  [x] = next tile of XCD x's chunk, [8] = wavefronts of the launch that are through:
     // zero before the first launch (gnr_prepare), set back to zero by the last wavefront of every launch
     unsigned* tile_ctr;
+    int b0;                // first scene of the launch (a launch over a part of the batch: scenes b0 .. b0 + B - 1 of every array)
 };
 
 struct ViewGeom {          // per (point, view) quantities that are cheap to recompute
@@ -744,6 +745,9 @@ constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
 #define GNR_DYN_TILES 1         // k_chain takes its tiles from a per-XCD counter (ChainArgs::tile_ctr); 0: static round-robin shares; 2: a wavefront whose XCD's chunk is
                                 // empty goes on with the next XCD's -- MEASURED NEGATIVE (profiles/r06_c_dyn_tiles_ab.json: step 6.40 -> 6.83 ms, render launches
                                 // 2.28 -> 2.58 ms: the time between two tiles of a wavefront goes from 2.4 % to 6.7 % of its life)
+#endif
+#ifndef GNR_TAIL_OLD_ONLY
+#define GNR_TAIL_OLD_ONLY 0      // in quarters of the XCD's wavefront count: 4 = the last 256 tiles of a 256-wavefront XCD
 #endif
 #ifndef GNR_DESC_PREFETCH
 #define GNR_DESC_PREFETCH 0      // 1: the next tile's point descriptors are loaded behind the second view loop (eight registers carried through the tile's tail).
@@ -890,6 +894,7 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
     auto locate = [&](int tile_, int& b_, int& ts_) {
         b_ = tile_ / tps;
         ts_ = tile_ - b_ * tps;
+        b_ += a.b0;
         if (a.vol_res > 0) {
             // Volume points are stored column-major (x, y, then z top->down).  Visit them in bricks of
             // (R/4) x (R/4) columns instead of whole x-planes: at R = 40 a brick (100 columns, 250 tiles) is what the
@@ -1347,7 +1352,15 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
 #if GNR_WAVE_CLOCK
         const unsigned long long wc_p3 = wall_clock64();
 #endif
-        if (dyn) tile_nxt = grab();
+        if (dyn) {
+            // GNR_TAIL_OLD_ONLY: the younger half of a workgroup (wavefronts 4-7: the SIMD issues them second, a tile takes them ~1.5x as long)
+            // leaves the chunk's last tiles to the older half -- a wavefront whose current index is within TAIL_K of the chunk's end fetches no further one
+            bool more = true;
+#if GNR_TAIL_OLD_ONLY
+            if (wave >= 4) more = (t_end - tile) > (GNR_TAIL_OLD_ONLY * nlblk * waves_per_block) / 4;
+#endif
+            tile_nxt = more ? grab() : 0x7fffffffu;
+        }
         if constexpr (DPF) {
             tile_after = dyn ? resolve(tile_nxt) : tile + nlblk * waves_per_block;
             have_nxt = dyn ? tile_after >= 0 : tile_after < t_end;

@@ -73,6 +73,9 @@ typedef struct GnrScene {
  *   GNR_OPT_STATIC_TILES        the chain launches of the call give every wavefront its static round-robin share of the tiles instead of
  *                               handing the tiles out through the workspace's per-XCD counters (round 6; bit-identical outputs, the
  *                               launches' tails are longer: tests, measurements)
+ *   GNR_OPT_SPLIT_LAUNCH        (experiment) gnr_sample_volume_fwd runs the two halves of the batch as two launch sequences on two streams (the
+ *                               caller's and a library-owned one, joined before the call returns its stream), so that each half's
+ *                               launches fill the other's tails; bit-identical outputs
  *   GNR_OPT_TEST_LOSE_PARTNER   (tests) the partner wavefronts of k_view1_bwd_pw / k_view2_bwd_pw return at once: the compute wavefronts'
  *                               bounded waits give up, the call's gradients are garbage and bit 4 of gnr_range_status says so */
 #define GNR_OPT_FP32_CHAIN 0x001u
@@ -85,7 +88,8 @@ typedef struct GnrScene {
 #define GNR_OPT_GEO_DUAL_FP32 0x080u
 #define GNR_OPT_TEST_LOSE_PARTNER 0x100u
 #define GNR_OPT_STATIC_TILES 0x200u
-#define GNR_OPT_ALL 0x3ffu
+#define GNR_OPT_SPLIT_LAUNCH 0x400u
+#define GNR_OPT_ALL 0x7ffu
 
 /* Query rays of B scenes.  Replaces the `que_imgs_info` dict (imgs_info.py:126-135). */
 typedef struct GnrRays {

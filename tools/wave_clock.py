@@ -53,6 +53,9 @@ for which, name in ((0, 'volume'), (1, 'render (the step\'s last launch: the fin
              tile_us_p95=float(np.percentile(tt, 95)), tile_us_max=float(tt.max()),
              sum_tile_over_life=float(tt.sum() / life.sum()))
     r['phase_us_per_tile'] = {k: float(w[:, 4 + j].sum() * 0.01 / ntile) for j, k in enumerate(('head + view loop 1', 'reduction 1 + hoist', 'view loop 2', 'reduction 2 + geometry_fc + record'))}
+    widx = (np.arange(4096) % 8)[keep]
+    r['tiles_per_wave_by_index_in_workgroup'] = [float(n[widx == k].mean()) for k in range(8)]
+    r['end_us_after_launch_start_by_index'] = [float((t2[widx == k].mean() - t0.min()) * 0.01) for k in range(8)]
     # per XCD (workgroup b -> XCD b % 8): when its last wavefront ends, relative to the launch start
     r['xcd_end_us'] = [float((t2[(wg % 8) == x].max() - t0.min()) * 0.01) for x in range(8)]
     r['xcd_mean_life_us'] = [float(life[(wg % 8) == x].mean()) for x in range(8)]
