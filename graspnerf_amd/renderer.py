@@ -276,7 +276,9 @@ class NeuralRayRenderer(nn.Module):
             ('disable_view_dir', not c['disable_view_dir']),
             ('volume_type', list(c.get('volume_type', ['sdf'])) == ['sdf'])) if not ok]
         if unsupported:
-            # Not configured by the reference's only yaml.  disable_view_dir cannot run in the reference either with
+            # Not configured by the reference's only yaml.  agg_net_type 'default' (the density branch) does not run in the reference either:
+            # network_rendering (renderer.py:93) passes every aggregation net five arguments, DefaultAggregationNet.forward (aggregate_net.py:78)
+            # takes four -> TypeError at the first render (tools/probe_agg_default.py, tests/golden/ref_agg_default_probe.json).  disable_view_dir cannot run in the reference either with
             # agg_net_type neus (aggregate_net.py:126 unpacks que_dir.shape of None), and volume_type ['alpha'] raises in the
             # reference's own call (renderer.py:190 -> network_rendering :100 "ValueError: too many values to unpack (expected 2)":
             # the neus aggregation returns five values; recorded by tools/make_goldens.py --no-hier-only in

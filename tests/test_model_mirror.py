@@ -281,6 +281,23 @@ def test_without_hierarchical_sampling_the_fine_level_does_not_exist():
     assert str(G['volume_type_alpha']).startswith('raises ValueError')        # why volume_type ['alpha'] stays refused here
 
 
+def test_agg_net_type_default_is_refused_because_the_reference_cannot_run_it():
+    """agg_net_type 'default' (the density branch, renderer.py:21,98-100 / aggregate_net.py:72-85 / ibrnet.py:240-371) is the reference's
+    base_cfg default but NOT a runnable configuration: network_rendering (renderer.py:93) calls every aggregation net with five arguments
+    and DefaultAggregationNet.forward (aggregate_net.py:78) takes four -- recorded from the imported reference by tools/probe_agg_default.py
+    (tests/golden/ref_agg_default_probe.json).  The mirror refuses the option at construction instead of at the first render."""
+    import copy, json
+    from graspnerf_amd.renderer import GraspNeRF
+    probe = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'ref_agg_default_probe.json')))
+    for rec in probe.values():
+        assert rec['runs'] is False and rec['exception'].startswith('TypeError: DefaultAggregationNet.forward() takes from 3 to 5 positional arguments but 6 were given')
+        assert rec['raised_at'][-1].startswith('src/nr/network/renderer.py:93')
+    cfg = copy.deepcopy(CFG)
+    cfg['agg_net_type'] = 'default'
+    with pytest.raises(NotImplementedError, match='agg_net_type'):
+        GraspNeRF(cfg)
+
+
 @pytest.mark.gpu
 def test_without_hierarchical_sampling_matches_reference():
     """cfg use_hierarchical_sampling: false (the reference's base_cfg default, renderer.py:22,153-162): forward returns the coarse
