@@ -87,3 +87,27 @@ def test_training_forward_is_unchanged_by_the_hand_out(weights_np):
     assert torch.equal(vol_d, vol_s)
     for a, b in zip(saves_d, saves_s):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize('B', [2, 5])
+def test_split_launch_option_is_bitwise_the_single_stream_call(B, weights_np):
+    """GNR_OPT_SPLIT_LAUNCH (experiment, measured +1 %: kept as an option): the volume call's two half-batches on the caller's stream and the
+    library's side stream, joined before the call hands the stream back -- same volume and masks bit for bit, odd batch sizes included, and the
+    next call on the caller's stream sees the finished result without any synchronisation of its own."""
+    hp, batch_scenes = _hot(weights_np)
+    ref, _ = batch_scenes([make_scene(i, 'cfg2', with_query_image=False) for i in range(B)])
+    ref = {k: torch.from_numpy(v).cuda() for k, v in ref.items()}
+    prep = hp.prepare(ref, 40)
+    v0, m0 = hp.sample_volume(ref, 40, want_mask=True, prepared=prep)
+    v0, m0 = v0.clone(), m0.clone()
+    hp.set_option('split_launch', True)
+    try:
+        for _ in range(3):
+            v1, m1 = hp.sample_volume(ref, 40, want_mask=True, prepared=prep)
+            s = v1.sum()                                  # a consumer on the caller's stream right behind the call
+        torch.cuda.synchronize()
+    finally:
+        hp.set_option('split_launch', False)
+    assert torch.equal(v0.view(torch.int32), v1.view(torch.int32)) and torch.equal(m0, m1)
+    assert float(s) == float(v0.sum())
+    assert int(_counters(hp, prep)[:32].abs().sum()) == 0
