@@ -610,6 +610,8 @@ struct ChainArgs {
     // dynamic tile hand-out (null: static round-robin).  [x] = next tile of XCD x's chunk, [8] = wavefronts of the launch that are through:
     // zero before the first launch (gnr_prepare), set back to zero by the last wavefront of every launch
     unsigned* tile_ctr;
+    const float* bbox_min; // volume launches of the inference path: [B][3]; the points are computed in the kernel (k_points_volume's arithmetic), desc is not read
+    int pts_R;             // grid resolution of those points (0: read desc)
     int b0;                // first scene of the launch (a launch over a part of the batch: scenes b0 .. b0 + B - 1 of every array)
 };
 
@@ -745,6 +747,9 @@ constexpr int rows_b(int V) { return GNR_TWO_QUEUES ? V / 2 : 0; }
 #define GNR_DYN_TILES 1         // k_chain takes its tiles from a per-XCD counter (ChainArgs::tile_ctr); 0: static round-robin shares; 2: a wavefront whose XCD's chunk is
                                 // empty goes on with the next XCD's -- MEASURED NEGATIVE (profiles/r06_c_dyn_tiles_ab.json: step 6.40 -> 6.83 ms, render launches
                                 // 2.28 -> 2.58 ms: the time between two tiles of a wavefront goes from 2.4 % to 6.7 % of its life)
+#endif
+#ifndef GNR_VOLUME_POINTS_INLINE
+#define GNR_VOLUME_POINTS_INLINE 1
 #endif
 #ifndef GNR_TAIL_OLD_ONLY
 #define GNR_TAIL_OLD_ONLY 0      // in quarters of the XCD's wavefront count: 4 = the last 256 tiles of a 256-wavefront XCD
@@ -937,6 +942,18 @@ __global__ __launch_bounds__(GNR_CHAIN_THREADS, GNR_CHAIN_MIN_BLOCKS) void k_cha
         {
             f4 d0, d1;
             if (DPF && have_nxt) { d0 = d0n; d1 = d1n; }
+            else if (!RENDER && !SAVE && GNR_VOLUME_POINTS_INLINE != 0 && a.pts_R > 0) {
+                // the grid point of voxel n of scene b, as k_points_volume writes it (field_utils.py:17-27: float64 arithmetic, then the cast;
+                // renderer.py:167-170: + bbox_min, z from the top down): one launch and one exposed load per tile less
+                const int R = a.pts_R;
+                const float invR = 1.f / (float)R;
+                const int col = (int)(((float)n + 0.5f) * invR), sz = n - col * R;          // exact for n < 2^22
+                const int ix = (int)(((float)col + 0.5f) * invR), iy = col - ix * R, iz = R - 1 - sz;
+                const double vs = 0.3 / (double)R, hv = vs / 2;
+                const float* bm = a.bbox_min + b * 3;
+                d0 = (f4){(float)(ix * vs + hv) + bm[0], (float)(iy * vs + hv) + bm[1], (float)(iz * vs + hv) + bm[2], 0.f};
+                d1 = (f4){0.f, 1.f, 0.005f, 0.005f};
+            }
             else { d0 = reinterpret_cast<const f4*>(a.desc)[pt * 2]; d1 = reinterpret_cast<const f4*>(a.desc)[pt * 2 + 1]; }
             p[0] = d0.x; p[1] = d0.y; p[2] = d0.z; qd[0] = d0.w; qd[1] = d1.x; qd[2] = d1.y; lo = d1.z; hi = d1.w;
         }
