@@ -536,7 +536,8 @@ __global__ __launch_bounds__(256) void k_ray_order(const float* __restrict__ coo
 __global__ void k_points_rays(const float* __restrict__ coords, const float* __restrict__ que_pose,
                               const float* __restrict__ que_K, const float* __restrict__ que_dr,
                               const float* __restrict__ depth, float* __restrict__ desc, int rn, int dn, int B,
-                              const int* __restrict__ perm = nullptr) {
+                              const int* __restrict__ perm = nullptr, float* __restrict__ depth_gen = nullptr) {
+    // depth_gen: the coarse pass -- the depths are k_coarse_depth's (same arithmetic), computed here and written to depth_gen; `depth` is not read
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * rn * dn) return;
     const int b = i / (rn * dn), slot = (i / dn) % rn, k = i % dn;
@@ -552,11 +553,21 @@ __global__ void k_points_rays(const float* __restrict__ coords, const float* __r
         const float rc = P[c] * cam[0] + P[4 + c] * cam[1] + P[8 + c] * cam[2];
         dir[c] = __fsub_rn(__fadd_rn(rc, tr[c]), tr[c]);          // render_ops.py:22-23
     }
-    const float* z = depth + ((size_t)b * rn + ray) * dn;
-    const float zk = z[k];
+    const float* zp = depth_gen ? nullptr : depth + ((size_t)b * rn + ray) * dn;
+    const float dnear = que_dr[b * 2], dfar = que_dr[b * 2 + 1];
+    auto z = [&](int j) -> float {
+        if (!depth_gen) return zp[j];
+        const float diff = __fsub_rn(__fdiv_rn(1.f, dfar), __fdiv_rn(1.f, dnear));              // k_coarse_depth (render_ops.py:146-170, random_sample False)
+        float tick = __fmul_rn(__fdiv_rn(diff, (float)(dn - 1)), (float)j);
+        if (j == 0) tick = 0.f;
+        if (j == dn - 1) tick = diff;
+        return __fdiv_rn(1.f, __fadd_rn(__fdiv_rn(1.f, dnear), tick));
+    };
+    const float zk = z(k);
+    if (depth_gen) depth_gen[((size_t)b * rn + ray) * dn + k] = zk;
     const float nrm = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-    const float near = -1.f / que_dr[b * 2], far = -1.f / que_dr[b * 2 + 1];
-    auto inv = [&](int j) { return __fdiv_rn(__fsub_rn(__fdiv_rn(-1.f, z[j]), near), __fsub_rn(far, near)); };
+    const float near = -1.f / dnear, far = -1.f / dfar;
+    auto inv = [&](int j) { return __fdiv_rn(__fsub_rn(__fdiv_rn(-1.f, z(j)), near), __fsub_rn(far, near)); };
     auto half = [&](int j) { return (j == dn - 1) ? 0.5e6f : __fmul_rn(__fsub_rn(inv(j + 1), inv(j)), 0.5f); };
     float* d = desc + (size_t)i * DESC_FLOATS;
     for (int c = 0; c < 3; ++c) {
@@ -2222,8 +2233,9 @@ __global__ void k_gerr_reduce(const float* __restrict__ part, float* __restrict_
 }
 
 // pixel_colors_gt: bilinear, zeros padding, align_corners=True  (renderer.py:125-127, ops.py:29-33)
+// out2: nullable second copy of the result (the coarse and the fine pass of one call render the same rays: one launch serves both)
 __global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restrict__ coords, float* __restrict__ out,
-                           int rn, int H, int W, int B) {
+                           int rn, int H, int W, int B, float* __restrict__ out2 = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * rn) return;
     const int b = i / rn;
@@ -2236,8 +2248,10 @@ __global__ void k_pixel_gt(const float* __restrict__ imgs, const float* __restri
     for (int c = 0; c < 3; ++c) {
         const float* im = imgs + ((size_t)b * 3 + c) * H * W;
         auto tap = [&](int yy, int xx) { return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? im[yy * W + xx] : 0.f; };
-        out[(size_t)i * 3 + c] = tap(y0i, x0i) * (1.f - wx1) * (1.f - wy1) + tap(y0i, x0i + 1) * wx1 * (1.f - wy1) +
-                                 tap(y0i + 1, x0i) * (1.f - wx1) * wy1 + tap(y0i + 1, x0i + 1) * wx1 * wy1;
+        const float v = tap(y0i, x0i) * (1.f - wx1) * (1.f - wy1) + tap(y0i, x0i + 1) * wx1 * (1.f - wy1) +
+                        tap(y0i + 1, x0i) * (1.f - wx1) * wy1 + tap(y0i + 1, x0i + 1) * wx1 * wy1;
+        out[(size_t)i * 3 + c] = v;
+        if (out2) out2[(size_t)i * 3 + c] = v;
     }
 }
 
