@@ -61,6 +61,12 @@ def weights_np():
 
 
 @pytest.fixture(scope='session')
+def weights_trained_np():
+    """Hot-path weights after 1 000 optimiser steps of this repository's own trainer (tools/train_probe.py; same keys as weights_seed0)."""
+    return dict(np.load(os.path.join(GOLDEN, 'weights_trained_probe.npz')))
+
+
+@pytest.fixture(scope='session')
 def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, f'golden_{name}.npz')))

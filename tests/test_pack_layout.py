@@ -632,3 +632,23 @@ def test_rm_section_encodes_the_vjp_tail_of_k_ray(weights_np):
                     assert np.isinf(ga[0, nb, lane, e]) and ga[0, nb, lane, e] > 0          # no fp16 pair
                 else:
                     assert abs(ga[0, nb, lane, e] - G2[c, h]) <= tol(G2[c, h]), ('RM_GEOA', nb, lane, e)
+
+
+def test_optimiser_moved_weights_fixture_is_what_the_probe_wrote(weights_np, weights_trained_np):
+    """tests/golden/weights_trained_probe.npz (tools/train_probe.py: 1 000 Adam steps of this repository's trainer on the GPU; record in
+    profiles/r06_g_train_probe.json): the hot-path tensors of weights_seed0 by name and shape, finite, moved by the optimiser, every one
+    inside the fp16-pair range of the packer, and no sampled training step tripped the range guard or was skipped."""
+    import json
+    assert list(weights_trained_np) == list(weights_np)
+    for k, v in weights_np.items():
+        t = weights_trained_np[k]
+        assert t.shape == v.shape and t.dtype == np.float32 and np.isfinite(t).all(), k
+    for lvl in ('coarse', 'fine'):
+        blob = weights.pack_state_dict(weights_trained_np, lvl)
+        assert np.isfinite(blob).all()                              # (a weight without an fp16 pair is stored as inf by the pair packer)
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'r06_g_train_probe.json')))
+    assert rec['steps'] == 1000 and rec['status_bits_or_over_sampled_steps'] == 0 and rec['skipped_optimizer_steps'] == 0
+    # how far the optimiser moved the tensors from the trainer's own initialisation (synth.synth_state_dict, not weights_seed0)
+    assert 0.05 < rec['median_rel_change'] < 1.0 and rec['max_rel_change'] > 0.5
+    for k, t in weights_trained_np.items():
+        assert abs(float(np.abs(t).max()) - rec['tensors'][k]['absmax_after']) <= 1e-6 * max(1.0, rec['tensors'][k]['absmax_after']), k

@@ -218,6 +218,20 @@ CFG_FULL = {'depth_sample_num': 40, 'fine_depth_sample_num': 40}
 
 @pytest.mark.parametrize('case', ['cfg2 scene alone', 'scenes 0 and 17 of the B=32 bench batch'])
 def test_fp64_arbiter_benched_shape(case, weights_np):
+    _arbiter_benched_shape(case, weights_np)
+
+
+def test_fp64_arbiter_on_weights_an_optimiser_has_moved(weights_trained_np, weights_np):
+    """The same arbiter, same bounds, on hot-path weights after 1 000 Adam steps of this repository's trainer (tools/train_probe.py: HIP path in
+    both directions, the reference's losses, synthetic scenes; lr 1e-3: the tensors moved by a median of 17 % and up to 170 % from the trainer's initialisation -- recorded in
+    profiles/r06_g_train_probe.json, where no sampled step's forward or backward tripped the range guard).  Not a trained GraspNeRF -- there is
+    none in this environment -- but weights whose dynamic ranges an optimiser chose, not a seeded generator: the pair form's distance from
+    float64 stays within the fp32 oracle's, and no launch falls back to its fp32 twin."""
+    assert set(weights_trained_np) == set(weights_np) and all(np.isfinite(v).all() for v in weights_trained_np.values())
+    _arbiter_benched_shape('cfg2 scene alone', weights_trained_np, tag=' [optimiser-moved weights]')
+
+
+def _arbiter_benched_shape(case, weights_np, tag=''):
     """The same arbiter at the shape bench.py times (BASELINE configs[1] / configs[2]): 6 views of 288x512, 40^3 voxels, 512 rays x
     (40 coarse + 40 fine) samples -- where the unscaled-residual floor of the inner layers (gnr_kernels.hip GNR_UNSCALED_ACT) meets
     6-view statistics.  |HIP pair form - fp64| against |fp32 oracle - fp64| over every voxel and every coarse / fine sample (the fine
@@ -259,7 +273,7 @@ def test_fp64_arbiter_benched_shape(case, weights_np):
             rows.append(('fine ' + k, fi[k][s], r32[k + '_fine'].numpy().astype(np.float64), r64[k + '_fine'].numpy()))
         for name, hip, o32, o64 in rows:
             qh, qo = _quantiles(hip.astype(np.float64).reshape(o64.shape) - o64), _quantiles(o32.reshape(o64.shape) - o64)
-            PARITY_LOG.append({'what': f'fp64 arbiter, benched shape ({case}, scene {ids[s]}): {name}', 'hip_pairs_vs_fp64': qh,
+            PARITY_LOG.append({'what': f'fp64 arbiter, benched shape ({case}, scene {ids[s]}){tag}: {name}', 'hip_pairs_vs_fp64': qh,
                                'fp32_oracle_vs_fp64': qo, 'rms_ratio': qh['rms'] / (qo['rms'] + 1e-30), 'p99_ratio': qh['p99'] / (qo['p99'] + 1e-30),
                                'max_abs_err': qh['max'], 'max_over_tol': qh['rms'] / (1.5 * qo['rms'] + 1e-12)})
             assert qh['rms'] <= 1.5 * qo['rms'] + 1e-7, (case, s, name, qh, qo)
