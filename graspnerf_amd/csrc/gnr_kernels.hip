@@ -1583,6 +1583,31 @@ DEV void head_logits_s(const float (&qs)[16], const float* __restrict__ Kj, floa
     }
 }
 
+// the same logits with the softmax shift as the seed of each dot product's FMA chain (SD): s_h - shift_h in four instructions per
+// head instead of five, and one rounding less.  The seeded chain and the plain one differ by the rounding of the partial sums, so a
+// row whose shift is its EXACT maximum (found with the plain chain) must subtract it from the plain chain too: only then is the
+// largest exponent exactly 0 whatever the magnitude of the logits -- k_ray's `exact` rows run with SD = false.  (GNR_RAY_SEED=0: never seeded.)
+#ifndef GNR_RAY_SEED
+#define GNR_RAY_SEED 1
+#endif
+template <bool SD>
+DEV void head_logits_shifted(const float (&qs)[16], const float* __restrict__ Kj, const float (&shift)[4], float (&s)[4]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const f4 k = reinterpret_cast<const f4*>(Kj)[h];
+        if constexpr (SD && GNR_RAY_SEED)
+            s[h] = fmaf(qs[4 * h + 3], k.w, fmaf(qs[4 * h + 2], k.z, fmaf(qs[4 * h + 1], k.y, fmaf(qs[4 * h], k.x, -shift[h]))));
+        else
+            s[h] = (qs[4 * h] * k.x + qs[4 * h + 1] * k.y + qs[4 * h + 2] * k.z + qs[4 * h + 3] * k.w) - shift[h];
+    }
+}
+// a . b - c for float4 a, b the same way
+template <bool SD = true>
+DEV float dot4_minus(float a0, float a1, float a2, float a3, const f4& b, float c) {
+    if constexpr (SD && GNR_RAY_SEED) return fmaf(a3, b.w, fmaf(a2, b.z, fmaf(a1, b.y, fmaf(a0, b.x, -c))));
+    else return (a0 * b.x + a1 * b.y + a2 * b.z + a3 * b.w) - c;
+}
+
 #ifndef GNR_RAY_UNROLL
 #define GNR_RAY_UNROLL 1
 #endif
@@ -1633,7 +1658,7 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
     constexpr int KNS = 4;
     float* Qb = OVL ? sc : sc + dn * 36;              // [dn][16]   (RENDER, column pass)
     float* Ob = OVL ? sc + dn * 16 : sc + dn * 52;    // [dn][16]   dO
-    float* St = OVL ? sc + dn * 32 : sc + dn * 68;    // [dn][12]   shift[4] (log2 domain), 1/sum[4], rs[4]
+    float* St = OVL ? sc + dn * 32 : sc + dn * 68;    // [dn][12]   shift[4] (log2 domain), rs[4] / sum[4] (dO is stored divided by the row sum as well); a workgroup with an `exact` row: shift, rs, 1/sum
     (void)Qb; (void)St; (void)Ob;
     const size_t pt = (size_t)ray * dn + i;
     // the ray in the caller's order (RENDER with sorted descriptors): index of every user-visible array
@@ -1715,27 +1740,34 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
     // accumulators of the sweeps are float4 per head: the compiler issues them as v_pk_fma_f32 (two lanes of fp32 per
     // instruction; no MFMA in this kernel, so the packed form is a gain here)
     float o[16], ainv[4];
+    bool exact = false;
     {
         float l[4];
         f4 o4[4];
-        auto sweep = [&]() {
+        auto sweep = [&](auto seeded) {
+            constexpr bool SD = decltype(seeded)::value;
 #pragma unroll
             for (int h = 0; h < 4; ++h) { l[h] = 0.f; o4[h] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll UA
             for (int j = 0; j < dn; ++j) {
                 float sj[4];
-                head_logits_s(qs, Kb + j * 16, sj);
+                head_logits_shifted<SD>(qs, Kb + j * 16, amax, sj);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
-                    const float pj = __builtin_amdgcn_exp2f(sj[h] - amax[h]);
+                    const float pj = __builtin_amdgcn_exp2f(sj[h]);
                     l[h] += pj;
                     o4[h] += pj * vj;
                 }
             }
         };
-        sweep();
-        if (!(fminf(fminf(l[0], l[1]), fminf(l[2], l[3])) > 1e-30f)) {      // rare: exact row maxima, second sweep
+        sweep(std::true_type{});
+        // Rare: a second sweep on the exact row maxima (`exact`: plain chain, see head_logits_shifted) -- when the bound was so loose
+        // that a head's row sum fell below 2^-40 (this also bounds 1 / l <= 1.1e12, which the VJP below multiplies into dO and rs before
+        // the column pass: no overflow for |dO| < 3e26), or when the logits are so large (bound > 2^22) that the rounding of the dot
+        // product could lift an exponent above the Cauchy-Schwarz bound by whole units.
+        if (!(fminf(fminf(l[0], l[1]), fminf(l[2], l[3])) > 9.0e-13f) || fmaxf(fmaxf(amax[0], amax[1]), fmaxf(amax[2], amax[3])) > 4194304.f) {
+            exact = true;
 #pragma unroll
             for (int h = 0; h < 4; ++h) amax[h] = -3.0e38f;
             for (int j = 0; j < dn; ++j) {
@@ -1744,7 +1776,7 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
 #pragma unroll
                 for (int h = 0; h < 4; ++h) amax[h] = fmaxf(amax[h], sj[h]);
             }
-            sweep();
+            sweep(std::false_type{});
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -1816,23 +1848,32 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
             f4 A1[4];
 #pragma unroll
             for (int h = 0; h < 4; ++h) A1[h] = (f4){0.f, 0.f, 0.f, 0.f};
+            // FAST: shift / rs as the seeds of the FMA chains, P un-normalised (1 / l_i multiplies the finished sum).  !FAST (the lane's row
+            // is `exact`): the plain chains and the normalised P of the forward's second sweep -- for a row that is (nearly) one-hot,
+            // dA_ij - rs_i then cancels EXACTLY on the key that holds the weight, whatever the magnitudes (rs_i = dO_i . o_i is the same
+            // chain over the same numbers); a seeded chain would leave the rounding of a huge dA times a huge k there.
+            auto row_pass = [&](auto fast) {
+                constexpr bool FAST = decltype(fast)::value;
 #pragma unroll UB
-            for (int j = 0; j < dn; ++j) {
-                float sj[4];
-                head_logits_s(qs, Kb + j * 16, sj);
+                for (int j = 0; j < dn; ++j) {
+                    float sj[4];
+                    head_logits_shifted<FAST>(qs, Kb + j * 16, amax, sj);
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
-                    const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
-                    const float pj = __builtin_amdgcn_exp2f(sj[h] - amax[h]) * ainv[h];
-                    const float dA = dO[4 * h] * vj.x + dO[4 * h + 1] * vj.y + dO[4 * h + 2] * vj.z + dO[4 * h + 3] * vj.w;
-                    A1[h] += (pj * (dA - rsv[h])) * kj;
+                    for (int h = 0; h < 4; ++h) {
+                        const f4 kj = reinterpret_cast<const f4*>(Kb + j * 16)[h];
+                        const f4 vj = reinterpret_cast<const f4*>(Vb + j * 16)[h];
+                        float pj = __builtin_amdgcn_exp2f(sj[h]);
+                        if constexpr (!FAST) pj *= ainv[h];
+                        const float dAr = dot4_minus<FAST>(dO[4 * h], dO[4 * h + 1], dO[4 * h + 2], dO[4 * h + 3], vj, rsv[h]);      // dA_ij - rs_i
+                        A1[h] += (pj * dAr) * kj;
+                    }
                 }
-            }
+            };
+            if (exact) row_pass(std::false_type{}); else row_pass(std::true_type{});
             const float sc2 = rowok ? 0.5f : 0.f;       // masked query rows: d logits = 0
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const f4 d4 = A1[h] * sc2;
+                const f4 d4 = A1[h] * (exact ? sc2 : sc2 * ainv[h]);
                 dQ[4 * h] = d4.x; dQ[4 * h + 1] = d4.y; dQ[4 * h + 2] = d4.z; dQ[4 * h + 3] = d4.w;
             }
         }
@@ -1844,11 +1885,21 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
                 vv[4 * c] = v4.x; vv[4 * c + 1] = v4.y; vv[4 * c + 2] = v4.z; vv[4 * c + 3] = v4.w;
             }
         }
+        // The barrier carries a vote: ONE `exact` query row among the workgroup's rays sends every lane of the workgroup through the
+        // plain column pass (lanes that shadow a ray beyond the launch ran on stale LDS: they do not vote).
+        __shared__ int exact_wave[4];
+        {
+            const bool w_exact = __ballot(exact && act) != 0ull;
+            if ((threadIdx.x & 63) == 0) exact_wave[threadIdx.x >> 6] = w_exact ? 1 : 0;
+        }
         __syncthreads();                                  // every lane is past the row pass (and the key-norm sweep): K / V / KN are free
+        const bool any_exact = (exact_wave[0] | exact_wave[1] | exact_wave[2] | exact_wave[3]) != 0;
         if (act) {
+            // fast column pass: dO_i / l_i and rs_i / l_i are stored, so that it needs no 1 / l_i per (query, head); plain: dO, 1 / l, rs
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f4 d4 = {dO[4 * c], dO[4 * c + 1], dO[4 * c + 2], dO[4 * c + 3]};
+                const float sc = any_exact ? 1.f : ainv[c];
+                const f4 d4 = {dO[4 * c] * sc, dO[4 * c + 1] * sc, dO[4 * c + 2] * sc, dO[4 * c + 3] * sc};
                 reinterpret_cast<f4*>(Ob + i * 16)[c] = d4;
                 if constexpr (OVL) {
                     const f4 q4 = {qs[4 * c], qs[4 * c + 1], qs[4 * c + 2], qs[4 * c + 3]};
@@ -1856,10 +1907,10 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
                 }
             }
             const f4 m4 = {amax[0], amax[1], amax[2], amax[3]}, i4 = {ainv[0], ainv[1], ainv[2], ainv[3]};
-            const f4 r4 = {rsv[0], rsv[1], rsv[2], rsv[3]};
+            const f4 r4 = any_exact ? (f4){rsv[0], rsv[1], rsv[2], rsv[3]} : (f4){rsv[0] * ainv[0], rsv[1] * ainv[1], rsv[2] * ainv[2], rsv[3] * ainv[3]};
             reinterpret_cast<f4*>(St + i * 12)[0] = m4;
-            reinterpret_cast<f4*>(St + i * 12)[1] = i4;
-            reinterpret_cast<f4*>(St + i * 12)[2] = r4;
+            reinterpret_cast<f4*>(St + i * 12)[1] = r4;
+            if (any_exact) reinterpret_cast<f4*>(St + i * 12)[2] = i4;
         }
         __syncthreads();
         // column pass (lane = key j = i): dK_j = sum_i dL_ij q_i / 2 ; dV_j = sum_i P_ij dO_i
@@ -1870,22 +1921,28 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
             f4 dK4[4], dV4[4];
 #pragma unroll
             for (int h = 0; h < 4; ++h) { dK4[h] = (f4){0.f, 0.f, 0.f, 0.f}; dV4[h] = (f4){0.f, 0.f, 0.f, 0.f}; }
+            auto col_pass = [&](auto fast) {
+                constexpr bool FAST = decltype(fast)::value;
 #pragma unroll UB
-            for (int qi = 0; qi < dn; ++qi) {
-                const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
-                const f4 il4 = reinterpret_cast<const f4*>(St + qi * 12)[1];
-                const f4 rs4 = reinterpret_cast<const f4*>(St + qi * 12)[2];
+                for (int qi = 0; qi < dn; ++qi) {
+                    const f4 mx4 = reinterpret_cast<const f4*>(St + qi * 12)[0];
+                    const f4 rs4 = reinterpret_cast<const f4*>(St + qi * 12)[1];
+                    f4 il4 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (!FAST) il4 = reinterpret_cast<const f4*>(St + qi * 12)[2];
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const f4 qv = reinterpret_cast<const f4*>(Qb + qi * 16)[h];
-                    const f4 dov = reinterpret_cast<const f4*>(Ob + qi * 16)[h];
-                    const float s = qv.x * kk[4 * h] + qv.y * kk[4 * h + 1] + qv.z * kk[4 * h + 2] + qv.w * kk[4 * h + 3];
-                    const float pj = __builtin_amdgcn_exp2f(s - mx4[h]) * il4[h];
-                    const float dA = dov.x * vv[4 * h] + dov.y * vv[4 * h + 1] + dov.z * vv[4 * h + 2] + dov.w * vv[4 * h + 3];
-                    dK4[h] += (pj * (dA - rs4[h])) * qv;
-                    dV4[h] += pj * dov;
+                    for (int h = 0; h < 4; ++h) {
+                        const f4 qv = reinterpret_cast<const f4*>(Qb + qi * 16)[h];
+                        const f4 dov = reinterpret_cast<const f4*>(Ob + qi * 16)[h];
+                        const float s = dot4_minus<FAST>(qv.x, qv.y, qv.z, qv.w, (f4){kk[4 * h], kk[4 * h + 1], kk[4 * h + 2], kk[4 * h + 3]}, mx4[h]);   // logit - shift of query qi
+                        float pj = __builtin_amdgcn_exp2f(s);                           // FAST: P_ij l_i (dO and rs arrive divided by l_i)
+                        if constexpr (!FAST) pj *= il4[h];
+                        const float dAr = dot4_minus<FAST>(dov.x, dov.y, dov.z, dov.w, (f4){vv[4 * h], vv[4 * h + 1], vv[4 * h + 2], vv[4 * h + 3]}, rs4[h]);   // dA - rs of query qi
+                        dK4[h] += (pj * dAr) * qv;
+                        dV4[h] += pj * dov;
+                    }
                 }
-            }
+            };
+            if (any_exact) col_pass(std::false_type{}); else col_pass(std::true_type{});
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 dK[4 * h] = dK4[h].x * kLn2; dK[4 * h + 1] = dK4[h].y * kLn2; dK[4 * h + 2] = dK4[h].z * kLn2; dK[4 * h + 3] = dK4[h].w * kLn2;

@@ -19,8 +19,13 @@ below and recorded tensor by tensor (gpurun_out/bwd_arbiter.json -> profiles/). 
 product on fp32 instructions, ARBITER_FP32=1) the table is the same to two digits.
  * cancellation-dominated tensors: the var / aw decoders of the coarse level (gradient norms 10 - 50x below the mean decoder's: their
    upstream is the DIFFERENCE of the two logistic edges of a sample, (far - mean) sech^2(u1) - (near - mean) sech^2(u0) over an interval
-   of 1 / 39 of the range, dist_decoder.py:109-142) amplify the rounding of tanh 40 - 80 times; the path's tanh is 1 - 2 rcp(e^2x + 1) on
-   v_exp_f32 / v_rcp_f32 (~2e-7 absolute) against libm's 6e-8: ratios 2.5 - 13 on ten tensors whose relative error is 3e-5;
+   of 1 / 39 of the range, dist_decoder.py:109-142, and the sum over ~1e6 (view, sample) terms cancels to 1e-8 .. 1e-6): ratios 2.5 - 13 on
+   ten tensors whose relative error is 3e-5.  These are ratios of two rounding errors of ill-conditioned sums, not a deficit of the path:
+   over 1 / 2 / 4 / 8 scenes of the coarse pass the var decoder's bias reads hip 7e-6 / 9e-6 / 2.4e-4 / 2.7e-4 against torch fp32's
+   3.2e-5 / 2.7e-6 / 1.5e-4 / 4.8e-5 (torch is the FARTHER one at one scene), both at an absolute 1e-12 .. 3e-11, while well-conditioned
+   tensors stay at 2e-6 .. 1e-5 on both sides at every size.  (Round 6 first blamed the path's tanh, 1 - 2 rcp(e^2x + 1) on v_exp_f32 /
+   v_rcp_f32 at ~2e-7 against libm's 6e-8; a ~1-ulp tanh with sech^2 = fma(-y, y, 1) in the backward kernels changed no ratio --
+   profiles/r06_h_tanh_experiment.json, docs/experiments/r06_tanh_acc.patch.)
  * one-to-35-element bias tensors at 1.5 - 5: a ratio of two rounding errors of single numbers.
 Gate: every tensor within 16 (a wrong kernel, a lost tile or a bad scale shows as hundreds: the border samples below did), three quarters
 within the forward's (1.5, 2), the median within 1.2, the feature maps within (1.5, 2).
