@@ -11,7 +11,7 @@ ap.add_argument('--no-compile', action='store_true')
 ap.add_argument('--kern', default=r'k_chainILi6ELb[01]ELb0ELb0E')
 ap.add_argument('--flags', default='')
 ap.add_argument('--src', default='graspnerf_amd/csrc/gnr_kernels.hip')
-ap.add_argument('--top', type=int, default=16)
+ap.add_argument("--top", type=int, default=16); ap.add_argument("--min-lines", type=int, default=150)
 ap.add_argument('--dir', default='/tmp/isa')
 a = ap.parse_args()
 os.makedirs(a.dir, exist_ok=True)
@@ -74,7 +74,7 @@ for m in re.finditer(r'\n(_ZN3gnr\d+(%s)\w*):.*?\n\.Lfunc_end\d+:' % a.kern, txt
     print('==', name, '| lines', len(body), '|', info)
     tot = mix(body)
     print('  whole kernel static:', show(tot))
-    big = [(lo, hi) for lo, hi in loops if hi - lo >= 150]
+    big = [(lo, hi) for lo, hi in loops if hi - lo >= a.min_lines]
     # inner view loops = big loops that contain no other big loop; the tile loop is the outermost
     inner = [(lo, hi) for lo, hi in big if not any(l2 > lo and h2 < hi for l2, h2 in big)]
     outer = [(lo, hi) for lo, hi in big if (lo, hi) not in inner]
