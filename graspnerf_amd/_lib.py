@@ -216,6 +216,8 @@ def lib():
     L.gnr_upsample2x_bilinear.restype = C.c_int
     L.gnr_last_error.restype = C.c_char_p
     L.gnr_dominant_kernel_name.restype = C.c_char_p
+    L.gnr_debug_fill_lds.argtypes = [C.c_uint, C.c_void_p]
+    L.gnr_debug_fill_lds.restype = C.c_int
     _lib = L
     return L
 
@@ -230,7 +232,7 @@ EXPORTED = ['gnr_canonical_weights_floats', 'gnr_packed_weights_floats', 'gnr_pa
             'gnr_train_workspace_layout', 'gnr_sample_volume_fwd_train', 'gnr_sample_volume_bwd',
             'gnr_render_chain_train_workspace_bytes', 'gnr_render_chain_fwd_train', 'gnr_render_chain_bwd', 'gnr_conv3d_bwd_weight', 'gnr_conv3d_same_workspace_bytes', 'gnr_conv3d_same', 'gnr_conv3d_tap_mask_words', 'gnr_conv3d_tap_mask', 'gnr_conv3d_same_masked', 'gnr_conv3d_same_bwd_weight_masked', 'gnr_conv3d_same_bwd_weight', 'gnr_conv3d_same_bwd_weight_workspace_bytes',
             'gnr_render_tail_fwd_train', 'gnr_ray_tail_grad_floats', 'gnr_ray_tail_dual_bwd', 'gnr_ray_tail_dual_bwd_workspace_bytes', 'gnr_composite_bwd', 'gnr_composite_bwd_workspace_bytes', 'gnr_geo_dual_fwd', 'gnr_geo_dual_fwd_workspace_bytes', 'gnr_geo_dual_bwd', 'gnr_geo_dual_bwd_workspace_bytes', 'gnr_host_randperm_prefix',
-            'gnr_img_last_error', 'gnr_instnorm_act', 'gnr_instnorm_act_bwd', 'gnr_reflect_pad2d', 'gnr_reflect_pad2d_bwd', 'gnr_upsample2x_bilinear']
+            'gnr_debug_fill_lds', 'gnr_img_last_error', 'gnr_instnorm_act', 'gnr_instnorm_act_bwd', 'gnr_reflect_pad2d', 'gnr_reflect_pad2d_bwd', 'gnr_upsample2x_bilinear']
 
 
 def check(rc, what):

@@ -1889,7 +1889,11 @@ __global__ __launch_bounds__(256, (RENDER ? GNR_RAY_BLOCKS : 2)) void k_ray(RayA
         // plain column pass (lanes that shadow a ray beyond the launch ran on stale LDS: they do not vote).
         __shared__ int exact_wave[4];
         {
+#ifdef GNR_DBG_SHADOW_VOTE      // (the bug as found, for tests/test_range_guard.py::test_a_partly_filled_last_workgroup_...: must FAIL on this build)
+            const bool w_exact = __ballot(exact) != 0ull;
+#else
             const bool w_exact = __ballot(exact && act) != 0ull;
+#endif
             if ((threadIdx.x & 63) == 0) exact_wave[threadIdx.x >> 6] = w_exact ? 1 : 0;
         }
         __syncthreads();                                  // every lane is past the row pass (and the key-norm sweep): K / V / KN are free

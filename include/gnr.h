@@ -507,6 +507,10 @@ int gnr_chain_timing_end(float* avg_ms_out, int* count_out);
 int gnr_time_chain_kernel(const GnrScene* scene, int volume_res, const float* packed_coarse,
                           void* workspace, size_t workspace_bytes, int iters, float* ms_out, void* stream);
 
+/* Test tooling: fill the LDS of every CU with a 32-bit pattern (LDS is not cleared between kernels; a kernel that reads LDS it did
+ * not write would compute on it).  tests/test_range_guard.py runs the path after two patterns and asks for identical bits. */
+int gnr_debug_fill_lds(unsigned pattern, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,3 +244,59 @@ def test_train_step_path_gradients_are_bit_reproducible(feat_same):
     assert len(feat[0]) >= 2
     for k in feat[0]:
         feat_same(feat[1][k], feat[0][k])
+
+
+@pytest.mark.parametrize('pattern', [0x7fc00000, 0x7149f2ca])          # NaN, 1e30
+def test_backward_entry_points_ignore_stale_lds(pattern, weights_np):
+    """LDS is not cleared between kernels: every backward entry point after gnr_debug_fill_lds(0) and after a NaN / 1e30 flood of
+    every CU's LDS (ragged sizes: partly filled tiles and workgroups whose spare lanes shadow valid ones) -- the same bits, in the
+    fixed-point feature-gradient mode also for the feature maps.  (The forward's twin: tests/test_range_guard.py::test_stale_lds_...)"""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    prev = HotPath.default_options
+    HotPath.default_options = prev | _lib.OPTIONS['feature_grad_fixed']
+    try:
+        hp = _hot(weights_np)
+
+        def fill(p):
+            _lib.check(_lib.lib().gnr_debug_fill_lds(p, torch.cuda.current_stream().cuda_stream), 'gnr_debug_fill_lds')
+        # ---- sample_volume backwards (3 views, 16^3, 2 scenes)
+        dvol = _volume_case(hp, 3, 16, 2)
+        vols = []
+        for p in (0, pattern):
+            fill(p)
+            vols.append([x.clone() for x in hp.sample_volume_bwd(dvol, hp.can_dev['coarse'])])
+        for a, b in zip(*vols):
+            assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+        # ---- one fine render pass backwards (3 views, 33 rays x 16 samples, 2 scenes)
+        rn, dn, B = 33, 16, 2
+        bref, bque = batch_scenes([make_scene(70 + i, dict(CONFIGS['cfg1'], V=3, rn=rn)) for i in range(B)])
+        prep = hp.prepare(bref, 1, rn, dn)
+        rng = np.random.default_rng(rn)
+        depth = torch.sort(torch.from_numpy(rng.uniform(0.25, 0.75, (B, rn, dn)).astype(np.float32)), -1)[0].cuda()
+        cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+        bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
+        t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+        ds, dc, a_, gamma = t(B, rn * dn, 65), t(B, rn * dn, 3), t(B * rn, dn), t(B * rn, dn, 3)
+        dpix, wg = t(B * rn, 3), torch.full((B * rn,), 1e-3, device='cuda')
+        canon = hp.can_dev['fine']
+
+        def once(p):
+            fill(p); stats, colors, geo, ctx = hp.render_chain_train(bq, depth, 'fine', cfg, prep)
+            fill(p); fw = hp.render_tail_train(ctx, bq, depth, colors)
+            st = stats.reshape(B * rn * dn, 66)
+            fill(p); dcan, dray, dimg = hp.render_chain_bwd(ctx, ds, dc)
+            fill(p); g, gd = hp.geo_dual_fwd(canon, st, geo['pts'], gamma.reshape(-1, 3))
+            fill(p); gbar, gdbar, dt = hp.ray_tail_dual_bwd('fine', g.reshape(B * rn, dn, 16), gd.reshape(B * rn, dn, 16), a_, st[:, 65].reshape(B * rn, dn))
+            fill(p); dstats, dgeo = hp.geo_dual_bwd(canon, st, geo['pts'], gamma.reshape(-1, 3), gbar.reshape(-1, 16), gdbar.reshape(-1, 16))
+            fill(p); comp = hp.composite_bwd('fine', fw['sdf_values'].reshape(B * rn, dn), fw['sdf_gradient'].reshape(B * rn, dn, 3),
+                                             colors.reshape(B * rn, dn, 3), depth.reshape(B * rn, dn), geo['qdir'], dpix, None, wg, a_, None)
+            return dict(stats=stats.clone(), colors=colors.clone(), sdf=fw['sdf_values'].clone(), grad=fw['sdf_gradient'].clone(), dcan=dcan.clone(),
+                        dray=dray.clone(), dimg=dimg.clone(), g=g.clone(), gd=gd.clone(), gbar=gbar.clone(), dt=dt.clone(), dstats=dstats.clone(),
+                        dgeo=dgeo.clone(), a=comp[0].clone(), gamma=comp[1].clone(), dvar=comp[3].clone())
+        r0, r1 = once(0), once(pattern)
+        torch.cuda.synchronize()
+        for k, v in r0.items():
+            assert bool(torch.isfinite(v).all()), k
+            assert torch.equal(v, r1[k]), k
+    finally:
+        HotPath.default_options = prev

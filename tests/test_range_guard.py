@@ -138,6 +138,38 @@ def test_a_weight_without_an_fp16_pair_runs_on_the_fp32_twin(weights_np):
     _check_fallback(hp, w, ref, que, 4, 'mean_decoder.0 weight = 1e5')
 
 
+@pytest.mark.parametrize('rn', [64, 50])
+def test_stale_lds_does_not_reach_the_outputs(rn, weights_np):
+    """LDS is not cleared between kernels.  64 rays of 16 samples are 14 rays per k_ray workgroup: the last workgroup holds eight
+    rays and six ray slots whose lanes shadow the last ray on LDS nobody wrote.  Those lanes take part in the barriers -- and, since
+    round 6, would take part in the workgroup's vote for the plain-chain column pass (csrc/gnr_kernels.hip: `exact`): they must not,
+    or the last rays' SDF gradients depend on what earlier kernels left behind (found as a one-ulp difference between a launch and
+    its repeat that only showed after the x3000 scene had run; a build with -DGNR_DBG_SHADOW_VOTE=1 fails here).  The whole forward
+    after gnr_debug_fill_lds(0), after a NaN pattern and after 1e30: the same bits, SDF gradient included."""
+    from graspnerf_amd import _lib
+    from graspnerf_amd.hotpath import batch_scenes
+    ref, que = make_scene(0, 'cfg1')
+    que = dict(que, coords=que['coords'][:rn])
+    hp = _hp(weights_np)
+    bref, bque = batch_scenes([(ref, que)])
+
+    def run(pattern):
+        prep = hp.prepare(bref, 16, rn, 16)
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().gnr_debug_fill_lds(pattern, s), 'gnr_debug_fill_lds')
+        vol = hp.sample_volume(bref, 16, prepared=prep)
+        _lib.check(_lib.lib().gnr_debug_fill_lds(pattern, s), 'gnr_debug_fill_lds')
+        co, fi = hp.render(bref, bque, CFG, debug=True, prepared=prep)[:2]
+        assert hp.range_status(prep) == 0
+        return {**{'coarse ' + k: v.cpu().numpy() for k, v in co.items()}, **{'fine ' + k: v.cpu().numpy() for k, v in fi.items()}, 'volume': vol.cpu().numpy()}
+    zero = run(0)
+    assert 'coarse sdf_gradient' in zero and np.isfinite(zero['coarse sdf_gradient']).all()
+    for pattern in (0x7fc00000, 0x7149f2ca):          # NaN, 1e30
+        got = run(pattern)
+        for k in zero:
+            assert np.array_equal(zero[k], got[k], equal_nan=True), (hex(pattern), k)
+
+
 @pytest.mark.parametrize('key,ij', [('agg_impl.geometry_fc.2.weight', (3, 5)), ('agg_impl.ray_attention.w_ks.weight', (2, 9)),
                                     ('agg_impl.geometry_fc.0.weight', (7, 70))])
 def test_a_k_ray_weight_without_an_fp16_pair_runs_on_the_fp32_twin(key, ij, weights_np):
