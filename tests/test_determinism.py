@@ -300,3 +300,61 @@ def test_backward_entry_points_ignore_stale_lds(pattern, weights_np):
             assert torch.equal(v, r1[k]), k
     finally:
         HotPath.default_options = prev
+
+
+def _fill_allocations(monkeypatch, byte):
+    """torch.empty hands out memory filled with `byte` (0xff: every float a NaN, every index -1) for the rest of the test: workspaces,
+    output arrays, scratch -- whatever graspnerf_amd/hotpath.py allocates without initialising."""
+    real = torch.empty
+
+    def filled(*a, **k):
+        t = real(*a, **k)
+        if t.is_cuda and t.numel():
+            t.view(torch.uint8).fill_(byte) if t.is_contiguous() else None
+        return t
+    monkeypatch.setattr(torch, 'empty', filled)
+
+
+def test_nothing_reads_memory_it_did_not_write(weights_np, monkeypatch):
+    """The forward (volume + both render passes with their debug outputs) and a training render pass with its backward on freshly
+    allocated workspaces / outputs / scratch filled with 0x00 and with 0xff bytes (NaNs): the same bits, everything finite -- no kernel
+    reads a workspace region, a partial slot or an output array before something wrote it."""
+    from graspnerf_amd.hotpath import HotPath, batch_scenes
+    prev = HotPath.default_options
+    HotPath.default_options = prev | _lib.OPTIONS['feature_grad_fixed']
+    try:
+        rn, dn, B = 50, 16, 2
+        bref, bque = batch_scenes([make_scene(70 + i, dict(CONFIGS['cfg1'], V=3, rn=rn)) for i in range(B)])
+        rng = np.random.default_rng(5)
+        depth_np = np.sort(rng.uniform(0.25, 0.75, (B, rn, dn)).astype(np.float32), -1)
+        up = {k: rng.standard_normal(s).astype(np.float32) for k, s in (('dvol', (B, 1, 16, 16, 16)), ('ds', (B, rn * dn, 65)), ('dc', (B, rn * dn, 3)))}
+        cfg = {'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8}
+
+        def run(byte):
+            _fill_allocations(monkeypatch, byte)
+            hp = _hot(weights_np)
+            out = {}
+            prep = hp.prepare(bref, 16, rn, dn)
+            out['volume'] = hp.sample_volume(bref, 16, prepared=prep)
+            co, fi = hp.render(bref, bque, cfg, debug=True, prepared=prep)[:2]
+            out.update({'coarse ' + k: v for k, v in co.items()}); out.update({'fine ' + k: v for k, v in fi.items()})
+            hp.sample_volume_train(bref, 16)
+            dcan, dray, dimg = hp.sample_volume_bwd(torch.from_numpy(up['dvol']).cuda(), hp.can_dev['coarse'])
+            out.update(vol_dcan=dcan, vol_dray=dray, vol_dimg=dimg)
+            prep2 = hp.prepare(bref, 1, rn, dn)
+            bq = {k: torch.from_numpy(v).cuda() for k, v in bque.items() if k != 'imgs'}
+            depth = torch.from_numpy(depth_np).cuda()
+            stats, colors, geo, ctx = hp.render_chain_train(bq, depth, 'fine', cfg, prep2)
+            fw = hp.render_tail_train(ctx, bq, depth, colors)
+            dcan2, dray2, dimg2 = hp.render_chain_bwd(ctx, torch.from_numpy(up['ds']).cuda(), torch.from_numpy(up['dc']).cuda())
+            out.update(stats=stats, colors=colors, sdf=fw['sdf_values'], grad=fw['sdf_gradient'], dcan=dcan2, dray=dray2, dimg=dimg2)
+            torch.cuda.synchronize()
+            assert hp.range_status(prep) == 0 and hp.range_status(prep2) & 7 == 0
+            return {k: v.clone() for k, v in out.items() if v is not None}
+        a, b = run(0x00), run(0xff)
+        for k, v in a.items():
+            if v.dtype.is_floating_point:
+                assert bool(torch.isfinite(v).all()), k
+            assert torch.equal(v, b[k]), k
+    finally:
+        HotPath.default_options = prev
