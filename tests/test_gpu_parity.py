@@ -351,10 +351,11 @@ def test_random_geometry_sweep(seed, hot, W):
     assert np.array_equal(o['ray_mask'].cpu().numpy()[0][rays], ref_o['ray_mask'].numpy()[0][rays])
 
 
-@pytest.mark.parametrize('scale', [6.0, 40.0])
+@pytest.mark.parametrize('scale', [6.0, 40.0, 160.0])
 def test_attention_with_peaked_softmax(scale, weights_np):
-    """Attention projections scaled up: logits of +-hundreds (one-hot softmax).  The kernel shifts the softmax by the
-    Cauchy-Schwarz bound |q||k|/2 and must fall back to the exact row maximum when that bound underflows a whole row."""
+    """Attention projections scaled up: logits of +-hundreds (one-hot softmax; x160: +-thousands).  The kernel shifts the softmax by the
+    Cauchy-Schwarz bound |q||k|/2 and must fall back to the exact row maximum when that bound underflows a whole row or exceeds 2^12
+    (round 6: such `exact` rows, and the workgroups that hold one, keep the plain FMA chains in all three sweeps of k_ray)."""
     from graspnerf_amd.hotpath import HotPath
     wn = dict(weights_np)
     for lvl in ('agg_net', 'fine_agg_net'):
